@@ -206,6 +206,8 @@ class RefHanabiEnv:
         self.players = lib.NumPlayers(C.byref(self.game))
         self.num_moves = lib.MaxMoves(C.byref(self.game))
         self.num_colors = lib.NumColors(C.byref(self.game))
+        self.num_ranks = lib.NumRanks(C.byref(self.game))
+        self.hand_size = lib.HandSize(C.byref(self.game))
         self.obs_len = int(self._str(lib.ObservationShape(C.byref(self.enc))))
         self.own_len = int(self._str(lib.OwnHandShape(C.byref(self.enc))))
         self.state = None

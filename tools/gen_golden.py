@@ -1,0 +1,292 @@
+#!/usr/bin/env python3
+"""tools/gen_golden.py -- generate tests/golden/*.npz from the GENUINE reference (oracle/_ref/*.so).
+
+Runs only in the authoring container (needs /root/reference to build oracle/_ref via `make -C oracle ref`).
+The fixtures are DATA: inputs and the reference's outputs.  No reference source travels with them.
+
+  tree_<name>.npz   inputs (noises, root logits, legal, fake-net tables) and, per simulation, the reference's
+                    (ix, iy, last_action), path length, min/max stats; final visit distributions, root values,
+                    greedy trajectories and root priors.       [core/ctree via oracle/ref_tree_harness.cpp]
+  env_<game>.npz    per (seed, policy) episode streams: actions and the reference's reward/done/score/state
+                    probe/legal mask/share_obs bits after reset and after every step, >=3 episodes per game
+                    object so the per-game mt19937 carries across reset.        [envs/hanabi via C API]
+  nets_<game>.npz   reference MuZeroNet / MuZeroNetFull (config/hanabi_control/model.py, loaded by file path)
+                    state_dict + inputs + initial/recurrent inference outputs, CPU fp32, eval mode.
+
+Usage: python tools/gen_golden.py [--only tree|env|nets]
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle.ref import RefTree, RefHanabiEnv, ref_available, _hanabi, _Handle  # noqa: E402
+import ctypes as C  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+PB_C_BASE, PB_C_INIT, DISCOUNT, DELTA, FRAC = 19652, 1.25, 0.999, 0.006, 0.25  # core/config.py:107-111
+
+
+# ------------------------------------------------------------------------------------------- tree
+def gen_tree(name, N, A, S, family, seed, tie_seed):
+    rng = np.random.RandomState(seed)
+    noises = rng.dirichlet([0.3] * A, N).astype(np.float32)
+    legal = (rng.rand(N, A) < 0.6).astype(np.int32)
+    legal[np.arange(N), rng.randint(0, A, N)] = 1
+    if family == "all_legal":
+        legal[:] = 1
+    root_logits = rng.randn(N, A).astype(np.float32)
+    root_rewards = np.zeros(N, np.float32)  # core/model.py:71
+    rewards = rng.randint(-3, 4, (S - 1, N)).astype(np.float32) * (rng.rand(S - 1, N) < 0.3)
+    values = (rng.rand(S - 1, N) * 25).astype(np.float32)
+    logits = rng.randn(S - 1, N, A).astype(np.float32)
+    with_noise = 1
+    if family == "init_zero":  # zero-initialised heads: config/hanabi_control/model.py:151-156
+        root_logits[:] = 0
+        rewards[:] = 0
+        values[:] = 0
+        logits[:] = 0
+    elif family == "nan":
+        root_logits[rng.rand(N, A) < 0.1] = np.nan
+        root_logits[0, :] = np.nan
+        logits[rng.rand(S - 1, N, A) < 0.02] = np.nan
+        values[rng.rand(S - 1, N) < 0.05] = 0
+    elif family == "no_noise":  # core/test.py:93 prepare_no_noise
+        with_noise = 0
+    elif family == "small_delta":  # max-min < value_delta_max branch of cminimax.cpp:35-37
+        rewards[:] = 0
+        values = (1.0 + rng.rand(S - 1, N) * 0.004).astype(np.float32)
+    elif family == "reanalyze":  # reanalyze_worker.py:344-346: noise pre-masked by legal, value prefix as reward
+        noises = noises * legal
+        root_rewards = rng.randn(N).astype(np.float32)
+    rewards = rewards.astype(np.float32)
+
+    t = RefTree(N, A, S, mode=1, seed=tie_seed, value_delta_max=DELTA)
+    if with_noise:
+        t.prepare(FRAC, noises, root_rewards, root_logits, legal)
+    else:
+        t.prepare_no_noise(root_rewards, root_logits, legal)
+    priors = t.root_priors()
+    ixs, iys, las, plens, mins, maxs = [], [], [], [], [], []
+    for sim in range(S - 1):  # core/mcts.py:24-26: the last simulation is skipped
+        ix, iy, la = t.traverse(sim, PB_C_BASE, PB_C_INIT, DISCOUNT)
+        ixs.append(ix), iys.append(iy), las.append(la), plens.append(t.path_len())
+        t.backprop(sim + 1, DISCOUNT, rewards[sim], values[sim], logits[sim])
+        mn, mx = t.minmax()
+        mins.append(mn), maxs.append(mx)
+    out = dict(N=N, A=A, S=S, family=family, tie_seed=np.uint64(tie_seed), with_noise=with_noise,
+               pb_c_base=PB_C_BASE, pb_c_init=np.float32(PB_C_INIT), discount=np.float32(DISCOUNT),
+               value_delta_max=np.float32(DELTA), frac=np.float32(FRAC),
+               noises=noises, root_logits=root_logits, root_rewards=root_rewards, legal=legal,
+               rewards=rewards, values=values, logits=logits,
+               out_root_priors=priors, out_ix=np.array(ixs), out_iy=np.array(iys), out_last_action=np.array(las),
+               out_path_len=np.array(plens), out_min=np.array(mins), out_max=np.array(maxs),
+               out_distributions=t.distributions(), out_values=t.values(), out_trajectories=t.trajectories(S))
+    np.savez_compressed(os.path.join(GOLD, "tree_%s.npz" % name), **out)
+    print("tree_%s: N=%d A=%d S=%d family=%s mean path len %.2f" % (name, N, A, S, family, np.mean(plens)))
+
+
+def check_tree_equivalence():
+    """mode 0 (one N-root CRoots, as cytree builds it) == mode 2 (N single-root CRoots), both with rand()==0."""
+    N, A, S = 64, 20, 50
+    rng = np.random.RandomState(3)
+    noises = rng.dirichlet([0.3] * A, N).astype(np.float32)
+    legal = (rng.rand(N, A) < 0.6).astype(np.int32)
+    legal[:, 0] = 1
+    logits0 = rng.randn(N, A).astype(np.float32)
+    a, b = RefTree(N, A, S, mode=0), RefTree(N, A, S, mode=2)
+    for t in (a, b):
+        t.prepare(FRAC, noises, np.zeros(N), logits0, legal)
+    for sim in range(S - 1):
+        ra, rb = a.traverse(sim, PB_C_BASE, PB_C_INIT, DISCOUNT), b.traverse(sim, PB_C_BASE, PB_C_INIT, DISCOUNT)
+        for x, y in zip(ra, rb):
+            assert (x == y).all()
+        r, v, l = rng.rand(N).astype(np.float32), (rng.rand(N) * 9).astype(np.float32), rng.randn(N, A).astype(np.float32)
+        a.backprop(sim + 1, DISCOUNT, r, v, l), b.backprop(sim + 1, DISCOUNT, r, v, l)
+    assert (a.distributions() == b.distributions()).all()
+    assert (a.values().view(np.uint32) == b.values().view(np.uint32)).all()
+    print("reference: one N-root CRoots == N single-root CRoots (rand()==0): OK")
+
+
+# -------------------------------------------------------------------------------------------- env
+class _Card(C.Structure):
+    _fields_ = [("color", C.c_int), ("rank", C.c_int)]
+
+
+def ref_hands(env):
+    lib = _hanabi()
+    lib.StateGetHandCard.argtypes = [C.POINTER(_Handle), C.c_int, C.c_int, C.POINTER(_Card)]
+    hands = []
+    for p in range(env.players):
+        n = lib.StateGetHandSize(C.byref(env.state), p)
+        cards = []
+        for i in range(n):
+            c = _Card()
+            lib.StateGetHandCard(C.byref(env.state), p, i, C.byref(c))
+            cards.append((c.color, c.rank))
+        hands.append(cards)
+    return hands
+
+
+def policy_action(policy, env, legal, rng, step):
+    ids = np.nonzero(legal)[0]
+    if policy == "first":
+        return int(ids[0])
+    if policy == "last":
+        return int(ids[-1])
+    if policy == "hash":
+        return int(ids[(step * 2654435761 + 12345) % len(ids)])
+    if policy == "random":
+        return int(rng.choice(ids))
+    # "smart" / "perfect": look at the true state (the fixture stores the resulting actions, tests only replay them)
+    pr = env.probe()
+    cur, fw = pr["cur_player"], pr["fireworks"]
+    hand = ref_hands(env)[cur]
+    hand_size = env.hand_size
+    playable = [i for i, (c, r) in enumerate(hand) if fw[c] == r]
+    if playable and (policy == "perfect" or rng.rand() < 0.9):
+        return hand_size + playable[0]
+    dead = [i for i, (c, r) in enumerate(hand) if r < fw[c]]
+    hints = [a for a in ids if a >= 2 * hand_size]
+    discards = [a for a in ids if a < hand_size]
+    if policy == "perfect":
+        if discards and dead:
+            return dead[0]
+        if hints:
+            return int(hints[step % len(hints)])
+        if discards:
+            # discard the card with the highest rank (least likely to be needed soon)
+            return int(max(discards, key=lambda a: hand[a][1] if a < len(hand) else -1))
+        return int(ids[0])
+    if hints and rng.rand() < 0.5:
+        return int(rng.choice(hints))
+    if discards:
+        return int(rng.choice(discards))
+    return int(rng.choice(ids))
+
+
+def gen_env(game, seeds, policies, episodes=3):
+    out = {}
+    meta = []
+    for seed in seeds:
+        for policy in policies:
+            env = RefHanabiEnv(game, seed)
+            rng = np.random.RandomState(seed * 7 + 1)
+            acts, rews, dones, scores, probes, legals, obss, boundaries = [], [], [], [], [], [], [], []
+            row = 0
+            for ep in range(episodes):
+                share, _, legal = env.reset()
+                p = env.probe()
+                boundaries.append(row)
+                probes.append([p["cur_player"], p["deck_size"], p["info"], p["life"]] + (p["fireworks"] + [0] * 5)[:5] +
+                              (p["hand_sizes"] + [0] * 5)[:5] + [p["status"], p["score"]])
+                legals.append(legal.astype(np.uint8)), obss.append(share.astype(np.uint8))
+                acts.append(-1), rews.append(0), dones.append(0), scores.append(0)
+                row += 1
+                step, done = 0, False
+                while not done:
+                    a = policy_action(policy, env, legal, rng, step)
+                    share, _, rew, done, score, legal = env.step(a)
+                    p = env.probe()
+                    probes.append([p["cur_player"], p["deck_size"], p["info"], p["life"]] + (p["fireworks"] + [0] * 5)[:5] +
+                                  (p["hand_sizes"] + [0] * 5)[:5] + [p["status"], p["score"]])
+                    legals.append(legal.astype(np.uint8)), obss.append(share.astype(np.uint8))
+                    acts.append(a), rews.append(rew), dones.append(int(done)), scores.append(score)
+                    row += 1
+                    step += 1
+            key = "s%d_%s" % (seed, policy)
+            out[key + "_action"] = np.array(acts, np.int32)       # -1 marks a reset row
+            out[key + "_reward"] = np.array(rews, np.int32)
+            out[key + "_done"] = np.array(dones, np.uint8)
+            out[key + "_score"] = np.array(scores, np.int32)
+            out[key + "_probe"] = np.array(probes, np.int32)
+            out[key + "_legal"] = np.packbits(np.array(legals, np.uint8), axis=1)
+            out[key + "_obs"] = np.packbits(np.array(obss, np.uint8), axis=1)
+            meta.append(key)
+            ends = [probes[b - 1][14] for b in boundaries[1:]] + [probes[-1][14]]
+            print("env %s %s: %d rows, end statuses %s, final scores %s" % (
+                game, key, row, ends, [scores[b - 1] for b in boundaries[1:]] + [scores[-1]]))
+    e = RefHanabiEnv(game, 0)
+    out["keys"] = np.array(meta)
+    out["num_moves"], out["obs_len"], out["own_len"], out["players"] = e.num_moves, e.obs_len, e.own_len, e.players
+    np.savez_compressed(os.path.join(GOLD, "env_%s.npz" % game), **out)
+
+
+# ------------------------------------------------------------------------------------------- nets
+def inverse_scalar_transform(logits, support_min, support_max):
+    """core/config.py:210-232 restated (delta = 1, epsilon = 0.001); the reference module cannot be imported
+    (core/config.py -> core/game.py -> ray)."""
+    import torch
+    probs = torch.softmax(logits, dim=1)
+    support = torch.arange(support_min, support_max + 1, dtype=probs.dtype)
+    value = (support * probs).sum(1, keepdim=True)
+    eps = 0.001
+    sign = torch.ones_like(value)
+    sign[value < 0] = -1.0
+    out = ((torch.sqrt(1 + 4 * eps * (torch.abs(value) + 1 + eps)) - 1) / (2 * eps)) ** 2 - 1
+    out = sign * out
+    out[torch.isnan(out)] = 0.0
+    return out
+
+
+def gen_nets():
+    import importlib.util
+    import torch
+    sys.path.insert(0, "/root/reference")
+    spec = importlib.util.spec_from_file_location("ref_hanabi_model", "/root/reference/config/hanabi_control/model.py")
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    for game, cls, D, A, sup, stack in [("Hanabi-Small", m.MuZeroNet, 193, 11, 25, 1), ("Hanabi-Full", m.MuZeroNetFull, 785, 20, 100, 4)]:
+        torch.manual_seed(0)
+        inv = lambda x, s=sup: inverse_scalar_transform(x, -s, s)
+        net = cls(D * stack, A, 2 * sup + 1, 2 * sup + 1, inv, inv)
+        # weights from the shared recipe (tests/netgold.py): non-zero heads, non-trivial BatchNorm statistics
+        from tests.netgold import fill_state_dict
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in fill_state_dict(net.state_dict()).items()})
+        net.eval()
+        B = 32
+        obs = (torch.rand(B, D * stack) < 0.3).float()
+        with torch.no_grad():
+            o0 = net.initial_inference(obs)
+            act = torch.randint(0, A, (B, 1))
+            o1 = net.recurrent_inference(torch.from_numpy(o0.hidden_state), act)
+        out = dict(sd_keys=np.array(list(net.state_dict().keys())))
+        out.update(obs=obs.numpy(), action=act.numpy(), init_value=o0.value, init_logits=o0.policy_logits,
+                   init_hidden=o0.hidden_state, rec_value=o1.value, rec_reward=o1.reward, rec_logits=o1.policy_logits,
+                   rec_hidden=o1.hidden_state, D=D, A=A, support=sup, stack=stack)
+        np.savez_compressed(os.path.join(GOLD, "nets_%s.npz" % game), **out)
+        print("nets", game, "params", sum(p.numel() for p in net.parameters()))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    assert ref_available(), "run `make -C oracle ref` first (needs /root/reference)"
+    os.makedirs(GOLD, exist_ok=True)
+    if args.only in ("", "tree"):
+        check_tree_equivalence()
+        gen_tree("small_cfg1", 4, 11, 10, "rand", 0, 0)           # BASELINE config 1 shape
+        gen_tree("small_n64", 64, 11, 50, "rand", 1, 0)
+        gen_tree("full_n64", 64, 20, 50, "rand", 2, 0)
+        gen_tree("full5p_n16", 16, 48, 50, "rand", 3, 0)
+        gen_tree("full_init_zero", 64, 20, 50, "init_zero", 4, 0)
+        gen_tree("small_init_zero", 32, 11, 50, "init_zero", 5, 7)
+        gen_tree("full_nan", 32, 20, 50, "nan", 6, 1)
+        gen_tree("full_no_noise", 32, 20, 50, "no_noise", 7, 2)
+        gen_tree("full_small_delta", 32, 20, 50, "small_delta", 8, 3)
+        gen_tree("full_reanalyze", 32, 20, 50, "reanalyze", 9, 4)
+        gen_tree("full_all_legal_s100", 8, 20, 100, "all_legal", 10, 5)
+    if args.only in ("", "env"):
+        gen_env("Hanabi-Small", [0, 1, 7, 123], ["first", "last", "hash", "smart", "perfect"], episodes=4)
+        gen_env("Hanabi-Full", [0, 1, 7, 123], ["first", "last", "hash", "smart", "perfect"], episodes=3)
+        gen_env("Hanabi-Full-5p", [0, 1, 7, 123], ["first", "hash", "smart", "perfect"], episodes=3)
+    if args.only in ("", "nets"):
+        gen_nets()
+
+
+if __name__ == "__main__":
+    main()
