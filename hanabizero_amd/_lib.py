@@ -1,0 +1,70 @@
+"""ctypes binding of libhanabizero_hip.so (the C ABI declared in include/hz_tree.h and include/hz_env.h).
+
+There is NO CPU fallback: if the HIP library is missing or fails to load, importing the product raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhanabizero_hip.so")
+
+
+class HzError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "hanabizero_amd: %s not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    V, I, F, U64, U32, I64 = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_uint32, C.c_int64
+    lib.hz_last_error.restype = C.c_char_p
+    lib.hz_version.restype = I
+    sig = {
+        # include/hz_tree.h
+        "hz_tree_create": [C.POINTER(V), I, I, I, I],
+        "hz_tree_destroy": [V],
+        "hz_tree_set_params": [V, I, F, F, F, U64, U32],
+        "hz_tree_prepare": [V, F, V, V, V, V, V],
+        "hz_tree_traverse": [V, I, V, V, V, V],
+        "hz_tree_traverse_gather": [V, I, V, V, V, V, I, I, V, I, V],
+        "hz_tree_backprop": [V, I, V, V, V, V],
+        "hz_tree_get_distributions": [V, V, V],
+        "hz_tree_get_values": [V, V, V],
+        "hz_tree_get_trajectories": [V, V, I, V],
+        "hz_tree_get_minmax": [V, V, V, V],
+        "hz_tree_get_root_priors": [V, V, V],
+        "hz_tree_get_path_len": [V, V, V],
+        "hz_test_expf": [V, V, I64, V],
+        "hz_test_expf_checksum": [V, V],
+    }
+    for name, argtypes in sig.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = I
+    lib.hz_tree_hbm_bytes.argtypes = [V]
+    lib.hz_tree_hbm_bytes.restype = I64
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise HzError("%s failed (%d): %s" % (what, rc, lib.hz_last_error().decode()))
+
+
+def declared_symbols():
+    """Names every header under include/ declares (used by the CPU-side ABI test)."""
+    import re
+    names = []
+    inc = os.path.join(os.path.dirname(_HERE), "include")
+    for h in sorted(os.listdir(inc)):
+        if not h.endswith(".h"):
+            continue
+        text = open(os.path.join(inc, h)).read()
+        names += re.findall(r"\b(hz_[a-z0-9_]+)\s*\(", text)
+    return sorted(set(n for n in names if n not in ("hz_tiebreak_rand",)))

@@ -1,0 +1,98 @@
+// hz_common.h -- shared host/device helpers of libhanabizero_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "hz_tiebreak.h"
+
+#define HZ_FLOAT_MAX 1000000.0f  // reference core/ctree/cminimax.h:7
+#define HZ_FLOAT_MIN (-HZ_FLOAT_MAX)
+
+// ---- error plumbing: nothing in this library aborts (SURVEY 8b "what the build exports instead") ----
+void hz_set_error(const char* fmt, ...);
+
+#define HZ_HIP(call)                                                                   \
+  do {                                                                                 \
+    hipError_t _e = (call);                                                            \
+    if (_e != hipSuccess) {                                                            \
+      hz_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(_e)); \
+      return -2;                                                                       \
+    }                                                                                  \
+  } while (0)
+
+#define HZ_REQUIRE(cond, ...)   \
+  do {                          \
+    if (!(cond)) {              \
+      hz_set_error(__VA_ARGS__); \
+      return -1;                \
+    }                           \
+  } while (0)
+
+// ---- wave64 helpers --------------------------------------------------------------------------
+#define HZ_WAVE 64
+
+__device__ __forceinline__ float hz_readlane_f(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ int hz_readlane_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ int hz_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// max / min over the 64 lanes ignoring nothing (callers mask with +-inf); butterfly over ds_swizzle/DPP via __shfl_xor
+__device__ __forceinline__ float hz_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float hz_wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- expf, bit-identical to glibc >= 2.27 expf (sysdeps/ieee754/flt-32/e_expf.c, the x86-64 FMA ifunc
+//      variant every FMA-capable host selects).  The reference calls libm expf at core/ctree/cnode.cpp:87.
+//      Published algorithm (Szabolcs Nagy, ARM optimized-routines math/expf.c): x*N/ln2 = k + r,
+//      exp(x) = 2^(k/N) * (C0 r^3 + C1 r^2 + C2 r + 1) evaluated in double, N = 32.
+//      tests/test_hip_math.py checks all 2^32 inputs against the host libm on the GPU box.
+__device__ __constant__ const uint64_t hz_exp2f_tab[32] = {
+    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull,
+    0x3fef72b83c7d517bull, 0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull,
+    0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
+    0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull,
+    0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull,
+    0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+    0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull,
+    0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
+
+__device__ __forceinline__ float hz_expf(float x) {
+  const uint32_t ux = __float_as_uint(x);
+  const uint32_t abstop = (ux >> 20) & 0x7ff;
+  if (abstop >= (0x42b00000u >> 20)) {  // |x| >= 88 or NaN
+    if (ux == 0xff800000u) return 0.0f;                 // -inf
+    if (abstop >= (0x7f800000u >> 20)) return x + x;    // +inf / NaN
+    if (x > 0x1.62e42ep6f) return __uint_as_float(0x7f800000u);  // overflow
+    if (x < -0x1.9fe368p6f) return 0.0f;                // underflow
+  }
+  const double InvLn2N = 0x1.71547652b82fep+0 * 32.0;
+  const double Shift = 0x1.8p+52;
+  const double C0 = 0x1.c6af84b912394p-5 / 32.0 / 32.0 / 32.0;
+  const double C1 = 0x1.ebfce50fac4f3p-3 / 32.0 / 32.0;
+  const double C2 = 0x1.62e42ff0c52d6p-1 / 32.0;
+  const double xd = (double)x;
+  double z = InvLn2N * xd;
+  double kd = z + Shift;
+  const uint64_t ki = (uint64_t)__double_as_longlong(kd);
+  kd -= Shift;
+  const double r = __builtin_fma(InvLn2N, xd, -kd);  // as contracted by the host build
+  uint64_t t = hz_exp2f_tab[ki & 31];
+  t += ki << (52 - 5);
+  const double s = __longlong_as_double((long long)t);
+  z = __builtin_fma(C0, r, C1);
+  const double r2 = r * r;
+  double y = __builtin_fma(C2, r, 1.0);
+  y = __builtin_fma(z, r2, y);
+  y = y * s;
+  return (float)y;
+}

@@ -1,0 +1,620 @@
+// hz_tree.hip -- the pUCT search tree of HanabiZero as hand-written HIP for gfx950 (MI355X).
+//
+// What it replaces (reference, /root/reference): core/ctree/cnode.{h,cpp} + cminimax.{h,cpp} behind
+// core/ctree/cytree.pyx.  Written from scratch for CDNA4 -- no shared code with the reference or the oracle.
+//
+// Data layout in HBM (per hz_tree_t; N trees, A actions, S = num_simulations expandable entries per tree):
+//   rec   [N][S][A] float4   one 16-byte record per CHILD edge: {prior, value_sum, reward, bits(visit<<16 | child+1)}
+//                            entry e of a tree is an expanded node (e == its hidden_state_index_x; entry 0 = root);
+//                            its A children sit in rec[tree][e][0..A): one dwordx4 load per lane reads a whole level.
+//   qsa   [N][S]    f32      cached reward + discount*value() of expanded entry e (e >= 1) for the min-max pass
+//   ref   [N][S]    i32      (parent_entry << 8 | action) of entry e
+//   path  [N][S+1]  i32      (entry << 8 | action) per depth of the last descent (the reference's CSearchResults)
+//   root_visit/root_vsum/mm_min/mm_max/path_len [N];  best_action [N][S] i8
+// Execution model: ONE 64-lane wavefront per tree, lane a owns child a (A <= 64), 4 trees per 256-thread block.
+// Order-sensitive fp32 reductions of the reference (get_mean_q, policy_sum, legal_noise, the backup chain) are
+// evaluated in the reference's order with v_readlane broadcasts; order-free ones (max, min) with wave butterflies.
+// Compiled with -ffp-contract=off: one rounding per operation, like the reference's x86-64 build.
+#include <math.h>
+#include <stdarg.h>
+
+#include "hz_common.h"
+#include "hz_tree.h"
+
+// ------------------------------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+void hz_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* hz_last_error(void) { return g_err; }
+extern "C" int hz_version(void) { return 1; }
+
+// ------------------------------------------------------------------------------------------ handle
+struct hz_tree {
+  int N, A, S, device;
+  int pb_c_base;
+  float pb_c_init, discount, delta;
+  uint64_t seed;
+  uint32_t id_base;
+  int params_set;
+  int next_entry;  // host-side guard: the entry the next backprop must create
+  float4* rec;
+  float* qsa;
+  int32_t* ref;
+  int32_t* path;
+  int32_t* path_len;
+  int32_t* root_visit;
+  float* root_vsum;
+  float* mm_min;
+  float* mm_max;
+  int8_t* best_action;
+  float* pbc_tab;  // [S+1]: logf((n + base + 1) / base) + pb_c_init  for parent visit count n
+  int64_t bytes;
+};
+
+struct TreeView {
+  int N, A, S;
+  float discount, delta;
+  uint64_t seed;
+  uint32_t id_base;
+  float4* rec;
+  float* qsa;
+  int32_t* ref;
+  int32_t* path;
+  int32_t* path_len;
+  int32_t* root_visit;
+  float* root_vsum;
+  float* mm_min;
+  float* mm_max;
+  int8_t* best_action;
+  const float* pbc_tab;
+};
+
+static TreeView view(const hz_tree* t) {
+  TreeView v;
+  v.N = t->N; v.A = t->A; v.S = t->S;
+  v.discount = t->discount; v.delta = t->delta; v.seed = t->seed; v.id_base = t->id_base;
+  v.rec = t->rec; v.qsa = t->qsa; v.ref = t->ref; v.path = t->path; v.path_len = t->path_len;
+  v.root_visit = t->root_visit; v.root_vsum = t->root_vsum; v.mm_min = t->mm_min; v.mm_max = t->mm_max;
+  v.best_action = t->best_action; v.pbc_tab = t->pbc_tab;
+  return v;
+}
+
+__device__ __forceinline__ uint32_t pack_vc(int visit, int child) { return ((uint32_t)visit << 16) | (uint32_t)(child + 1); }
+
+// masked softmax -> priors, the arithmetic of CNode::expand (cnode.cpp:49-114).
+// lane a holds logit a; `legal_mask` bit a set = legal.  Returns this lane's prior.
+__device__ __forceinline__ float expand_prior(float logit, uint64_t legal_mask, int lane, int A) {
+  const bool legal = (legal_mask >> lane) & 1ull;
+  // policy_max = max over legal, non-NaN logits, starting from FLOAT_MIN (cnode.cpp:59,68-78)
+  float m = (legal && logit == logit) ? logit : -INFINITY;
+  m = hz_wave_max(m);
+  const float policy_max = fmaxf(m, HZ_FLOAT_MIN);
+  const float tp = legal ? hz_expf(logit - policy_max) : 0.0f;  // cnode.cpp:87
+  // policy_sum: 1e-4 + terms in action order over the legal children (cnode.cpp:57,88)
+  float policy_sum = 0.0001f;
+  uint64_t mm = legal_mask;
+  while (mm) {
+    const int a = __ffsll((unsigned long long)mm) - 1;
+    mm &= mm - 1;
+    policy_sum += hz_readlane_f(tp, a);
+  }
+  float prior = legal ? tp / policy_sum : 0.0f;  // cnode.cpp:98-103
+  if (prior != prior) prior = 0.0f;              // cnode.cpp:107-109
+  (void)A;
+  return prior;
+}
+
+// ------------------------------------------------------------------------------------------ prepare
+// CRoots::prepare / prepare_no_noise (cnode.cpp:247-259): reset the tree, expand the root (hidden index (0, tree)),
+// mix in exploration noise (cnode.cpp:116-142).
+__global__ __launch_bounds__(256) void k_prepare(TreeView tv, float frac, const float* __restrict__ noises,
+                                                 const float* __restrict__ rewards,
+                                                 const float* __restrict__ logits,
+                                                 const uint8_t* __restrict__ legal) {
+  const int lane = threadIdx.x & 63;
+  const int tree = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tree >= tv.N) return;
+  const int A = tv.A, S = tv.S;
+  const bool on = lane < A;
+  const float logit = on ? logits[(size_t)tree * A + lane] : 0.0f;
+  const int lg = on ? (int)legal[(size_t)tree * A + lane] : 0;
+  const uint64_t legal_mask = __ballot(on && lg != 0);  // expand skips legal == 0 (cnode.cpp:71)
+  float prior = expand_prior(logit, legal_mask, lane, A);
+  if (noises != nullptr) {
+    const float nz = on ? noises[(size_t)tree * A + lane] : 0.0f;
+    // legal_noise: sum in action order over legal == 1 (cnode.cpp:120-129)
+    float legal_noise = 0.0f;
+    uint64_t mm = __ballot(on && lg == 1);
+    while (mm) {
+      const int a = __ffsll((unsigned long long)mm) - 1;
+      mm &= mm - 1;
+      legal_noise += hz_readlane_f(nz, a);
+    }
+    if (lg <= 0) {
+      prior = 0.0f;  // cnode.cpp:131-135
+    } else {
+      const float noise = nz / legal_noise;          // cnode.cpp:136
+      prior = prior * (1 - frac) + noise * frac;     // cnode.cpp:140 (three roundings, no FMA)
+    }
+  }
+  if (on) {
+    float4 r;
+    r.x = prior; r.y = 0.0f; r.z = 0.0f; r.w = __uint_as_float(pack_vc(0, -1));
+    tv.rec[((size_t)tree * S + 0) * A + lane] = r;
+  }
+  for (int e = lane; e < S; e += 64) tv.best_action[(size_t)tree * S + e] = -1;
+  if (lane == 0) {
+    tv.root_visit[tree] = 0;
+    tv.root_vsum[tree] = 0.0f;
+    tv.mm_min[tree] = HZ_FLOAT_MAX;  // CMinMaxStats ctor (cminimax.cpp:5-9)
+    tv.mm_max[tree] = HZ_FLOAT_MIN;
+    tv.path_len[tree] = 0;
+  }
+  (void)rewards;  // the root's own reward is never read by the search (cnode.cpp:303,330 skip the root)
+}
+
+// ------------------------------------------------------------------------------------------ traverse
+// cmulti_traverse (cnode.cpp:407-441) with get_mean_q (:144-164), cselect_child (:346-374), cucb_score (:376-405)
+// and CMinMaxStats::normalize (cminimax.cpp:31-44).  Optionally fused with the hidden-state gather of
+// core/mcts.py:31-36.
+__global__ __launch_bounds__(256) void k_traverse(TreeView tv, int sim, int32_t* __restrict__ out_ix,
+                                                  int32_t* __restrict__ out_iy, int32_t* __restrict__ out_la,
+                                                  const uint8_t* __restrict__ pool, int row_bytes,
+                                                  uint8_t* __restrict__ net_in, int net_in_stride_bytes) {
+  const int lane = threadIdx.x & 63;
+  const int tree = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tree >= tv.N) return;
+  const int A = tv.A, S = tv.S;
+  const bool on = lane < A;
+  const float discount = tv.discount;
+  const float mn = tv.mm_min[tree], mx = tv.mm_max[tree];
+  const float delta = mx - mn;
+  const float4* rec = tv.rec + (size_t)tree * S * A;
+  int32_t* path = tv.path + (size_t)tree * (S + 1);
+
+  int e = 0;
+  int pvc = tv.root_visit[tree];
+  bool is_root = true;
+  float parent_q = 0.0f;  // cnode.cpp:414 (0 whenever it is read, see oracle/ref_tree_harness.cpp)
+  int depth = 0;
+  int action = 0;
+  while (true) {
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (on) r = rec[(size_t)e * A + lane];
+    const uint32_t w = __float_as_uint(r.w);
+    const int visit = (int)(w >> 16);
+    const int child = (int)(w & 0xffffu) - 1;
+    float prior = r.x;
+    if (prior != prior) prior = 0.0f;  // cnode.cpp:379-381
+    const float val = (visit == 0) ? 0.0f : r.y / (float)visit;  // CNode::value cnode.cpp:180-189
+    const float qsa = r.z + discount * val;
+    // get_mean_q: sum over visited children in action order
+    uint64_t vm = __ballot(on && visit > 0);
+    const int nvis = __popcll((unsigned long long)vm);
+    float total = 0.0f;
+    while (vm) {
+      const int a = __ffsll((unsigned long long)vm) - 1;
+      vm &= vm - 1;
+      total += hz_readlane_f(qsa, a);
+    }
+    float mean_q;
+    if (is_root && nvis > 0) mean_q = total / (float)nvis;
+    else mean_q = (parent_q + total) / (float)(nvis + 1);
+    is_root = false;
+    parent_q = mean_q;
+    // cucb_score
+    float pb_c = tv.pbc_tab[pvc];                                  // logf((n+base+1)/base) + pb_c_init
+    pb_c = pb_c * (sqrtf((float)pvc + 1.0f) / (float)(visit + 1));  // cnode.cpp:386
+    const float prior_score = pb_c * prior;
+    float vs = (visit == 0) ? mean_q : qsa;
+    if (delta > 0.0f) {  // CMinMaxStats::normalize
+      if (delta < tv.delta) vs = (vs - mn) / tv.delta;
+      else vs = (vs - mn) / delta;
+    }
+    if (vs < 0.0f) vs = 0.0f;
+    if (vs > 1.0f) vs = 1.0f;
+    const float score = prior_score + vs;
+    // cselect_child: final tie list = {first arg-max} U {later children within epsilon of the max}
+    const bool valid = on && (score == score) && (score > HZ_FLOAT_MIN);
+    const float M = hz_wave_max(valid ? score : -INFINITY);
+    const uint64_t eq = __ballot(valid && score == M);
+    action = 0;
+    if (eq != 0) {
+      const int first = __ffsll((unsigned long long)eq) - 1;
+      const float thr = M - 0.000001f;
+      uint64_t cand = __ballot(valid && score >= thr);
+      cand &= ~((1ull << first) - 1ull);
+      const uint32_t cnt = (uint32_t)__popcll((unsigned long long)cand);
+      const uint32_t rnd = hz_tiebreak_rand(tv.seed, tv.id_base + (uint32_t)tree, (uint32_t)sim, (uint32_t)depth);
+      uint32_t k = rnd % cnt;  // rand() % max_index_lst.size()  (cnode.cpp:369)
+      while (k--) cand &= cand - 1;
+      action = __ffsll((unsigned long long)cand) - 1;
+    }
+    action = hz_uniform(action);
+    if (lane == 0) {
+      tv.best_action[(size_t)tree * S + e] = (int8_t)action;  // node->best_action (cnode.cpp:426)
+      path[depth] = (e << 8) | action;
+    }
+    const int child_e = hz_readlane_i(child, action);
+    const int child_visit = hz_readlane_i(visit, action);
+    ++depth;
+    if (child_e < 0 || depth >= S) break;  // leaf reached (second clause: defensive bound, never true)
+    e = child_e;
+    pvc = child_visit;
+  }
+  if (lane == 0) {
+    out_ix[tree] = e;     // parent->hidden_state_index_x (entry index == hidden_state_index_x)
+    out_iy[tree] = tree;  // parent->hidden_state_index_y
+    out_la[tree] = action;
+    tv.path_len[tree] = depth + 1;
+  }
+  if (pool != nullptr) {
+    // hidden_states[i] = hidden_state_pool[ix][iy]  (core/mcts.py:31-32), 16 B per lane per trip
+    const uint8_t* src = pool + ((size_t)e * tv.N + tree) * (size_t)row_bytes;
+    uint8_t* dst = net_in + (size_t)tree * (size_t)net_in_stride_bytes;
+    for (int off = lane * 16; off < row_bytes; off += 64 * 16)
+      *reinterpret_cast<uint4*>(dst + off) = *reinterpret_cast<const uint4*>(src + off);
+  }
+}
+
+// ------------------------------------------------------------------------------------------ backprop
+// cmulti_back_propagate (cnode.cpp:337-344): expand (all legal) + cback_propagate (:317-335) + update_tree_q
+// (:296-315, here a wave min/max over the cached per-entry q values instead of a DFS of the whole tree).
+__global__ __launch_bounds__(256) void k_backprop(TreeView tv, int e_new, const float* __restrict__ rewards,
+                                                  const float* __restrict__ values,
+                                                  const float* __restrict__ logits) {
+  extern __shared__ float lds_q[];  // [4 waves][S]
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int tree = blockIdx.x * 4 + wave;
+  if (tree >= tv.N) return;
+  const int A = tv.A, S = tv.S;
+  const bool on = lane < A;
+  const float discount = tv.discount;
+  float4* rec = tv.rec + (size_t)tree * S * A;
+  const int32_t* path = tv.path + (size_t)tree * (S + 1);
+  float* lq = lds_q + wave * S;
+
+  // stage the cached q of entries 1..e_new-1 in LDS (coalesced), entry e_new is produced below
+  for (int e = 1 + lane; e < e_new; e += 64) lq[e] = tv.qsa[(size_t)tree * S + e];
+
+  // expand the leaf: priors of the new entry's children
+  const float logit = on ? logits[(size_t)tree * A + lane] : 0.0f;
+  const uint64_t all = (A >= 64) ? ~0ull : ((1ull << A) - 1ull);
+  const float prior = expand_prior(logit, all, lane, A);
+  if (on) {
+    float4 r;
+    r.x = prior; r.y = 0.0f; r.z = 0.0f; r.w = __uint_as_float(pack_vc(0, -1));
+    rec[(size_t)e_new * A + lane] = r;
+  }
+
+  const int npairs = tv.path_len[tree] - 1;  // edges on the path; the node below edge k is at depth k+1
+  float G = values[tree];                    // bootstrap_value (cnode.cpp:318)
+  const float leaf_reward = rewards[tree];
+  for (int base = ((npairs - 1) >> 6) << 6; base >= 0; base -= 64) {
+    const int k = base + lane;
+    const bool act = k < npairs;
+    int pr = 0;
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (act) {
+      pr = path[k];
+      r = rec[(size_t)(pr >> 8) * A + (pr & 255)];
+    }
+    uint32_t w = __float_as_uint(r.w);
+    int visit = (int)(w >> 16);
+    int child = (int)(w & 0xffffu) - 1;
+    if (act && k == npairs - 1) {  // the leaf: CNode::expand sets reward and hidden index (cnode.cpp:50-53)
+      r.z = leaf_reward;
+      child = e_new;
+      tv.ref[(size_t)tree * S + e_new] = pr;
+    }
+    // the backup chain, deepest node first: value_sum += G; G = reward + discount * G   (cnode.cpp:320-331)
+    float myG = 0.0f;
+    const int hi = min(npairs - 1 - base, 63);
+    for (int j = hi; j >= 0; --j) {
+      const float rj = hz_readlane_f(r.z, j);
+      if (lane == j) myG = G;
+      G = rj + discount * G;
+    }
+    if (act) {
+      r.y += myG;
+      visit += 1;
+      r.w = __uint_as_float(pack_vc(visit, child));
+      rec[(size_t)(pr >> 8) * A + (pr & 255)] = r;
+      const float q = r.z + discount * (r.y / (float)visit);  // update_tree_q's qsa (cnode.cpp:304)
+      lq[child] = q;
+      tv.qsa[(size_t)tree * S + child] = q;
+    }
+  }
+  if (lane == 0) {  // the root (search_path[0])
+    tv.root_vsum[tree] += G;
+    tv.root_visit[tree] += 1;
+  }
+  // min_max_stats.clear(); update_tree_q(root): every expanded non-root node contributes (cnode.cpp:332-334)
+  float vmax = -INFINITY, vmin = INFINITY;
+  for (int e = 1 + lane; e <= e_new; e += 64) {
+    const float q = lq[e];  // same-wave LDS traffic is processed in order: sees the stores above
+    if (q == q) {
+      vmax = fmaxf(vmax, q);
+      vmin = fminf(vmin, q);
+    }
+  }
+  vmax = hz_wave_max(vmax);
+  vmin = hz_wave_min(vmin);
+  if (lane == 0) {
+    tv.mm_max[tree] = fmaxf(vmax, HZ_FLOAT_MIN);  // CMinMaxStats::update from the cleared state (cminimax.cpp:17-29)
+    tv.mm_min[tree] = fminf(vmin, HZ_FLOAT_MAX);
+  }
+}
+
+// ------------------------------------------------------------------------------------------ read-outs
+__global__ void k_distributions(TreeView tv, int32_t* __restrict__ out) {  // cnode.cpp:205-214, 276-284
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= tv.N * tv.A) return;
+  const int tree = i / tv.A, a = i % tv.A;
+  const float4 r = tv.rec[((size_t)tree * tv.S) * tv.A + a];
+  out[i] = (int)(__float_as_uint(r.w) >> 16);
+}
+
+__global__ void k_values(TreeView tv, float* __restrict__ out) {  // cnode.cpp:286-292
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= tv.N) return;
+  const int v = tv.root_visit[i];
+  out[i] = v == 0 ? 0.0f : tv.root_vsum[i] / (float)v;
+}
+
+__global__ void k_trajectories(TreeView tv, int32_t* __restrict__ out, int max_len) {  // cnode.cpp:191-203
+  const int tree = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tree >= tv.N) return;
+  int e = 0, k = 0;
+  while (k < max_len && e >= 0) {
+    const int ba = tv.best_action[(size_t)tree * tv.S + e];
+    if (ba < 0) break;
+    out[(size_t)tree * max_len + k++] = ba;
+    const float4 r = tv.rec[((size_t)tree * tv.S + e) * tv.A + ba];
+    e = (int)(__float_as_uint(r.w) & 0xffffu) - 1;
+  }
+  for (; k < max_len; ++k) out[(size_t)tree * max_len + k] = -1;
+}
+
+__global__ void k_root_priors(TreeView tv, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= tv.N * tv.A) return;
+  const int tree = i / tv.A, a = i % tv.A;
+  out[i] = tv.rec[((size_t)tree * tv.S) * tv.A + a].x;
+}
+
+__global__ void k_copy_minmax(TreeView tv, float* __restrict__ mn, float* __restrict__ mx, int32_t* __restrict__ pl) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= tv.N) return;
+  if (mn) mn[i] = tv.mm_min[i];
+  if (mx) mx[i] = tv.mm_max[i];
+  if (pl) pl[i] = tv.path_len[i];
+}
+
+// ------------------------------------------------------------------------------------------ C ABI
+template <typename T>
+static int dev_alloc(T** p, size_t n, int64_t* total) {
+  HZ_HIP(hipMalloc((void**)p, n * sizeof(T)));
+  *total += (int64_t)(n * sizeof(T));
+  return 0;
+}
+
+extern "C" int hz_tree_create(hz_tree_t** out, int N, int A, int S, int device) {
+  HZ_REQUIRE(out != nullptr, "hz_tree_create: out is NULL");
+  HZ_REQUIRE(N > 0, "hz_tree_create: num_trees must be > 0 (got %d)", N);
+  HZ_REQUIRE(A > 0 && A <= HZ_MAX_ACTIONS, "hz_tree_create: num_actions must be in [1, %d] (got %d)", HZ_MAX_ACTIONS, A);
+  HZ_REQUIRE(S >= 2 && S <= HZ_MAX_SIMULATIONS, "hz_tree_create: num_simulations must be in [2, %d] (got %d)",
+             HZ_MAX_SIMULATIONS, S);
+  HZ_HIP(hipSetDevice(device));
+  hz_tree* t = new hz_tree();
+  memset(t, 0, sizeof(*t));
+  t->N = N; t->A = A; t->S = S; t->device = device;
+  int rc = 0;
+  rc |= dev_alloc(&t->rec, (size_t)N * S * A, &t->bytes);
+  rc |= dev_alloc(&t->qsa, (size_t)N * S, &t->bytes);
+  rc |= dev_alloc(&t->ref, (size_t)N * S, &t->bytes);
+  rc |= dev_alloc(&t->path, (size_t)N * (S + 1), &t->bytes);
+  rc |= dev_alloc(&t->path_len, (size_t)N, &t->bytes);
+  rc |= dev_alloc(&t->root_visit, (size_t)N, &t->bytes);
+  rc |= dev_alloc(&t->root_vsum, (size_t)N, &t->bytes);
+  rc |= dev_alloc(&t->mm_min, (size_t)N, &t->bytes);
+  rc |= dev_alloc(&t->mm_max, (size_t)N, &t->bytes);
+  rc |= dev_alloc(&t->best_action, (size_t)N * S, &t->bytes);
+  rc |= dev_alloc(&t->pbc_tab, (size_t)S + 1, &t->bytes);
+  if (rc != 0) {
+    hz_tree_destroy(t);
+    return -2;
+  }
+  HZ_HIP(hipMemset(t->path_len, 0, sizeof(int32_t) * N));
+  *out = t;
+  // reference defaults (core/config.py:107-111, config/hanabi_control/__init__.py:25-27)
+  return hz_tree_set_params(t, 19652, 1.25f, 0.999f, 0.0f, 0, 0);
+}
+
+extern "C" int hz_tree_destroy(hz_tree_t* t) {
+  if (!t) return 0;
+  (void)hipSetDevice(t->device);
+  hipFree(t->rec); hipFree(t->qsa); hipFree(t->ref); hipFree(t->path); hipFree(t->path_len);
+  hipFree(t->root_visit); hipFree(t->root_vsum); hipFree(t->mm_min); hipFree(t->mm_max);
+  hipFree(t->best_action); hipFree(t->pbc_tab);
+  delete t;
+  return 0;
+}
+
+extern "C" int hz_tree_set_params(hz_tree_t* t, int pb_c_base, float pb_c_init, float discount,
+                                  float value_delta_max, uint64_t tie_seed, uint32_t tree_id_base) {
+  HZ_REQUIRE(t != nullptr, "hz_tree_set_params: NULL handle");
+  HZ_REQUIRE(pb_c_base > 0, "hz_tree_set_params: pb_c_base must be > 0");
+  t->pb_c_base = pb_c_base; t->pb_c_init = pb_c_init; t->discount = discount; t->delta = value_delta_max;
+  t->seed = tie_seed; t->id_base = tree_id_base;
+  // pb_c's first factor depends only on the parent visit count n <= S: tabulate it with the host libm logf
+  // the reference links against (cnode.cpp:385), same expression, same fp32 roundings.
+  float* tab = new float[t->S + 1];
+  const float base = (float)pb_c_base;
+  for (int n = 0; n <= t->S; ++n) {
+    const float pvc = (float)n;
+    volatile float num = pvc + base;
+    num = num + 1;
+    volatile float ratio = num / base;
+    tab[n] = logf(ratio) + pb_c_init;
+  }
+  HZ_HIP(hipSetDevice(t->device));
+  hipError_t e = hipMemcpy(t->pbc_tab, tab, sizeof(float) * (t->S + 1), hipMemcpyHostToDevice);
+  delete[] tab;
+  HZ_HIP(e);
+  t->params_set = 1;
+  return 0;
+}
+
+static inline dim3 tree_grid(const hz_tree* t) { return dim3((unsigned)((t->N + 3) / 4)); }
+
+extern "C" int hz_tree_prepare(hz_tree_t* t, float frac, const float* noises, const float* rewards,
+                               const float* logits, const uint8_t* legal, void* stream) {
+  HZ_REQUIRE(t != nullptr, "hz_tree_prepare: NULL handle");
+  HZ_REQUIRE(logits != nullptr && legal != nullptr, "hz_tree_prepare: policy_logits and legal must not be NULL");
+  hipLaunchKernelGGL(k_prepare, tree_grid(t), dim3(256), 0, (hipStream_t)stream, view(t), frac, noises, rewards,
+                     logits, legal);
+  HZ_HIP(hipGetLastError());
+  t->next_entry = 1;
+  return 0;
+}
+
+static int launch_traverse(hz_tree_t* t, int sim, int32_t* ix, int32_t* iy, int32_t* la, const void* pool,
+                           int row_bytes, void* net_in, int stride_bytes, void* stream) {
+  HZ_REQUIRE(t != nullptr, "hz_tree_traverse: NULL handle");
+  HZ_REQUIRE(t->next_entry >= 1, "hz_tree_traverse: call hz_tree_prepare first");
+  HZ_REQUIRE(ix && iy && la, "hz_tree_traverse: output pointers must not be NULL");
+  HZ_REQUIRE(sim >= 0 && sim < 65536, "hz_tree_traverse: sim out of range (%d)", sim);
+  hipLaunchKernelGGL(k_traverse, tree_grid(t), dim3(256), 0, (hipStream_t)stream, view(t), sim, ix, iy, la,
+                     (const uint8_t*)pool, row_bytes, (uint8_t*)net_in, stride_bytes);
+  HZ_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int hz_tree_traverse(hz_tree_t* t, int sim, int32_t* ix, int32_t* iy, int32_t* la, void* stream) {
+  return launch_traverse(t, sim, ix, iy, la, nullptr, 0, nullptr, 0, stream);
+}
+
+extern "C" int hz_tree_traverse_gather(hz_tree_t* t, int sim, int32_t* ix, int32_t* iy, int32_t* la,
+                                       const void* pool, int hidden, int dtype, void* net_in, int net_in_stride,
+                                       void* stream) {
+  HZ_REQUIRE(pool != nullptr && net_in != nullptr, "hz_tree_traverse_gather: pool and net_in must not be NULL");
+  HZ_REQUIRE(dtype == HZ_F32 || dtype == HZ_BF16 || dtype == HZ_F16, "hz_tree_traverse_gather: bad dtype %d", dtype);
+  const int es = dtype == HZ_F32 ? 4 : 2;
+  HZ_REQUIRE(hidden > 0 && (hidden * es) % 16 == 0, "hz_tree_traverse_gather: hidden*elem_size must be a multiple of 16 B");
+  HZ_REQUIRE(net_in_stride >= hidden && (net_in_stride * es) % 16 == 0,
+             "hz_tree_traverse_gather: net_in_stride*elem_size must be a multiple of 16 B and >= hidden");
+  HZ_REQUIRE(((uintptr_t)pool % 16) == 0 && ((uintptr_t)net_in % 16) == 0, "hz_tree_traverse_gather: pointers must be 16-B aligned");
+  return launch_traverse(t, sim, ix, iy, la, pool, hidden * es, net_in, net_in_stride * es, stream);
+}
+
+extern "C" int hz_tree_backprop(hz_tree_t* t, int hidden_state_index_x, const float* rewards, const float* values,
+                                const float* logits, void* stream) {
+  HZ_REQUIRE(t != nullptr, "hz_tree_backprop: NULL handle");
+  HZ_REQUIRE(rewards && values && logits, "hz_tree_backprop: input pointers must not be NULL");
+  HZ_REQUIRE(hidden_state_index_x >= 1 && hidden_state_index_x < t->S,
+             "hz_tree_backprop: hidden_state_index_x=%d outside [1, num_simulations=%d)", hidden_state_index_x, t->S);
+  HZ_REQUIRE(hidden_state_index_x == t->next_entry,
+             "hz_tree_backprop: hidden_state_index_x must advance 1,2,3,... after prepare (expected %d, got %d)",
+             t->next_entry, hidden_state_index_x);
+  const size_t lds = (size_t)4 * t->S * sizeof(float);
+  hipLaunchKernelGGL(k_backprop, tree_grid(t), dim3(256), lds, (hipStream_t)stream, view(t), hidden_state_index_x,
+                     rewards, values, logits);
+  HZ_HIP(hipGetLastError());
+  t->next_entry = hidden_state_index_x + 1;
+  return 0;
+}
+
+extern "C" int hz_tree_get_distributions(hz_tree_t* t, int32_t* out, void* stream) {
+  HZ_REQUIRE(t && out, "hz_tree_get_distributions: NULL argument");
+  const int n = t->N * t->A;
+  hipLaunchKernelGGL(k_distributions, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, view(t), out);
+  HZ_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int hz_tree_get_values(hz_tree_t* t, float* out, void* stream) {
+  HZ_REQUIRE(t && out, "hz_tree_get_values: NULL argument");
+  hipLaunchKernelGGL(k_values, dim3((t->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, view(t), out);
+  HZ_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int hz_tree_get_trajectories(hz_tree_t* t, int32_t* out, int max_len, void* stream) {
+  HZ_REQUIRE(t && out && max_len > 0, "hz_tree_get_trajectories: bad argument");
+  hipLaunchKernelGGL(k_trajectories, dim3((t->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, view(t), out, max_len);
+  HZ_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int hz_tree_get_minmax(hz_tree_t* t, float* mn, float* mx, void* stream) {
+  HZ_REQUIRE(t && mn && mx, "hz_tree_get_minmax: NULL argument");
+  hipLaunchKernelGGL(k_copy_minmax, dim3((t->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, view(t), mn, mx,
+                     (int32_t*)nullptr);
+  HZ_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int hz_tree_get_path_len(hz_tree_t* t, int32_t* out, void* stream) {
+  HZ_REQUIRE(t && out, "hz_tree_get_path_len: NULL argument");
+  hipLaunchKernelGGL(k_copy_minmax, dim3((t->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, view(t),
+                     (float*)nullptr, (float*)nullptr, out);
+  HZ_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int hz_tree_get_root_priors(hz_tree_t* t, float* out, void* stream) {
+  HZ_REQUIRE(t && out, "hz_tree_get_root_priors: NULL argument");
+  const int n = t->N * t->A;
+  hipLaunchKernelGGL(k_root_priors, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, view(t), out);
+  HZ_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int64_t hz_tree_hbm_bytes(const hz_tree_t* t) { return t ? t->bytes : 0; }
+
+// ------------------------------------------------------------------------------------------ test hooks
+// Device expf over an array, and a blocked checksum over ALL 2^32 float bit patterns (tests/test_hip_math.py
+// compares it with the same checksum of the host libm expf the reference links against).
+__global__ void k_expf(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = hz_expf(x[i]);
+}
+
+__global__ __launch_bounds__(256) void k_expf_checksum(uint64_t* __restrict__ out) {
+  // block b covers bit patterns [b << 20, (b+1) << 20); checksum = sum over patterns of (bits(expf) * odd multiplier)
+  __shared__ uint64_t part[256];
+  const uint32_t base = (uint32_t)blockIdx.x << 20;
+  uint64_t acc = 0;
+  for (uint32_t i = threadIdx.x; i < (1u << 20); i += 256) {
+    const uint32_t u = base + i;
+    const float r = hz_expf(__uint_as_float(u));
+    uint32_t rb = __float_as_uint(r);
+    if (r != r) rb = 0x7fc00000u;  // canonical NaN
+    acc += (uint64_t)rb * (2ull * (uint64_t)i + 1ull);
+  }
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = part[0];
+}
+
+extern "C" int hz_test_expf(const float* x, float* y, int64_t n, void* stream) {
+  hipLaunchKernelGGL(k_expf, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, n);
+  HZ_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int hz_test_expf_checksum(uint64_t* out4096, void* stream) {
+  hipLaunchKernelGGL(k_expf_checksum, dim3(4096), dim3(256), 0, (hipStream_t)stream, out4096);
+  HZ_HIP(hipGetLastError());
+  return 0;
+}

@@ -51,6 +51,8 @@ def lib():
         L.hzo_env_observe.argtypes = [V, V, V]
         L.hzo_env_probe.argtypes = [V, V]
         L.hzo_env_hands.argtypes = [V, C.c_int, V]
+        L.hzo_expf_checksum_range.argtypes = [V, C.c_int, C.c_int]
+        L.hzo_expf_array.argtypes = [V, V, C.c_int64]
         L.hzo_mt_seed.argtypes = [V, C.c_uint32]
         L.hzo_mt_next.restype = C.c_uint32
         L.hzo_mt_next.argtypes = [V]
@@ -196,3 +198,21 @@ class OracleEnv:
         out = np.empty((self.players, self.hand_size), np.int32)
         self.lib.hzo_env_hands(self.h, env, _p(out))
         return out
+
+
+def expf_checksums(threads=8):
+    """checksum per block of 2^20 bit patterns over all 2^32 floats, host libm expf (ctypes drops the GIL)."""
+    from concurrent.futures import ThreadPoolExecutor
+    L = lib()
+    out = np.zeros(4096, np.uint64)
+    step = 64
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(lambda b: L.hzo_expf_checksum_range(_p(out), b, min(b + step, 4096)), range(0, 4096, step)))
+    return out
+
+
+def expf_array(x):
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.empty_like(x)
+    lib().hzo_expf_array(_p(x), _p(y), x.size)
+    return y
