@@ -37,6 +37,14 @@ def _load():
         "hz_tree_get_minmax": [V, V, V, V],
         "hz_tree_get_root_priors": [V, V, V],
         "hz_tree_get_path_len": [V, V, V],
+        # include/hz_env.h
+        "hz_env_create": [C.POINTER(V), I, I, I, I, I, I, I, V, I],
+        "hz_env_destroy": [V],
+        "hz_env_dims": [V, C.POINTER(I), C.POINTER(I), C.POINTER(I), C.POINTER(I)],
+        "hz_env_reset": [V, V, V],
+        "hz_env_step": [V, V, V, V, V, V, V, V],
+        "hz_env_observe": [V, I, V, I, I64, V, V, V],
+        "hz_env_probe": [V, V, V],
         "hz_test_expf": [V, V, I64, V],
         "hz_test_expf_checksum": [V, V],
     }
@@ -46,6 +54,8 @@ def _load():
         fn.restype = I
     lib.hz_tree_hbm_bytes.argtypes = [V]
     lib.hz_tree_hbm_bytes.restype = I64
+    lib.hz_env_hbm_bytes.argtypes = [V]
+    lib.hz_env_hbm_bytes.restype = I64
     return lib
 
 

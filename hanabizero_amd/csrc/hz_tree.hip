@@ -439,9 +439,9 @@ extern "C" int hz_tree_create(hz_tree_t** out, int N, int A, int S, int device) 
 extern "C" int hz_tree_destroy(hz_tree_t* t) {
   if (!t) return 0;
   (void)hipSetDevice(t->device);
-  hipFree(t->rec); hipFree(t->qsa); hipFree(t->ref); hipFree(t->path); hipFree(t->path_len);
-  hipFree(t->root_visit); hipFree(t->root_vsum); hipFree(t->mm_min); hipFree(t->mm_max);
-  hipFree(t->best_action); hipFree(t->pbc_tab);
+  void* bufs[] = {t->rec, t->qsa, t->ref, t->path, t->path_len, t->root_visit, t->root_vsum, t->mm_min,
+                  t->mm_max, t->best_action, t->pbc_tab};
+  for (void* b : bufs) (void)hipFree(b);
   delete t;
   return 0;
 }

@@ -51,3 +51,32 @@ class HipTree:
 
 def sync():
     torch.cuda.synchronize()
+
+
+class HipEnv:
+    """OracleEnv-shaped adapter over hanabizero_amd.hanabi_env.HanabiVecEnv (global observation)."""
+
+    def __init__(self, name, seeds):
+        from hanabizero_amd.hanabi_env import HanabiVecEnv
+        self.e = HanabiVecEnv(name, seeds, mdp="global")
+        self.N, self.num_moves, self.obs_len, self.own_len, self.players = (
+            self.e.N, self.e.num_moves, self.e.obs_len, self.e.own_len, self.e.players)
+        self.D = self.e.obs_dim
+
+    def reset(self, mask=None):
+        self.e.reset(None if mask is None else np.asarray(mask, np.uint8))
+
+    def step(self, actions, mask=None):
+        r, d, s, st = self.e.step(np.asarray(actions, np.int32), None if mask is None else np.asarray(mask, np.uint8))
+        st = st.cpu().numpy()
+        m = np.ones(self.N, bool) if mask is None else np.asarray(mask, bool)
+        if (st[m] != 0).any():
+            raise ValueError("illegal move in env %d" % int(np.nonzero((st != 0) & m)[0][0]))
+        return r.cpu().numpy(), d.cpu().numpy(), s.cpu().numpy()
+
+    def observe(self):
+        obs, legal = self.e.observe()
+        return obs.cpu().numpy(), legal.cpu().numpy()
+
+    def probe(self):
+        return self.e.probe().cpu().numpy()
