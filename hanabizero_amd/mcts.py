@@ -1,0 +1,69 @@
+"""hanabizero_amd.mcts -- ``MCTS(config).run_multi(roots, model, hidden_state_roots)`` of
+/root/reference/core/mcts.py:7-57, device-resident.
+
+The reference round-trips every simulation through the host (per-tree Python gather mcts.py:31-32, 2 H2D and 4 D2H
+copies, .tolist() conversions mcts.py:45-50).  Here the hidden-state pool [num_simulations, N, H] stays in HBM, the
+traverse kernel gathers each tree's parent state straight into the dynamics net's input buffer, the nets are
+invoked once per simulation over all N trees, and their outputs feed the backup kernel without leaving the device.
+Same quirks as the reference: num_simulations - 1 real simulations (mcts.py:24-26), NaN logits -> 0 (mcts.py:48-49).
+"""
+import numpy as np
+import torch
+
+from . import cytree as tree
+from .model import InferenceEngine
+
+
+class MCTS(object):
+    def __init__(self, config):
+        self.config = config
+
+    def run_multi(self, roots, model, hidden_state_roots, pool=None):
+        """roots: hanabizero_amd.cytree.Roots (already prepared).  model: an InferenceEngine (fast path) or a
+        module with the reference's recurrent_inference (numpy outputs; compatibility path).
+        hidden_state_roots: [N, H] CUDA tensor or numpy array.  Mutates `roots`; returns None."""
+        cfg = self.config
+        with torch.no_grad():
+            num, S = roots.num, cfg.num_simulations
+            roots.set_params(cfg.pb_c_base, cfg.pb_c_init, cfg.discount, cfg.value_delta_max)
+            if not isinstance(model, InferenceEngine):
+                return self._run_multi_compat(roots, model, hidden_state_roots)
+            h0 = hidden_state_roots if isinstance(hidden_state_roots, torch.Tensor) else torch.as_tensor(
+                np.asarray(hidden_state_roots), device=roots.device)
+            H = h0.shape[1]
+            if pool is None:
+                pool = torch.empty((S, num, H), dtype=model.dtype, device=roots.device)
+            pool[0].copy_(h0)
+            net_in = torch.empty((num, H), dtype=model.dtype, device=roots.device)
+            for index_simulation in range(S - 1):
+                _, _, last_actions = roots.traverse_tensors(pool, net_in)
+                value, reward, logits, _ = model.recurrent(net_in, last_actions, hidden_out=pool[index_simulation + 1])
+                logits = torch.nan_to_num_(logits, nan=0.0, posinf=float("inf"), neginf=float("-inf"))
+                roots.backprop_tensors(index_simulation + 1, reward, value, logits)
+
+    def _run_multi_compat(self, roots, model, hidden_state_roots):
+        """The reference loop verbatim in structure (lists / numpy through the drop-in cytree API): lets an unmodified
+        reference model object drive the HIP tree."""
+        cfg = self.config
+        model.eval()
+        num = roots.num
+        hidden_state_pool = [np.asarray(hidden_state_roots)]
+        hidden_state_index_x = 0
+        mm = tree.MinMaxStatsList(num)
+        mm.set_delta(cfg.value_delta_max)
+        dev = next(model.parameters()).device
+        for index_simulation in range(cfg.num_simulations):
+            if index_simulation == cfg.num_simulations - 1:
+                continue
+            results = tree.ResultsWrapper(num)
+            ix_lst, iy_lst, last_actions = tree.multi_traverse(roots, cfg.pb_c_base, cfg.pb_c_init, cfg.discount, mm, results)
+            hidden_states = np.asarray([hidden_state_pool[ix][iy] for ix, iy in zip(ix_lst, iy_lst)])
+            hidden_states = torch.from_numpy(hidden_states).to(dev)
+            la = torch.from_numpy(np.asarray(last_actions)).to(dev).unsqueeze(1).long()
+            out = model.recurrent_inference(hidden_states, la)
+            logits = np.array(out.policy_logits)
+            logits[np.isnan(logits)] = 0.0
+            hidden_state_pool.append(out.hidden_state)
+            hidden_state_index_x += 1
+            tree.multi_back_propagate(hidden_state_index_x, cfg.discount, np.asarray(out.reward).reshape(-1).tolist(),
+                                      np.asarray(out.value).reshape(-1).tolist(), logits.tolist(), mm, results)

@@ -1,0 +1,304 @@
+"""hanabizero_amd.model -- the representation / dynamics / prediction networks of HanabiZero in PyTorch-ROCm.
+
+Architecture and parameter names follow /root/reference/config/hanabi_control/model.py (``MuZeroNet`` :127-156 for
+Hanabi-Small, ``MuZeroNetFull`` :237-276 for Hanabi-Full) and core/model.py:46-97 (``BaseMuZeroNet``), so a reference
+``state_dict`` loads unchanged (``set_weights`` / ``get_weights``) and core/train.py can keep training this module.
+
+What is different is the inference side, which the self-play hot path calls once per tree depth over the whole
+envs batch: ``InferenceEngine`` folds every eval-mode BatchNorm1d into its Linear, keeps weights pre-cast
+(bf16 / fp16 / fp32) and pre-transposed in HBM, replaces the one-hot concat of ``dynamics`` (model.py:215-219) by a
+column lookup of the first layer's action block, runs the three heads' first layers as one GEMM, and returns DEVICE
+tensors (the reference returns numpy on the host: core/model.py:65-71,78-82).  The GEMMs go to hipBLASLt/rocBLAS
+(MFMA); nothing else on the hot path touches the matrix cores.
+"""
+import math
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class NetworkOutput(NamedTuple):  # core/model.py:13-17
+    value: object
+    reward: object
+    policy_logits: object
+    hidden_state: object
+
+
+# ------------------------------------------------------------------------------------------------ transforms
+def inverse_scalar_transform(logits, support_min, support_max, epsilon=0.001):
+    """core/config.py:210-232 (delta = 1): categorical logits over integers [min, max] -> scalar via h^-1."""
+    probs = torch.softmax(logits.float(), dim=1)
+    support = torch.arange(support_min, support_max + 1, dtype=probs.dtype, device=probs.device)
+    value = (probs * support).sum(1, keepdim=True)
+    sign = torch.where(value < 0, -torch.ones_like(value), torch.ones_like(value))
+    out = ((torch.sqrt(1 + 4 * epsilon * (torch.abs(value) + 1 + epsilon)) - 1) / (2 * epsilon)) ** 2 - 1
+    out = sign * out
+    return torch.nan_to_num(out, nan=0.0, posinf=float("inf"), neginf=float("-inf"))
+
+
+# ------------------------------------------------------------------------------------------------ blocks
+def _lbr(i, o):
+    return [nn.Linear(i, o), nn.BatchNorm1d(o), nn.ReLU()]
+
+
+class _Res(nn.Module):
+    """Two Linear+BatchNorm layers with a skip connection.  early_skip=True is the reference's ``ResMLP``
+    (skip added after the first BN, model.py:18-30); False is ``NewResMLP`` (after the second, model.py:43-57)."""
+
+    def __init__(self, dim, early_skip):
+        super().__init__()
+        self.in_dim, self.early_skip = dim, early_skip
+        self.fc1, self.bn1 = nn.Linear(dim, dim), nn.BatchNorm1d(dim)
+        self.fc2, self.bn2 = nn.Linear(dim, dim), nn.BatchNorm1d(dim)
+
+    def forward(self, x):
+        y = self.bn1(self.fc1(x))
+        if self.early_skip:
+            y = y + x
+        y = self.bn2(self.fc2(F.relu(y)))
+        if not self.early_skip:
+            y = y + x
+        return F.relu(y)
+
+
+class _Dyn(nn.Module):
+    """Three Linear+BatchNorm layers over [state | one-hot action]; the state is added back after the first
+    (``DynamicNet`` model.py:61-91) or the last (``NewDynamicNet`` model.py:93-125) of them."""
+
+    def __init__(self, state_dim, action_dim, early_skip):
+        super().__init__()
+        self.state_dim, self.action_dim, self.early_skip = state_dim, action_dim, early_skip
+        self.fc1, self.bn1 = nn.Linear(state_dim + action_dim, state_dim), nn.BatchNorm1d(state_dim)
+        self.fc2, self.bn2 = nn.Linear(state_dim, state_dim), nn.BatchNorm1d(state_dim)
+        self.fc3, self.bn3 = nn.Linear(state_dim, state_dim), nn.BatchNorm1d(state_dim)
+
+    def forward(self, state_action):
+        state = state_action[:, :self.state_dim]
+        y = self.bn1(self.fc1(state_action))
+        if self.early_skip:
+            y = y + state
+        y = F.relu(y)
+        y = F.relu(self.bn2(self.fc2(y)))
+        y = self.bn3(self.fc3(y))
+        if not self.early_skip:
+            y = y + state
+        return F.relu(y)
+
+
+class _HanabiNet(nn.Module):
+    """BaseMuZeroNet (core/model.py:46-103) for both games; subclasses only lay out the sub-networks."""
+
+    feature_size = 512
+
+    def __init__(self, action_space_n, inverse_value_transform, inverse_reward_transform, state_norm=False):
+        super().__init__()
+        assert not state_norm, "state_norm is off in both Hanabi configs (config/hanabi_control/__init__.py:37,155)"
+        self.action_space_n = action_space_n
+        self.inverse_value_transform = inverse_value_transform
+        self.inverse_reward_transform = inverse_reward_transform
+        self.state_norm = state_norm
+
+    def _zero_heads(self):  # model.py:151-156 / :271-276
+        for head in (self._prediction_value, self._dynamics_reward, self._prediction_actor):
+            nn.init.zeros_(head[-1].weight)
+            nn.init.zeros_(head[-1].bias)
+
+    def representation(self, obs_history):
+        return self._representation(obs_history)
+
+    def prediction(self, state):
+        return self._prediction_actor(state), self._prediction_value(state)
+
+    def dynamics(self, state, action):
+        assert state.dim() == 2 and action.shape[1] == 1
+        one_hot = torch.zeros(action.shape[0], self.action_space_n, dtype=torch.float32, device=action.device)
+        one_hot.scatter_(1, action, 1.0)
+        next_state = self._dynamics_state(torch.cat((state, one_hot), dim=1))
+        return next_state, self._dynamics_reward(next_state)
+
+    def initial_inference(self, obs):  # core/model.py:61-71
+        state = self.representation(obs)
+        logits, value = self.prediction(state)
+        if not self.training:
+            value = self.inverse_value_transform(value).detach().cpu().numpy()
+            state = state.detach().cpu().numpy()
+            logits = logits.detach().cpu().numpy()
+        return NetworkOutput(value, [0. for _ in range(obs.size(0))], logits, state)
+
+    def recurrent_inference(self, hidden_state, action):  # core/model.py:74-84
+        state, reward = self.dynamics(hidden_state, action)
+        logits, value = self.prediction(state)
+        if not self.training:
+            value = self.inverse_value_transform(value).detach().cpu().numpy()
+            reward = self.inverse_reward_transform(reward).detach().cpu().numpy()
+            state = state.detach().cpu().numpy()
+            logits = logits.detach().cpu().numpy()
+        return NetworkOutput(value, reward, logits, state)
+
+    def get_weights(self):
+        return {k: v.cpu() for k, v in self.state_dict().items()}
+
+    def set_weights(self, weights):
+        self.load_state_dict(weights)
+
+    def get_params_mean(self):
+        return 0, 0, 0, 0
+
+
+class MuZeroNet(_HanabiNet):
+    """Hanabi-Small network (model.py:127-156): feature 512, head hidden 128."""
+
+    def __init__(self, input_size, action_space_n, reward_support_size, value_support_size, inverse_value_transform,
+                 inverse_reward_transform, state_norm=False, proj=False):
+        super().__init__(action_space_n, inverse_value_transform, inverse_reward_transform, state_norm)
+        assert not proj, "the projection heads are asserted off in the reference (model.py:160-161)"
+        f, h = self.feature_size, 128
+        self.hidden_size = h
+        self._representation = nn.Sequential(*_lbr(input_size, f), _Res(f, early_skip=True))
+        self._dynamics_state = _Dyn(f, action_space_n, early_skip=True)
+        self._dynamics_reward = nn.Sequential(*_lbr(f, h), nn.Linear(h, reward_support_size))
+        self._prediction_actor = nn.Sequential(*_lbr(f, h), nn.Linear(h, action_space_n))
+        self._prediction_value = nn.Sequential(*_lbr(f, h), nn.Linear(h, value_support_size))
+        self._zero_heads()
+
+
+class MuZeroNetFull(_HanabiNet):
+    """Hanabi-Full network (model.py:237-276): representation 1024 -> 512, head hidden 256."""
+
+    def __init__(self, input_size, action_space_n, reward_support_size, value_support_size, inverse_value_transform,
+                 inverse_reward_transform, state_norm=False):
+        super().__init__(action_space_n, inverse_value_transform, inverse_reward_transform, state_norm)
+        f, i, h = self.feature_size, 1024, 256
+        self.init_size, self.hidden_size = i, h
+        self._representation = nn.Sequential(*_lbr(input_size, i), _Res(i, early_skip=False), *_lbr(i, f),
+                                             _Res(f, early_skip=False))
+        self._dynamics_state = _Dyn(f, action_space_n, early_skip=False)
+        self._dynamics_reward = nn.Sequential(*_lbr(f, h), *_lbr(h, h), nn.Linear(h, reward_support_size))
+        self._prediction_actor = nn.Sequential(*_lbr(f, h), _Res(h, early_skip=False), nn.Linear(h, action_space_n))
+        self._prediction_value = nn.Sequential(*_lbr(f, h), *_lbr(h, h), nn.Linear(h, value_support_size))
+        self._zero_heads()
+
+
+# ------------------------------------------------------------------------------------------------ inference engine
+def _fold(linear, bn):
+    """eval-mode BatchNorm1d(Linear(x)) == x @ W'^T + b' (fp32 fold)."""
+    w, b = linear.weight.detach().float(), linear.bias.detach().float()
+    if bn is None:
+        return w, b
+    s = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+    return w * s[:, None], (b - bn.running_mean.detach().float()) * s + bn.bias.detach().float()
+
+
+class _Lin:
+    """y = x @ Wt + b with Wt [in, out] resident in `dtype`; optional in-place ReLU."""
+
+    def __init__(self, w, b, dtype, device):
+        self.wt = w.t().contiguous().to(device=device, dtype=dtype)
+        self.b = b.to(device=device, dtype=dtype)
+
+    def __call__(self, x, relu=False, out=None):
+        y = torch.addmm(self.b, x, self.wt, out=out) if out is not None else torch.addmm(self.b, x, self.wt)
+        return torch.relu_(y) if relu else y
+
+
+class InferenceEngine:
+    """Device-resident eval-mode forward of a MuZeroNet / MuZeroNetFull.
+
+    initial(obs [N, stack*D])                      -> value [N] f32, logits [N, A] f32, hidden [N, 512] (engine dtype)
+    recurrent(hidden [N, 512], action [N] int)     -> value [N] f32, reward [N] f32, logits [N, A] f32, hidden
+    `hidden_out=` lets the caller point the new hidden state at its slot of the search's hidden-state pool.
+    """
+
+    def __init__(self, net, support, dtype=torch.bfloat16, device="cuda"):
+        self.dtype, self.device = dtype, torch.device(device)
+        self.A, self.H = net.action_space_n, net.feature_size
+        self.support = int(support)
+        self.full = isinstance(net, MuZeroNetFull)
+        self.load(net)
+
+    def load(self, net):
+        """(Re)build the folded weights from `net` (call after set_weights: selfplay_worker.py:177-184)."""
+        L = lambda lin, bn=None: _Lin(*_fold(lin, bn), self.dtype, self.device)
+        rep, dyn = net._representation, net._dynamics_state
+        rw, ac, va = net._dynamics_reward, net._prediction_actor, net._prediction_value
+        if self.full:
+            self.rep = [L(rep[0], rep[1]), L(rep[3].fc1, rep[3].bn1), L(rep[3].fc2, rep[3].bn2), L(rep[4], rep[5]),
+                        L(rep[7].fc1, rep[7].bn1), L(rep[7].fc2, rep[7].bn2)]
+        else:
+            self.rep = [L(rep[0], rep[1]), L(rep[3].fc1, rep[3].bn1), L(rep[3].fc2, rep[3].bn2)]
+        # dynamics layer 1: split [W_state | W_action]; the one-hot product is a row lookup of W_action^T
+        w1, b1 = _fold(dyn.fc1, dyn.bn1)
+        self.dyn1 = _Lin(w1[:, :self.H], b1, self.dtype, self.device)
+        self.dyn1_act = w1[:, self.H:].t().contiguous().to(device=self.device, dtype=self.dtype)  # [A, H]
+        self.dyn2, self.dyn3 = L(dyn.fc2, dyn.bn2), L(dyn.fc3, dyn.bn3)
+        # the three heads' first layers share their input: one GEMM [512 -> 3h] (reward | actor | value)
+        ws, bs = zip(_fold(rw[0], rw[1]), _fold(ac[0], ac[1]), _fold(va[0], va[1]))
+        self.h = ws[0].shape[0]
+        self.heads1 = _Lin(torch.cat(ws, 0), torch.cat(bs, 0), self.dtype, self.device)
+        self.pred1 = _Lin(torch.cat(ws[1:], 0), torch.cat(bs[1:], 0), self.dtype, self.device)
+        if self.full:
+            self.rw_tail = [L(rw[3], rw[4]), L(rw[6])]
+            self.ac_tail = [L(ac[3].fc1, ac[3].bn1), L(ac[3].fc2, ac[3].bn2), L(ac[4])]
+            self.va_tail = [L(va[3], va[4]), L(va[6])]
+        else:
+            self.rw_tail, self.ac_tail, self.va_tail = [L(rw[3])], [L(ac[3])], [L(va[3])]
+
+    # -- pieces ---------------------------------------------------------------------------------------
+    def _scalar(self, logits):
+        return inverse_scalar_transform(logits, -self.support, self.support).reshape(-1)
+
+    def _representation(self, x):
+        r = self.rep
+        if self.full:  # Linear-BN-ReLU, NewResMLP(1024), Linear-BN-ReLU, NewResMLP(512)
+            x = r[0](x, relu=True)
+            x = torch.relu_(r[2](r[1](x, relu=True)) + x)
+            x = r[3](x, relu=True)
+            return torch.relu_(r[5](r[4](x, relu=True)) + x)
+        x = r[0](x, relu=True)  # Linear-BN-ReLU, ResMLP(512)
+        y = torch.relu_(r[1](x) + x)
+        return r[2](y, relu=True)
+
+    def _dynamics(self, state, action, out=None):
+        y = self.dyn1(state) + self.dyn1_act.index_select(0, action)
+        if self.full:
+            y = self.dyn2(torch.relu_(y), relu=True)
+            y = self.dyn3(y, out=out)
+            return torch.relu_(y.add_(state))
+        y = torch.relu_(y.add_(state))
+        y = self.dyn2(y, relu=True)
+        return self.dyn3(y, relu=True, out=out)
+
+    def _tails(self, z, with_reward):
+        h = self.h
+        off = h if with_reward else 0
+        za, zv = z[:, off:off + h], z[:, off + h:off + 2 * h]
+        if self.full:
+            a = self.ac_tail
+            ya = torch.relu_(a[1](a[0](za, relu=True)) + za)
+            logits = a[2](ya)
+            value = self.va_tail[1](self.va_tail[0](zv, relu=True))
+            reward = self.rw_tail[1](self.rw_tail[0](z[:, :h], relu=True)) if with_reward else None
+        else:
+            logits, value = self.ac_tail[0](za), self.va_tail[0](zv)
+            reward = self.rw_tail[0](z[:, :h]) if with_reward else None
+        return logits.float(), value, reward
+
+    # -- entry points -----------------------------------------------------------------------------------
+    @torch.no_grad()
+    def initial(self, obs):
+        state = self._representation(obs.to(self.dtype))
+        logits, value, _ = self._tails(self.pred1(state, relu=True), with_reward=False)
+        return self._scalar(value), logits, state
+
+    @torch.no_grad()
+    def recurrent(self, hidden, action, hidden_out=None):
+        state = self._dynamics(hidden, action.long(), out=hidden_out)
+        logits, value, reward = self._tails(self.heads1(state, relu=True), with_reward=True)
+        return self._scalar(value), self._scalar(reward), logits, state
+
+    def flops_per_sample(self):
+        """MACs*2 of one recurrent inference (for the MFMA roofline line in bench.py)."""
+        mats = [self.dyn1.wt, self.dyn2.wt, self.dyn3.wt, self.heads1.wt] + [l.wt for l in self.rw_tail + self.ac_tail + self.va_tail]
+        return 2 * sum(int(m.numel()) for m in mats)

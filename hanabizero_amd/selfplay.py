@@ -1,0 +1,221 @@
+"""hanabizero_amd.selfplay -- the self-play actor of HanabiZero, one process per MI355X, device-resident.
+
+What it replaces: ``DataWorker.run_multi`` (/root/reference/core/selfplay_worker.py:91-393).  Per lock-step the
+reference does, per env and in Python: stack observations (:258-265), initial inference (:269-276), build a new
+cytree.Roots + Dirichlet noise (:278-280), MCTS (:282), read distributions/values (:284-285), then a loop over envs:
+select_action, env.step, store_search_stats, append, episode bookkeeping (:286-347) and, for finished games,
+game_over + put + save_pools + reset (:215-256).  Here all of that is ONE stream of kernels over the whole batch --
+optionally captured once into a hipGraph and replayed per lock-step -- with no host round trip inside a move:
+
+    initial inference -> hz_tree_prepare -> (S-1) x [hz_tree_traverse_gather -> dynamics/prediction GEMMs ->
+    hz_tree_backprop] -> read-outs -> hz_select_action -> trajectory append -> hz_env_step -> hz_env_observe ->
+    finished-game flush (hz_rows_scatter into an outbox ring) -> hz_env_reset(mask) -> hz_env_observe -> stack update
+
+Finished games leave the device as fixed-layout packed records (``drain()``), which ``unpack_record`` /
+``GameHistory.from_packed`` turn back into reference-shaped histories on the replay side, and which
+``hanabizero_amd.dist.gather_records`` moves to the replay owner's rank.
+
+Reference behaviours kept: num_simulations-1 simulations; illegal root children can collect visits and are masked at
+action selection; child_visits are the MASKED counts normalised by their sum; the terminal observation is stored;
+rewards are raw score deltas (put()'s turn-reward reshape is applied by the consumer: game.reshape_turn_rewards).
+Deliberate deviations: env i is seeded ``seed + global_env_id`` (the reference seeds every env of actor
+rank 0 identically: selfplay_worker.py:102); Dirichlet noise and sampling uniforms come from the device generator
+instead of numpy's global one; tie-breaks from include/hz_tiebreak.h.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import cytree
+from ._lib import check, lib
+from .hanabi_env import HanabiVecEnv
+from .mcts import MCTS
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class SelfPlayActor:
+    def __init__(self, config, engine, num_envs, rank=0, seed=0, device=None, use_graph=True, outbox_games=None,
+                 deterministic=False):
+        self.cfg, self.engine, self.N = config, engine, int(num_envs)
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        d, N = self.device, self.N
+        self.env_id_base = rank * N
+        self.deterministic = deterministic
+        seeds = seed + self.env_id_base + np.arange(N)
+        self.env = HanabiVecEnv(config.env_name, seeds, device=d, mdp=config.mdp)
+        self.A, self.D = self.env.num_moves, self.env.obs_dim
+        assert self.A == config.action_space_size and self.D == config.obs_dim
+        self.S, self.stack, self.T = config.num_simulations, config.stacked_observations, config.max_moves
+        self.W = self.env.packed_words
+        self.roots = cytree.Roots(N, self.A, self.S, device=d, tie_seed=seed, tree_id_base=self.env_id_base)
+        self.mcts = MCTS(config)
+        dt = engine.dtype
+        z = lambda *s, dtype: torch.zeros(s, dtype=dtype, device=d)
+        # model input ring and search state (static addresses: the whole step can be graph-captured)
+        self.stack_buf = z(N, self.stack, self.D, dtype=dt)
+        self.newest = z(N, self.D, dtype=dt)
+        self.legal = z(N, self.A, dtype=torch.uint8)
+        self.pool = z(self.S, N, engine.H, dtype=dt)
+        self.noise = z(N, self.A, dtype=torch.float32)
+        self.uniform = z(N, dtype=torch.float64)
+        self.zeros_n = z(N, dtype=torch.float32)
+        self.action = z(N, dtype=torch.int32)
+        self.entropy = z(N, dtype=torch.float64)
+        self.ar = torch.arange(N, device=d)
+        # per-env trajectory under construction
+        T, A, W = self.T, self.A, self.W
+        self.traj = dict(action=z(N, T, dtype=torch.int8), reward=z(N, T, dtype=torch.int8),
+                         value=z(N, T, dtype=torch.float32), visits=z(N, T, A, dtype=torch.int16),
+                         legal=z(N, T + 1, A, dtype=torch.uint8), obs=z(N, T + 1, W, dtype=torch.int32))
+        self.traj_len = z(N, dtype=torch.int64)
+        self.ent_sum = z(N, dtype=torch.float64)
+        self.meta = z(N, 4, dtype=torch.int32)  # len, final score, global env id, visit-entropy sum (f32 bits)
+        # outbox ring of finished games
+        self.cap = int(outbox_games or max(4 * N, 64))
+        self.out = {k: torch.zeros((self.cap,) + v.shape[1:], dtype=v.dtype, device=d) for k, v in self.traj.items()}
+        self.out_meta = z(self.cap, 4, dtype=torch.int32)
+        self.out_count = z(1, dtype=torch.int64)
+        self.slot = z(N, dtype=torch.int32)
+        self.tmp_packed = z(N, W, dtype=torch.int32)
+        self.tmp_legal = z(N, A, dtype=torch.uint8)
+        self.illegal_steps = z(1, dtype=torch.int64)
+        self.total_moves = 0
+        self._drained = 0
+        self._graph = None
+        self.use_graph = use_graph
+        self.gen = torch.Generator(device=d)
+        self.gen.manual_seed(int(seed) * 1000003 + rank)
+        self._alpha = torch.full((N, self.A), float(config.root_dirichlet_alpha), dtype=torch.float64, device=d)
+        self._start()
+
+    # -- episode start for every env (selfplay_worker.py:118-138) ----------------------------------------
+    def _start(self):
+        self.env.reset()
+        self.env.observe(out=self.newest, packed=self.tmp_packed, legal=self.legal)
+        self.stack_buf.copy_(self.newest[:, None, :].expand(-1, self.stack, -1))
+        self.traj["obs"][:, 0] = self.tmp_packed
+        self.traj["legal"][:, 0] = self.legal
+        self.traj_len.zero_()
+        torch.cuda.synchronize(self.device)
+
+    # -- host-side randomness for one lock-step (inputs of the captured step) -------------------------------
+    def _draw(self):
+        # np.random.dirichlet([alpha]*A).astype(float32) per env (selfplay_worker.py:279): Gamma(alpha) normalised, fp64
+        g = torch._standard_gamma(self._alpha, generator=self.gen)
+        self.noise.copy_((g / g.sum(1, keepdim=True)).to(torch.float32))
+        self.uniform.copy_(torch.rand(self.N, dtype=torch.float64, device=self.device, generator=self.gen))
+
+    # -- one lock-step, device only --------------------------------------------------------------------------
+    def _step_body(self):
+        cfg, N, ar = self.cfg, self.N, self.ar
+        value0, logits0, hidden0 = self.engine.initial(self.stack_buf.view(N, self.stack * self.D))
+        self.roots.prepare(cfg.root_exploration_fraction, self.noise, self.zeros_n, logits0, self.legal)
+        self.mcts.run_multi(self.roots, self.engine, hidden0, pool=self.pool)
+        counts = self.roots.distributions_tensor()
+        values = self.roots.values_tensor()
+        check(lib.hz_select_action(N, self.A, counts.data_ptr(), self.legal.data_ptr(), self.uniform.data_ptr(),
+                                   float(cfg.visit_softmax_temperature_fn(0, 0)), int(self.deterministic),
+                                   self.action.data_ptr(), self.entropy.data_ptr(), _stream()), "hz_select_action")
+        t = self.traj_len.clamp(max=self.T - 1)  # a Hanabi game cannot outlast max_moves; clamp keeps indices in range
+        tr = self.traj
+        tr["action"][ar, t] = self.action.to(torch.int8)
+        tr["visits"][ar, t] = counts.to(torch.int16)  # masked counts (store_search_stats gets the mutated list)
+        tr["value"][ar, t] = values
+        reward, done, score, status = self.env.step(self.action)
+        self.illegal_steps += (status != 0).sum()
+        tr["reward"][ar, t] = reward.to(torch.int8)
+        self.ent_sum += self.entropy
+        t1 = t + 1
+        # the observation after the move (terminal one included: selfplay_worker.py:308)
+        self.env.observe_packed(self.tmp_packed, self.tmp_legal)
+        tr["obs"][ar, t1] = self.tmp_packed
+        tr["legal"][ar, t1] = self.tmp_legal
+        # finished games -> outbox ring
+        db = done.bool()
+        self.meta[:, 0] = t1.to(torch.int32)
+        self.meta[:, 1] = score
+        self.meta[:, 2] = (ar + self.env_id_base).to(torch.int32)
+        self.meta[:, 3] = self.ent_sum.to(torch.float32).view(torch.int32)
+        csum = torch.cumsum(done.to(torch.int64), 0)
+        self.slot.copy_(torch.where(db, (self.out_count + csum - 1) % self.cap, torch.full_like(csum, -1)).to(torch.int32))
+        self.out_count += csum[-1:]
+        for k, v in tr.items():
+            o = self.out[k]
+            check(lib.hz_rows_scatter(v.data_ptr(), o.data_ptr(), v[0].numel() * v.element_size(), self.slot.data_ptr(), N,
+                                      _stream()), "hz_rows_scatter")
+        check(lib.hz_rows_scatter(self.meta.data_ptr(), self.out_meta.data_ptr(), 16, self.slot.data_ptr(), N, _stream()),
+              "hz_rows_scatter")
+        # reset finished envs (selfplay_worker.py:230-240) and take everybody's current observation
+        self.env.reset(done)
+        self.traj_len.copy_(torch.where(db, torch.zeros_like(t1), t1))
+        self.ent_sum.masked_fill_(db, 0.0)
+        self.env.observe(out=self.newest, packed=self.tmp_packed, legal=self.legal)
+        t0 = self.traj_len
+        tr["obs"][ar, t0] = self.tmp_packed
+        tr["legal"][ar, t0] = self.legal
+        # stack window: shift for running games, refill for new ones (selfplay_worker.py:237, 326-327)
+        shifted = torch.cat((self.stack_buf[:, 1:], self.newest[:, None, :]), dim=1)
+        filled = self.newest[:, None, :].expand(-1, self.stack, -1)
+        self.stack_buf.copy_(torch.where(db[:, None, None], filled, shifted))
+
+    def _capture(self):
+        self.roots.set_params(self.cfg.pb_c_base, self.cfg.pb_c_init, self.cfg.discount, self.cfg.value_delta_max)
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # warm-up outside capture (hipBLASLt workspaces, allocator)
+            for _ in range(2):
+                self._draw()
+                self._step_body()
+                self.total_moves += self.N
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._step_body()
+        self._graph = g
+
+    def step(self):
+        """Advance every env by one move."""
+        if self.use_graph and self._graph is None:
+            self._capture()
+        self._draw()
+        if self.use_graph:
+            self._graph.replay()
+        else:
+            self._step_body()
+        self.total_moves += self.N
+
+    # -- finished games ------------------------------------------------------------------------------------------
+    def drain(self):
+        """Packed records of the games finished since the last drain (synchronises).  Returns a dict of numpy arrays
+        with a leading games axis, or None.  Must be called at least once per `cap` finished games."""
+        count = int(self.out_count.item())
+        n = count - self._drained
+        if n <= 0:
+            return None
+        if n > self.cap:
+            raise RuntimeError("outbox overflow: %d games finished since the last drain, capacity %d" % (n, self.cap))
+        idx = torch.arange(self._drained, count, device=self.device) % self.cap
+        rec = {k: v.index_select(0, idx).cpu().numpy() for k, v in self.out.items()}
+        rec["meta"] = self.out_meta.index_select(0, idx).cpu().numpy()
+        self._drained = count
+        return rec
+
+
+def unpack_record(rec, i):
+    """Game i of a drained batch -> the dict GameHistory.from_packed takes."""
+    meta = rec["meta"][i]
+    T = int(meta[0])
+    return dict(len=T, score=int(meta[1]), env_id=int(meta[2]),
+                visit_entropy_sum=float(np.array([meta[3]], np.int32).view(np.float32)[0]),
+                action=rec["action"][i, :T], reward=rec["reward"][i, :T], value=rec["value"][i, :T],
+                visits=rec["visits"][i, :T], legal=rec["legal"][i, :T + 1],
+                obs_bits=rec["obs"][i, :T + 1].view(np.uint32))
+
+
+def record_nbytes(rec):
+    return int(sum(v.nbytes for v in rec.values()))

@@ -1,0 +1,86 @@
+"""Nets: hanabizero_amd.model against the reference's own networks (tests/golden/nets_*.npz were produced by
+config/hanabi_control/model.py loaded by file path, CPU fp32, eval mode; weights from tests/netgold.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.netgold import fill_state_dict
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def build(game):
+    from hanabizero_amd.model import MuZeroNet, MuZeroNetFull, inverse_scalar_transform
+    fx = dict(np.load(os.path.join(GOLD, "nets_%s.npz" % game)))
+    D, A, sup, stack = int(fx["D"]), int(fx["A"]), int(fx["support"]), int(fx["stack"])
+    inv = lambda x: inverse_scalar_transform(x, -sup, sup)
+    cls = MuZeroNet if game == "Hanabi-Small" else MuZeroNetFull
+    net = cls(D * stack, A, 2 * sup + 1, 2 * sup + 1, inv, inv)
+    assert list(net.state_dict().keys()) == [str(k) for k in fx["sd_keys"]], "state_dict keys differ from the reference"
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in fill_state_dict(net.state_dict()).items()})
+    net.eval()
+    return net, fx, sup
+
+
+def _close(a, b, tol):
+    a, b = np.asarray(a, np.float64).reshape(-1), np.asarray(b, np.float64).reshape(-1)
+    return np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))) <= tol
+
+
+@pytest.mark.parametrize("game", ["Hanabi-Small", "Hanabi-Full"])
+def test_module_matches_reference_fp32_cpu(game):
+    net, fx, _ = build(game)
+    with torch.no_grad():
+        o0 = net.initial_inference(torch.from_numpy(fx["obs"]))
+        o1 = net.recurrent_inference(torch.from_numpy(o0.hidden_state), torch.from_numpy(fx["action"]))
+    for got, want in [(o0.value, fx["init_value"]), (o0.policy_logits, fx["init_logits"]), (o0.hidden_state, fx["init_hidden"]),
+                      (o1.value, fx["rec_value"]), (o1.reward, fx["rec_reward"]), (o1.policy_logits, fx["rec_logits"]),
+                      (o1.hidden_state, fx["rec_hidden"])]:
+        assert _close(got, want, 1e-5)
+    assert o0.reward == [0.0] * fx["obs"].shape[0]  # core/model.py:71
+
+
+@pytest.mark.parametrize("game", ["Hanabi-Small", "Hanabi-Full"])
+def test_inference_engine_fp32_cpu_within_1e3(game):
+    """BatchNorm folding, action-column lookup and the fused head GEMM change rounding only: 1e-3 is the
+    north-star tolerance for net outputs; fp32 lands orders of magnitude inside it."""
+    from hanabizero_amd.model import InferenceEngine
+    net, fx, sup = build(game)
+    eng = InferenceEngine(net, sup, dtype=torch.float32, device="cpu")
+    v0, l0, h0 = eng.initial(torch.from_numpy(fx["obs"]))
+    assert _close(v0, fx["init_value"], 1e-4) and _close(l0, fx["init_logits"], 1e-4) and _close(h0, fx["init_hidden"], 1e-4)
+    v1, r1, l1, h1 = eng.recurrent(torch.from_numpy(fx["init_hidden"]), torch.from_numpy(fx["action"]).reshape(-1))
+    assert _close(v1, fx["rec_value"], 1e-4) and _close(r1, fx["rec_reward"], 1e-4)
+    assert _close(l1, fx["rec_logits"], 1e-4) and _close(h1, fx["rec_hidden"], 1e-4)
+    pool_slot = torch.zeros_like(h1)
+    eng.recurrent(torch.from_numpy(fx["init_hidden"]), torch.from_numpy(fx["action"]).reshape(-1), hidden_out=pool_slot)
+    assert torch.equal(pool_slot, h1)
+
+
+def test_zero_initialised_heads_like_the_reference():
+    from hanabizero_amd.model import MuZeroNetFull
+    net = MuZeroNetFull(785 * 4, 20, 201, 201, None, None)
+    for head in (net._prediction_value, net._dynamics_reward, net._prediction_actor):
+        assert float(head[-1].weight.abs().sum()) == 0.0 and float(head[-1].bias.abs().sum()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("game", ["Hanabi-Small", "Hanabi-Full"])
+def test_inference_engine_on_gpu(game):
+    """fp32 on the GPU stays within 1e-3 of the reference's fp32 outputs (relative to max(1,|ref|)).
+    bf16 / fp16 engines (8 / 11 significand bits) are checked at the accuracy those formats allow; the reference
+    itself runs these nets under fp16 autocast (core/mcts.py:38-40)."""
+    from hanabizero_amd.model import InferenceEngine
+    net, fx, sup = build(game)
+    obs = torch.from_numpy(fx["obs"]).cuda()
+    hid = torch.from_numpy(fx["init_hidden"]).cuda()
+    act = torch.from_numpy(fx["action"]).reshape(-1).cuda()
+    for dtype, tol in [(torch.float32, 1e-3), (torch.float16, 1e-2), (torch.bfloat16, 6e-2)]:
+        eng = InferenceEngine(net, sup, dtype=dtype, device="cuda")
+        v0, l0, h0 = eng.initial(obs)
+        v1, r1, l1, h1 = eng.recurrent(hid.to(dtype), act)
+        for got, want in [(v0, fx["init_value"]), (l0, fx["init_logits"]), (h0, fx["init_hidden"]), (v1, fx["rec_value"]),
+                          (r1, fx["rec_reward"]), (l1, fx["rec_logits"]), (h1, fx["rec_hidden"])]:
+            assert _close(got.float().cpu().numpy(), want, tol), (dtype, float(np.max(np.abs(got.float().cpu().numpy().reshape(-1) - np.asarray(want).reshape(-1)))))

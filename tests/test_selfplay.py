@@ -1,0 +1,139 @@
+"""GPU: the device-resident self-play actor against an independent replay of the same moves through the ORACLE
+tree + ORACLE env + a numpy restatement of select_action (core/utils.py:280-295), sharing only the nets."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def ref_select_action(visit_counts, legal, u):
+    """core/utils.py:280-295 with temperature 1, non-deterministic; np.random.choice's algorithm with a given u."""
+    visit_counts = list(visit_counts)
+    for i in range(len(legal)):
+        if legal[i] == 0 and visit_counts[i] >= 1:
+            visit_counts[i] = 0
+    probs = [float(v) ** 1.0 for v in visit_counts]
+    total = sum(probs)
+    probs = [x / total for x in probs]
+    cdf = np.cumsum(np.array(probs, dtype=np.float64))
+    cdf /= cdf[-1]
+    a = int(cdf.searchsorted(u, side="right"))
+    pk = np.array(probs) / np.sum(probs)
+    ent = -np.sum(np.where(pk > 0, pk * np.log(np.where(pk > 0, pk, 1.0)), 0.0)) / np.log(2.0)
+    return a, ent, visit_counts
+
+
+def make(game, N, sims, stack, dtype, use_graph, seed=3):
+    from hanabizero_amd.config import make_config
+    from hanabizero_amd.model import InferenceEngine
+    from hanabizero_amd.selfplay import SelfPlayActor
+    from tests.netgold import fill_state_dict
+    cfg = make_config(game, simulations=sims, stack=stack, p_mcts_num=N)
+    net = cfg.get_uniform_network()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in fill_state_dict(net.state_dict()).items()})
+    net.eval()
+    eng = InferenceEngine(net, cfg.value_support.max, dtype=dtype, device="cuda")
+    return cfg, eng, SelfPlayActor(cfg, eng, N, seed=seed, use_graph=use_graph)
+
+
+@pytest.mark.parametrize("game,N,sims,stack,steps", [("Hanabi-Small", 16, 10, 2, 40), ("Hanabi-Full", 8, 12, 4, 25)])
+def test_actor_matches_oracle_replay(game, N, sims, stack, steps):
+    from oracle.cport import OracleEnv, OracleTree
+    from hanabizero_amd.game import GameHistory
+    from hanabizero_amd.selfplay import unpack_record
+    cfg, eng, actor = make(game, N, sims, stack, torch.float32, use_graph=False)
+    A, D = cfg.action_space_size, cfg.obs_dim
+    seeds = 3 + np.arange(N)
+    oenv = OracleEnv(game, seeds)
+    oenv.reset()
+    obs, legal = oenv.observe()
+    windows = [[obs[i].copy() for _ in range(stack)] for i in range(N)]
+    hist = [dict(obs=[obs[i].copy()], legal=[legal[i].copy()], action=[], reward=[], visits=[], value=[]) for i in range(N)]
+    finished = []
+    for step in range(steps):
+        actor._draw()
+        noise, uni = actor.noise.cpu().numpy(), actor.uniform.cpu().numpy()
+        stack_in = np.stack([np.concatenate(w) for w in windows]).astype(np.float32)
+        assert (actor.stack_buf.view(N, -1).cpu().numpy() == stack_in).all(), step
+        assert (actor.legal.cpu().numpy() == legal).all()
+        actor._step_body()
+        # ---- oracle replay of the same move
+        v0, l0, h0 = eng.initial(torch.from_numpy(stack_in).cuda())
+        tree = OracleTree(N, A, sims, seed=3, value_delta_max=cfg.value_delta_max)
+        tree.prepare(cfg.root_exploration_fraction, noise, np.zeros(N, np.float32), l0.cpu().numpy(), legal)
+        pool = [h0]
+        for sim in range(sims - 1):
+            ix, iy, la = tree.traverse(sim, cfg.pb_c_base, cfg.pb_c_init, cfg.discount)
+            hid = torch.stack([pool[x][y] for x, y in zip(ix, iy)])
+            v, r, lg, h = eng.recurrent(hid, torch.from_numpy(la).cuda())
+            pool.append(h)
+            tree.backprop(sim + 1, cfg.discount, r.cpu().numpy(), v.cpu().numpy(), torch.nan_to_num(lg).cpu().numpy())
+        dist, vals = tree.distributions(), tree.values()
+        acts = np.zeros(N, np.int32)
+        for i in range(N):
+            a, ent, masked = ref_select_action(dist[i], legal[i], uni[i])
+            acts[i] = a
+            hist[i]["visits"].append(masked), hist[i]["value"].append(vals[i]), hist[i]["action"].append(a)
+            assert abs(ent - float(actor.entropy[i])) < 1e-12
+        assert (actor.action.cpu().numpy() == acts).all(), (step, actor.action.cpu().numpy(), acts)
+        rew, done, score = oenv.step(acts)
+        obs, legal = oenv.observe()
+        for i in range(N):
+            hist[i]["reward"].append(rew[i]), hist[i]["obs"].append(obs[i].copy()), hist[i]["legal"].append(legal[i].copy())
+            windows[i] = windows[i][1:] + [obs[i].copy()]
+        if done.any():
+            oenv.reset(done)
+            obs, legal = oenv.observe()
+            for i in np.nonzero(done)[0]:
+                finished.append((i, score[i], hist[i]))
+                hist[i] = dict(obs=[obs[i].copy()], legal=[legal[i].copy()], action=[], reward=[], visits=[], value=[])
+                windows[i] = [obs[i].copy() for _ in range(stack)]
+    assert int(actor.illegal_steps) == 0
+    rec = actor.drain()
+    assert len(finished) > 0 and rec is not None and rec["meta"].shape[0] == len(finished)
+    for g, (i, score, h) in enumerate(finished):  # flush order == env order within a step == our append order
+        r = unpack_record(rec, g)
+        assert (r["env_id"], r["score"], r["len"]) == (i, score, len(h["action"]))
+        assert (r["action"] == h["action"]).all() and (r["reward"] == h["reward"]).all()
+        assert (r["visits"] == np.array(h["visits"])).all()
+        assert (r["value"].view(np.uint32) == np.array(h["value"], np.float32).view(np.uint32)).all()
+        assert (r["legal"] == np.array(h["legal"])).all()
+        gh = GameHistory.from_packed(r, None, cfg)
+        assert len(gh) == r["len"] and gh.obs_history.shape == (r["len"] + stack, D)
+        assert (gh.obs_history[stack - 1:] == np.array(h["obs"])).all()
+        assert np.allclose(gh.child_visits.sum(1), 1.0) and gh.legal_actions.shape == (r["len"] + 1, A)
+
+
+def test_graph_replay_equals_eager():
+    """The hipGraph-captured lock-step produces exactly what the eager stream of the same kernels produces."""
+    outs = []
+    for use_graph in (False, True):
+        cfg, eng, actor = make("Hanabi-Small", 64, 10, 2, torch.bfloat16, use_graph, seed=11)
+        for _ in range(30):
+            actor.step()
+        torch.cuda.synchronize()
+        rec = actor.drain()
+        outs.append((actor.action.cpu().numpy().copy(), actor.env.probe().cpu().numpy().copy(), rec))
+    assert (outs[0][0] == outs[1][0]).all() and (outs[0][1] == outs[1][1]).all()
+    assert outs[0][2]["meta"].shape == outs[1][2]["meta"].shape
+    for k in outs[0][2]:
+        assert (outs[0][2][k] == outs[1][2][k]).all(), k
+
+
+def test_select_action_kernel_edge_cases():
+    from hanabizero_amd._lib import check, lib
+    N, A = 5, 11
+    counts = torch.tensor([[0] * 10 + [9], [3] * 11, [0] * 11, [5, 4] + [0] * 9, [1] * 11], dtype=torch.int32, device="cuda")
+    legal = torch.ones(N, A, dtype=torch.uint8, device="cuda")
+    legal[3, 0] = 0
+    u = torch.tensor([0.999, 0.0, 0.5, 0.0, 1.0 - 1e-16], dtype=torch.float64, device="cuda")
+    act = torch.zeros(N, dtype=torch.int32, device="cuda")
+    ent = torch.zeros(N, dtype=torch.float64, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    check(lib.hz_select_action(N, A, counts.data_ptr(), legal.data_ptr(), u.data_ptr(), 1.0, 0, act.data_ptr(), ent.data_ptr(), s), "x")
+    assert act.tolist() == [10, 0, -1, 1, 10]
+    assert counts[3].tolist() == [0, 4] + [0] * 9  # illegal count zeroed in place
+    assert abs(float(ent[1]) - np.log2(11)) < 1e-12 and float(ent[0]) == 0.0
+    check(lib.hz_select_action(N, A, counts.data_ptr(), legal.data_ptr(), u.data_ptr(), 1.0, 1, act.data_ptr(), None, s), "x")
+    assert act.tolist() == [10, 0, -1, 1, 0]
