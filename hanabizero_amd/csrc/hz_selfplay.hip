@@ -94,17 +94,18 @@ __global__ __launch_bounds__(256) void k_rows_scatter(const uint8_t* __restrict_
   if ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)row_bytes) & 15) == 0) {
     for (long long off = (long long)lane * 16; off < row_bytes; off += 64 * 16)
       *reinterpret_cast<uint4*>(b + off) = *reinterpret_cast<const uint4*>(a + off);
-  } else {
+  } else if ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)row_bytes) & 3) == 0) {
     for (long long off = (long long)lane * 4; off < row_bytes; off += 64 * 4)
       *reinterpret_cast<uint32_t*>(b + off) = *reinterpret_cast<const uint32_t*>(a + off);
+  } else {
+    for (long long off = lane; off < row_bytes; off += 64) b[off] = a[off];
   }
 }
 
 extern "C" int hz_rows_scatter(const void* src, void* dst, int64_t row_bytes, const int32_t* slot, int num_rows,
                                void* stream) {
   HZ_REQUIRE(src && dst && slot, "hz_rows_scatter: NULL argument");
-  HZ_REQUIRE(num_rows > 0 && row_bytes > 0 && row_bytes % 4 == 0, "hz_rows_scatter: row_bytes must be a positive multiple of 4");
-  HZ_REQUIRE(((uintptr_t)src % 4) == 0 && ((uintptr_t)dst % 4) == 0, "hz_rows_scatter: pointers must be 4-byte aligned");
+  HZ_REQUIRE(num_rows > 0 && row_bytes > 0, "hz_rows_scatter: num_rows and row_bytes must be positive");
   hipLaunchKernelGGL(k_rows_scatter, dim3((num_rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)src,
                      (uint8_t*)dst, (long long)row_bytes, slot, num_rows);
   HZ_HIP(hipGetLastError());

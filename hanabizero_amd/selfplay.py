@@ -75,7 +75,7 @@ class SelfPlayActor:
         self.ent_sum = z(N, dtype=torch.float64)
         self.meta = z(N, 4, dtype=torch.int32)  # len, final score, global env id, visit-entropy sum (f32 bits)
         # outbox ring of finished games
-        self.cap = int(outbox_games or max(4 * N, 64))
+        self.cap = int(outbox_games or max(4 * N, 1024))
         self.out = {k: torch.zeros((self.cap,) + v.shape[1:], dtype=v.dtype, device=d) for k, v in self.traj.items()}
         self.out_meta = z(self.cap, 4, dtype=torch.int32)
         self.out_count = z(1, dtype=torch.int64)

@@ -27,8 +27,8 @@ int hz_select_action(int num_envs, int num_actions, int32_t* counts, const uint8
 
 /* Finished-game flush (replaces the per-game Python of selfplay_worker.py:216-228: game_over() + put() +
  * replay_buffer.save_pools.remote): copies row i of `src` ([N] rows of row_bytes) to row slot[i] of `dst` for every
- * env with slot[i] >= 0; rows with slot[i] < 0 are skipped.  One wavefront per row, 16 B per lane per trip.
- * row_bytes must be a multiple of 4; src/dst 4-byte aligned. */
+ * env with slot[i] >= 0; rows with slot[i] < 0 are skipped.  One wavefront per row, 16 B per lane per trip when
+ * rows are 16-byte aligned (4 B or 1 B per lane otherwise). */
 int hz_rows_scatter(const void* src, void* dst, int64_t row_bytes, const int32_t* slot, int num_rows, void* stream);
 
 #ifdef __cplusplus
