@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""bench.py -- self-play moves/sec & MCTS sims/sec of the MI355X engine on BASELINE.json's headline workload.
+
+One "step" = one lock-step of the self-play hot path over every env of this GPU: root inference -> root prepare ->
+49 x (HIP select + gather -> dynamics/prediction GEMMs -> HIP expand/backup) -> read-out -> action sampling ->
+HIP env step + encode -> finished-game flush -> reset.  Inputs are resident in HBM; nothing is skipped.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  Besides the driver's contract fields it carries
+  roofline      the dominant hand-written kernel: algorithmic bytes per launch / average launch duration measured here
+                with HIP events on the launch stream (an instrumented eager pass over real search states after the
+                timed region), against the 8 TB/s HBM peak; `traffic` from profiles/ PMC summaries when present
+  cpu_baseline  the plain-C oracle (tree + env, no nets: the part the reference runs on CPU) timed on one host core
+                on a bounded sample of the same workload.  A reported baseline, not the target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (game, envs per GPU, simulations, stack)
+    "full4096": ("Hanabi-Full", 4096, 50, 4),     # BASELINE.json metric: Hanabi-Full 2p, 50 sims, 4096 envs
+    "small4096": ("Hanabi-Small", 4096, 50, 4),   # BASELINE.json configs[1]
+    "full8192": ("Hanabi-Full", 8192, 50, 4),     # BASELINE.json configs[2] (and [3] at --gpus 8)
+}
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def build_engine(cfg, dtype, device):
+    import torch
+    from hanabizero_amd.model import InferenceEngine
+    torch.manual_seed(0)
+    net = cfg.get_uniform_network()
+    with torch.no_grad():  # fixed random init, zero-initialised heads perturbed with N(0, 0.1)
+        for head in (net._prediction_value, net._dynamics_reward, net._prediction_actor):
+            head[-1].weight.normal_(0, 0.1)
+            head[-1].bias.normal_(0, 0.1)
+    net.eval()
+    return InferenceEngine(net, cfg.value_support.max, dtype=dtype, device=device)
+
+
+def instrumented_search(actor, moves=2):
+    """Eager (non-graph) lock-steps with a HIP event pair around every tree-kernel launch, on the launch stream.
+    Returns per-kernel average duration (s), launches, and the measured mean path length."""
+    import torch
+    cfg, roots, eng = actor.cfg, actor.roots, actor.engine
+    N, S = actor.N, actor.S
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    t_trav, t_back, depth_sum, n_launch = 0.0, 0.0, 0.0, 0
+    for _ in range(moves):
+        actor._draw()
+        value0, logits0, hidden0 = eng.initial(actor.stack_buf.view(N, actor.stack * actor.D))
+        roots.prepare(cfg.root_exploration_fraction, actor.noise, actor.zeros_n, logits0, actor.legal)
+        actor.pool[0].copy_(hidden0)
+        net_in = torch.empty((N, eng.H), dtype=eng.dtype, device=actor.device)
+        pairs = []
+        for sim in range(S - 1):
+            a, b, c, d = ev(), ev(), ev(), ev()
+            a.record()
+            _, _, la = roots.traverse_tensors(actor.pool, net_in)
+            b.record()
+            value, reward, logits, _ = eng.recurrent(net_in, la, hidden_out=actor.pool[sim + 1])
+            logits = torch.nan_to_num_(logits, nan=0.0)
+            c.record()
+            roots.backprop_tensors(sim + 1, reward, value, logits)
+            d.record()
+            pairs.append((a, b, c, d))
+            depth_sum += float(roots.path_len_tensor().float().mean()) - 1.0  # edges root->leaf
+        torch.cuda.synchronize()
+        for a, b, c, d in pairs:
+            t_trav += a.elapsed_time(b) * 1e-3
+            t_back += c.elapsed_time(d) * 1e-3
+            n_launch += 1
+        actor._step_body()  # advance the real state so the next instrumented move sees fresh positions
+    return t_trav / n_launch, t_back / n_launch, n_launch, depth_sum / n_launch
+
+
+def cpu_baseline(game, A, S, sample_trees, moves):
+    """Oracle tree + oracle env on ONE host core: prepare + (S-1) x (traverse, backprop with recorded fake-net outputs)
+    + env step + encode per move.  Returns moves/s."""
+    import numpy as np
+    from oracle.cport import OracleEnv, OracleTree
+    rng = np.random.RandomState(0)
+    N = sample_trees
+    env = OracleEnv(game, np.arange(N))
+    env.reset()
+    obs, legal = env.observe()
+    tree = OracleTree(N, A, S, seed=0, value_delta_max=0.006)
+    noises = rng.dirichlet([0.3] * A, N).astype(np.float32)
+    logits0 = rng.randn(N, A).astype(np.float32)
+    rew = (rng.randint(-1, 2, (S - 1, N)) * (rng.rand(S - 1, N) < 0.3)).astype(np.float32)
+    val = (rng.rand(S - 1, N) * 25).astype(np.float32)
+    lg = rng.randn(S - 1, N, A).astype(np.float32)
+    zeros = np.zeros(N, np.float32)
+    t0 = time.perf_counter()
+    done_moves = 0
+    for _ in range(moves):
+        tree = OracleTree(N, A, S, seed=0, value_delta_max=0.006)  # the reference builds a new Roots per move
+        tree.prepare(0.25, noises, zeros, logits0, legal)
+        for sim in range(S - 1):
+            tree.traverse(sim, 19652, 1.25, 0.999)
+            tree.backprop(sim + 1, 0.999, rew[sim], val[sim], lg[sim])
+        dist = tree.distributions().astype(np.float64) * legal
+        act = (dist + 1e-3 * legal).argmax(1).astype(np.int32)
+        _, done, _ = env.step(act)
+        if done.any():
+            env.reset(done)
+        obs, legal = env.observe()
+        done_moves += N
+    dt = time.perf_counter() - t0
+    return done_moves / dt, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="full4096", choices=sorted(WORKLOADS))
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
+    ap.add_argument("--flush-every", type=int, default=10, help="drain + gather finished games every this many steps")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-sample-trees", type=int, default=1024)
+    ap.add_argument("--cpu-sample-moves", type=int, default=4)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from hanabizero_amd.config import make_config
+    from hanabizero_amd.dist import gather_records
+    from hanabizero_amd.selfplay import SelfPlayActor, record_nbytes
+
+    game, N, S, stack = WORKLOADS[args.workload]
+    cfg = make_config(game, simulations=S, stack=stack, p_mcts_num=N)
+    dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype]
+    engine = build_engine(cfg, dtype, device)
+    actor = SelfPlayActor(cfg, engine, N, rank=rank, seed=0, device=device, use_graph=not args.no_graph)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    games, rec_bytes = 0, 0
+
+    def flush():
+        nonlocal games, rec_bytes
+        rec = actor.drain()
+        got = gather_records(rec, dst=0)
+        if rank == 0 and got is not None:
+            games += int(got["meta"].shape[0])
+            rec_bytes += record_nbytes(got)
+
+    for _ in range(args.warmup):  # includes graph capture (2 eager steps + capture) on the first call
+        actor.step()
+    flush()
+    torch.cuda.synchronize()
+    barrier()
+    games, rec_bytes = 0, 0
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        actor.step()
+        if (k + 1) % args.flush_every == 0:
+            flush()
+    flush()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert int(actor.illegal_steps) == 0, "the actor produced an illegal move"
+
+    moves = world * N * args.steps
+    out = {
+        "metric": "selfplay_moves_per_sec",
+        "value": moves / elapsed,
+        "unit": "moves/s",
+        "sims_per_sec": moves * (S - 1) / elapsed,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 tree + integer env (bit-exact), %s nets" % args.dtype,
+        "data": "synthetic",
+        "config": {"workload": "%s 2p, %d envs/GPU, %d sims/move (%d run, as the reference), stack %d, random-init "
+                               "nets (heads N(0,0.1)), global obs" % (game, N, S, S - 1, stack),
+                   "envs_per_gpu": N, "simulations": S, "hipgraph": not args.no_graph, "parallelism": "actor-per-GPU x%d" % world,
+                   "games_finished": games, "record_bytes_gathered": rec_bytes},
+    }
+
+    if rank == 0 and not args.no_roofline:
+        t_trav, t_back, launches, dbar = instrumented_search(actor, moves=2)
+        A, H, e = cfg.action_space_size, engine.H, (4 if dtype == torch.float32 else 2)
+        sbar = (S - 1) / 2.0
+        b_trav = N * (16 * A * dbar + 2 * H * e)                                  # child rows per level + hidden row in/out
+        b_back = N * (4 * A + 16 * A + 16 + 16 * (dbar + 1) + 12 * sbar)          # logits in, child rows out, backup, min-max
+        dom = "k_traverse" if t_trav >= t_back else "k_backprop"
+        byt, dur = (b_trav, t_trav) if dom == "k_traverse" else (b_back, t_back)
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(args.workload, {}).get(dom)
+            except Exception:
+                traffic = None
+        out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": byt / dur / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": byt / dur / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                           "bytes_per_launch": byt, "avg_launch_us": dur * 1e6, "launches_timed": launches,
+                           "mean_path_edges": dbar,
+                           "other": {"k_traverse": {"avg_launch_us": t_trav * 1e6, "GBps": b_trav / t_trav / 1e9},
+                                     "k_backprop": {"avg_launch_us": t_back * 1e6, "GBps": b_back / t_back / 1e9}}}
+        flops = engine.flops_per_sample() * N
+        out["nets"] = {"recurrent_flop_per_launch": flops, "note": "GEMMs via hipBLASLt/rocBLAS (MFMA); see profiles/"}
+
+    if rank == 0 and not args.no_cpu_baseline:
+        v, dt = cpu_baseline(game, cfg.action_space_size, S, args.cpu_sample_trees, args.cpu_sample_moves)
+        out["cpu_baseline"] = {"value": v, "unit": "moves/s", "cores": 1, "kind": "port",
+                               "sample": "oracle tree+env (no nets), %d envs x %d moves x %d sims, %.1f s on 1 core" % (
+                                   args.cpu_sample_trees, args.cpu_sample_moves, S - 1, dt)}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

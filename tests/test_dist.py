@@ -1,0 +1,57 @@
+"""CPU, world_size 2, gloo: the N>1 exchange steps (record gather to the replay owner, weight broadcast)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _fake_rec(n, seed, T=6, A=11, W=7):
+    rng = np.random.RandomState(seed)
+    return dict(action=rng.randint(0, A, (n, T)).astype(np.int8), reward=rng.randint(-2, 3, (n, T)).astype(np.int8),
+                value=rng.rand(n, T).astype(np.float32), visits=rng.randint(0, 9, (n, T, A)).astype(np.int16),
+                legal=rng.randint(0, 2, (n, T + 1, A)).astype(np.uint8), obs=rng.randint(-2**31, 2**31 - 1, (n, T + 1, W)).astype(np.int32),
+                meta=rng.randint(0, 100, (n, 4)).astype(np.int32))
+
+
+def _worker(rank, world, port, counts, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hanabizero_amd.dist import broadcast_weights, gather_records
+    ok = True
+    for rnd, cnts in enumerate(counts):
+        rec = _fake_rec(cnts[rank], 100 * rnd + rank) if cnts[rank] else None
+        got = gather_records(rec, dst=0)
+        if rank == 0:
+            want = [_fake_rec(c, 100 * rnd + r) for r, c in enumerate(cnts) if c]
+            if not want:
+                ok &= got is None
+            else:
+                for k in want[0]:
+                    ok &= bool((got[k] == np.concatenate([w[k] for w in want], 0)).all()) and got[k].dtype == want[0][k].dtype
+        else:
+            ok &= got is None
+    sd = {"b": torch.full((3,), float(rank)), "a": torch.arange(4.0) * (rank + 1)}
+    out = broadcast_weights(sd, src=0)
+    ok &= bool((out["b"] == 0).all()) and bool((out["a"] == torch.arange(4.0)).all())
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_gather_and_broadcast_world2_gloo():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    counts = [(3, 5), (0, 2), (4, 0), (0, 0)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, counts, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert res == [(0, True), (1, True)]
