@@ -29,8 +29,10 @@ def _load():
         "hz_tree_set_params": [V, I, F, F, F, U64, U32],
         "hz_tree_prepare": [V, F, V, V, V, V, V],
         "hz_tree_traverse": [V, I, V, V, V, V],
-        "hz_tree_traverse_gather": [V, I, V, V, V, V, I, I, V, I, V],
+        "hz_tree_traverse_gather": [V, I, V, V, V, V, I, I, V, I, I, V],
+        "hz_tree_backprop_nets": [V, I, V, I64, V, I64, I, I, V, I64, I, V, V, V],
         "hz_tree_backprop": [V, I, V, V, V, V],
+        "hz_support_to_scalar": [V, I64, I, I, I, V, I, V],
         "hz_tree_get_distributions": [V, V, V],
         "hz_tree_get_values": [V, V, V],
         "hz_tree_get_trajectories": [V, V, I, V],
@@ -48,6 +50,8 @@ def _load():
         # include/hz_selfplay.h
         "hz_select_action": [I, I, V, V, V, F, I, V, V, V],
         "hz_rows_scatter": [V, V, I64, V, I, V],
+        # include/hz_netglue.h
+        "hz_add_relu": [V, I64, V, I64, I, I, I, V],
         "hz_test_expf": [V, V, I64, V],
         "hz_test_expf_checksum": [V, V],
     }

@@ -164,7 +164,8 @@ __global__ __launch_bounds__(256) void k_prepare(TreeView tv, float frac, const 
 __global__ __launch_bounds__(256) void k_traverse(TreeView tv, int sim, int32_t* __restrict__ out_ix,
                                                   int32_t* __restrict__ out_iy, int32_t* __restrict__ out_la,
                                                   const uint8_t* __restrict__ pool, int row_bytes,
-                                                  uint8_t* __restrict__ net_in, int net_in_stride_bytes) {
+                                                  uint8_t* __restrict__ net_in, int net_in_stride_bytes,
+                                                  int onehot_cols, int dtype) {
   const int lane = threadIdx.x & 63;
   const int tree = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (tree >= tv.N) return;
@@ -258,15 +259,73 @@ __global__ __launch_bounds__(256) void k_traverse(TreeView tv, int sim, int32_t*
     uint8_t* dst = net_in + (size_t)tree * (size_t)net_in_stride_bytes;
     for (int off = lane * 16; off < row_bytes; off += 64 * 16)
       *reinterpret_cast<uint4*>(dst + off) = *reinterpret_cast<const uint4*>(src + off);
+    // action_one_hot of MuZeroNet.dynamics (config/hanabi_control/model.py:215-219), appended after the state
+    for (int c = lane; c < onehot_cols; c += 64) {
+      const bool hot = (c == action);
+      if (dtype == HZ_F32) reinterpret_cast<float*>(dst + row_bytes)[c] = hot ? 1.0f : 0.0f;
+      else reinterpret_cast<uint16_t*>(dst + row_bytes)[c] = hot ? (dtype == HZ_BF16 ? 0x3f80u : 0x3c00u) : 0u;
+    }
   }
 }
 
 // ------------------------------------------------------------------------------------------ backprop
 // cmulti_back_propagate (cnode.cpp:337-344): expand (all legal) + cback_propagate (:317-335) + update_tree_q
 // (:296-315, here a wave min/max over the cached per-entry q values instead of a DFS of the whole tree).
-__global__ __launch_bounds__(256) void k_backprop(TreeView tv, int e_new, const float* __restrict__ rewards,
-                                                  const float* __restrict__ values,
-                                                  const float* __restrict__ logits) {
+// Where the leaf's (reward, value, policy logits) come from.  Plain: three fp32 arrays (the cytree signature).
+// Fused: straight from the network heads -- categorical reward/value logits and policy logits in the net's dtype;
+// the kernel applies core/mcts.py:48-49 (NaN logits -> 0) and core/config.py:210-232 (softmax . support -> h^-1).
+struct NetOut {
+  const float* rewards;
+  const float* values;
+  const float* logits;
+  const void* reward_logits;
+  const void* value_logits;
+  const void* policy_logits;
+  long long reward_stride, value_stride, policy_stride;  // elements
+  int support_size, support_min, dtype;
+  float* out_rewards;
+  float* out_values;
+};
+
+__device__ __forceinline__ float load_as_f32(const void* p, long long i, int dtype) {
+  if (dtype == HZ_F32) return ((const float*)p)[i];
+  const uint16_t h = ((const uint16_t*)p)[i];
+  if (dtype == HZ_BF16) return __uint_as_float((uint32_t)h << 16);
+  return (float)(*reinterpret_cast<const _Float16*>(&h));
+}
+
+__device__ __forceinline__ float hz_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// inverse_scalar_transform (core/config.py:210-232, delta = 1, epsilon = 0.001) of one row of V categorical
+// logits over the integer support [support_min, support_min + V), by one wave.  Tolerance-level arithmetic (this is
+// a network output, north-star tolerance 1e-3); the tree arithmetic that consumes the scalar stays exact.
+__device__ __forceinline__ float support_to_scalar(const void* row, int V, int support_min, int dtype, int lane) {
+  float m = -INFINITY;
+  for (int i = lane; i < V; i += 64) m = fmaxf(m, load_as_f32(row, i, dtype));
+  m = hz_wave_max(m);
+  float se = 0.0f, sw = 0.0f;
+  for (int i = lane; i < V; i += 64) {
+    const float e = __expf(load_as_f32(row, i, dtype) - m);
+    se += e;
+    sw += e * (float)(support_min + i);
+  }
+  se = hz_wave_sum(se);
+  sw = hz_wave_sum(sw);
+  const float v = sw / se;
+  const float eps = 0.001f;
+  const float t = (sqrtf(1.0f + 4.0f * eps * (fabsf(v) + 1.0f + eps)) - 1.0f) / (2.0f * eps);
+  float out = t * t - 1.0f;
+  if (v < 0.0f) out = -out;
+  if (out != out) out = 0.0f;  // nan_part -> 0 (config.py:229-232)
+  return out;
+}
+
+template <bool FUSED>
+__global__ __launch_bounds__(256) void k_backprop(TreeView tv, int e_new, NetOut no) {
   extern __shared__ float lds_q[];  // [4 waves][S]
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -283,7 +342,15 @@ __global__ __launch_bounds__(256) void k_backprop(TreeView tv, int e_new, const 
   for (int e = 1 + lane; e < e_new; e += 64) lq[e] = tv.qsa[(size_t)tree * S + e];
 
   // expand the leaf: priors of the new entry's children
-  const float logit = on ? logits[(size_t)tree * A + lane] : 0.0f;
+  float logit = 0.0f;
+  if (on) {
+    if (FUSED) {
+      logit = load_as_f32(no.policy_logits, (long long)tree * no.policy_stride + lane, no.dtype);
+      if (logit != logit) logit = 0.0f;  // core/mcts.py:48-49
+    } else {
+      logit = no.logits[(size_t)tree * A + lane];
+    }
+  }
   const uint64_t all = (A >= 64) ? ~0ull : ((1ull << A) - 1ull);
   const float prior = expand_prior(logit, all, lane, A);
   if (on) {
@@ -293,8 +360,21 @@ __global__ __launch_bounds__(256) void k_backprop(TreeView tv, int e_new, const 
   }
 
   const int npairs = tv.path_len[tree] - 1;  // edges on the path; the node below edge k is at depth k+1
-  float G = values[tree];                    // bootstrap_value (cnode.cpp:318)
-  const float leaf_reward = rewards[tree];
+  float G, leaf_reward;                      // bootstrap_value (cnode.cpp:318) and the leaf's reward
+  if (FUSED) {
+    const int es = (no.dtype == HZ_F32) ? 4 : 2;
+    const uint8_t* vrow = (const uint8_t*)no.value_logits + (size_t)tree * (size_t)no.value_stride * es;
+    const uint8_t* rrow = (const uint8_t*)no.reward_logits + (size_t)tree * (size_t)no.reward_stride * es;
+    G = support_to_scalar(vrow, no.support_size, no.support_min, no.dtype, lane);
+    leaf_reward = support_to_scalar(rrow, no.support_size, no.support_min, no.dtype, lane);
+    if (lane == 0) {
+      if (no.out_values) no.out_values[tree] = G;
+      if (no.out_rewards) no.out_rewards[tree] = leaf_reward;
+    }
+  } else {
+    G = no.values[tree];
+    leaf_reward = no.rewards[tree];
+  }
   for (int base = ((npairs - 1) >> 6) << 6; base >= 0; base -= 64) {
     const int k = base + lane;
     const bool act = k < npairs;
@@ -485,32 +565,35 @@ extern "C" int hz_tree_prepare(hz_tree_t* t, float frac, const float* noises, co
 }
 
 static int launch_traverse(hz_tree_t* t, int sim, int32_t* ix, int32_t* iy, int32_t* la, const void* pool,
-                           int row_bytes, void* net_in, int stride_bytes, void* stream) {
+                           int row_bytes, void* net_in, int stride_bytes, int onehot_cols, int dtype, void* stream) {
   HZ_REQUIRE(t != nullptr, "hz_tree_traverse: NULL handle");
   HZ_REQUIRE(t->next_entry >= 1, "hz_tree_traverse: call hz_tree_prepare first");
   HZ_REQUIRE(ix && iy && la, "hz_tree_traverse: output pointers must not be NULL");
   HZ_REQUIRE(sim >= 0 && sim < 65536, "hz_tree_traverse: sim out of range (%d)", sim);
   hipLaunchKernelGGL(k_traverse, tree_grid(t), dim3(256), 0, (hipStream_t)stream, view(t), sim, ix, iy, la,
-                     (const uint8_t*)pool, row_bytes, (uint8_t*)net_in, stride_bytes);
+                     (const uint8_t*)pool, row_bytes, (uint8_t*)net_in, stride_bytes, onehot_cols, dtype);
   HZ_HIP(hipGetLastError());
   return 0;
 }
 
 extern "C" int hz_tree_traverse(hz_tree_t* t, int sim, int32_t* ix, int32_t* iy, int32_t* la, void* stream) {
-  return launch_traverse(t, sim, ix, iy, la, nullptr, 0, nullptr, 0, stream);
+  return launch_traverse(t, sim, ix, iy, la, nullptr, 0, nullptr, 0, 0, HZ_F32, stream);
 }
 
 extern "C" int hz_tree_traverse_gather(hz_tree_t* t, int sim, int32_t* ix, int32_t* iy, int32_t* la,
                                        const void* pool, int hidden, int dtype, void* net_in, int net_in_stride,
-                                       void* stream) {
+                                       int action_onehot_cols, void* stream) {
   HZ_REQUIRE(pool != nullptr && net_in != nullptr, "hz_tree_traverse_gather: pool and net_in must not be NULL");
   HZ_REQUIRE(dtype == HZ_F32 || dtype == HZ_BF16 || dtype == HZ_F16, "hz_tree_traverse_gather: bad dtype %d", dtype);
   const int es = dtype == HZ_F32 ? 4 : 2;
   HZ_REQUIRE(hidden > 0 && (hidden * es) % 16 == 0, "hz_tree_traverse_gather: hidden*elem_size must be a multiple of 16 B");
-  HZ_REQUIRE(net_in_stride >= hidden && (net_in_stride * es) % 16 == 0,
-             "hz_tree_traverse_gather: net_in_stride*elem_size must be a multiple of 16 B and >= hidden");
+  HZ_REQUIRE(action_onehot_cols == 0 || action_onehot_cols >= t->A,
+             "hz_tree_traverse_gather: action_onehot_cols must be 0 or >= num_actions");
+  HZ_REQUIRE(net_in_stride >= hidden + action_onehot_cols && (net_in_stride * es) % 16 == 0,
+             "hz_tree_traverse_gather: net_in_stride*elem_size must be a multiple of 16 B and >= hidden + one-hot columns");
   HZ_REQUIRE(((uintptr_t)pool % 16) == 0 && ((uintptr_t)net_in % 16) == 0, "hz_tree_traverse_gather: pointers must be 16-B aligned");
-  return launch_traverse(t, sim, ix, iy, la, pool, hidden * es, net_in, net_in_stride * es, stream);
+  return launch_traverse(t, sim, ix, iy, la, pool, hidden * es, net_in, net_in_stride * es, action_onehot_cols, dtype,
+                         stream);
 }
 
 extern "C" int hz_tree_backprop(hz_tree_t* t, int hidden_state_index_x, const float* rewards, const float* values,
@@ -523,8 +606,40 @@ extern "C" int hz_tree_backprop(hz_tree_t* t, int hidden_state_index_x, const fl
              "hz_tree_backprop: hidden_state_index_x must advance 1,2,3,... after prepare (expected %d, got %d)",
              t->next_entry, hidden_state_index_x);
   const size_t lds = (size_t)4 * t->S * sizeof(float);
-  hipLaunchKernelGGL(k_backprop, tree_grid(t), dim3(256), lds, (hipStream_t)stream, view(t), hidden_state_index_x,
-                     rewards, values, logits);
+  NetOut no;
+  memset(&no, 0, sizeof(no));
+  no.rewards = rewards; no.values = values; no.logits = logits;
+  hipLaunchKernelGGL(k_backprop<false>, tree_grid(t), dim3(256), lds, (hipStream_t)stream, view(t),
+                     hidden_state_index_x, no);
+  HZ_HIP(hipGetLastError());
+  t->next_entry = hidden_state_index_x + 1;
+  return 0;
+}
+
+extern "C" int hz_tree_backprop_nets(hz_tree_t* t, int hidden_state_index_x, const void* reward_logits,
+                                     int64_t reward_stride, const void* value_logits, int64_t value_stride,
+                                     int support_size, int support_min, const void* policy_logits,
+                                     int64_t policy_stride, int dtype, float* out_rewards, float* out_values,
+                                     void* stream) {
+  HZ_REQUIRE(t != nullptr, "hz_tree_backprop_nets: NULL handle");
+  HZ_REQUIRE(reward_logits && value_logits && policy_logits, "hz_tree_backprop_nets: input pointers must not be NULL");
+  HZ_REQUIRE(dtype == HZ_F32 || dtype == HZ_BF16 || dtype == HZ_F16, "hz_tree_backprop_nets: bad dtype %d", dtype);
+  HZ_REQUIRE(support_size > 0 && reward_stride >= support_size && value_stride >= support_size && policy_stride >= t->A,
+             "hz_tree_backprop_nets: strides shorter than the rows");
+  HZ_REQUIRE(hidden_state_index_x >= 1 && hidden_state_index_x < t->S,
+             "hz_tree_backprop_nets: hidden_state_index_x=%d outside [1, num_simulations=%d)", hidden_state_index_x, t->S);
+  HZ_REQUIRE(hidden_state_index_x == t->next_entry,
+             "hz_tree_backprop_nets: hidden_state_index_x must advance 1,2,3,... after prepare (expected %d, got %d)",
+             t->next_entry, hidden_state_index_x);
+  NetOut no;
+  memset(&no, 0, sizeof(no));
+  no.reward_logits = reward_logits; no.value_logits = value_logits; no.policy_logits = policy_logits;
+  no.reward_stride = reward_stride; no.value_stride = value_stride; no.policy_stride = policy_stride;
+  no.support_size = support_size; no.support_min = support_min; no.dtype = dtype;
+  no.out_rewards = out_rewards; no.out_values = out_values;
+  const size_t lds = (size_t)4 * t->S * sizeof(float);
+  hipLaunchKernelGGL(k_backprop<true>, tree_grid(t), dim3(256), lds, (hipStream_t)stream, view(t), hidden_state_index_x,
+                     no);
   HZ_HIP(hipGetLastError());
   t->next_entry = hidden_state_index_x + 1;
   return 0;
@@ -577,6 +692,28 @@ extern "C" int hz_tree_get_root_priors(hz_tree_t* t, float* out, void* stream) {
 }
 
 extern "C" int64_t hz_tree_hbm_bytes(const hz_tree_t* t) { return t ? t->bytes : 0; }
+
+// the scalar transform of hz_tree_backprop_nets on its own (same device function, hence bit-identical to it)
+__global__ __launch_bounds__(256) void k_support_to_scalar(const uint8_t* __restrict__ logits, long long stride_bytes,
+                                                           int V, int support_min, int dtype, float* __restrict__ out,
+                                                           int n) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const float v = support_to_scalar(logits + (size_t)row * (size_t)stride_bytes, V, support_min, dtype, lane);
+  if (lane == 0) out[row] = v;
+}
+
+extern "C" int hz_support_to_scalar(const void* logits, int64_t stride, int support_size, int support_min, int dtype,
+                                    float* out, int num_rows, void* stream) {
+  HZ_REQUIRE(logits && out && num_rows > 0 && support_size > 0 && stride >= support_size, "hz_support_to_scalar: bad argument");
+  HZ_REQUIRE(dtype == HZ_F32 || dtype == HZ_BF16 || dtype == HZ_F16, "hz_support_to_scalar: bad dtype %d", dtype);
+  const int es = dtype == HZ_F32 ? 4 : 2;
+  hipLaunchKernelGGL(k_support_to_scalar, dim3((num_rows + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                     (const uint8_t*)logits, (long long)stride * es, support_size, support_min, dtype, out, num_rows);
+  HZ_HIP(hipGetLastError());
+  return 0;
+}
 
 // ------------------------------------------------------------------------------------------ test hooks
 // Device expf over an array, and a blocked checksum over ALL 2^32 float bit patterns (tests/test_hip_math.py

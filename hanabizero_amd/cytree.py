@@ -154,9 +154,10 @@ class Roots:
         self._sim = 0
 
     # -- device-resident fast path ------------------------------------------------------------------
-    def traverse_tensors(self, pool=None, net_in=None):
+    def traverse_tensors(self, pool=None, net_in=None, onehot_cols=0):
         """One descent per tree.  Returns (ix, iy, last_action) int32 CUDA tensors (reused buffers).
-        With `pool` [S, N, H] and `net_in` [N, >=H]: also gathers pool[ix, tree] into net_in[:, :H]."""
+        With `pool` [S, N, H] and `net_in` [N, >=H]: also gathers pool[ix, tree] into net_in[:, :H] and, with
+        onehot_cols > 0, writes one_hot(last_action) into net_in[:, H:H+onehot_cols]."""
         if pool is None:
             check(lib.hz_tree_traverse(self._h, self._sim, self._ix.data_ptr(), self._iy.data_ptr(),
                                        self._la.data_ptr(), _stream()), "hz_tree_traverse")
@@ -166,7 +167,7 @@ class Roots:
             assert net_in.stride(1) == 1
             check(lib.hz_tree_traverse_gather(self._h, self._sim, self._ix.data_ptr(), self._iy.data_ptr(),
                                               self._la.data_ptr(), pool.data_ptr(), pool.shape[2], dt,
-                                              net_in.data_ptr(), net_in.stride(0), _stream()),
+                                              net_in.data_ptr(), net_in.stride(0), int(onehot_cols), _stream()),
                   "hz_tree_traverse_gather")
         self._sim += 1
         return self._ix, self._iy, self._la
@@ -179,6 +180,21 @@ class Roots:
         check(lib.hz_tree_backprop(self._h, int(hidden_state_index_x), rw.data_ptr(), vl.data_ptr(), lg.data_ptr(),
                                    _stream()), "hz_tree_backprop")
         self._keep_bp = (rw, vl, lg)
+
+    def backprop_nets_tensors(self, hidden_state_index_x, reward_logits, value_logits, support_size, support_min,
+                              policy_logits, out_rewards=None, out_values=None):
+        """multi_back_propagate fed by raw head outputs (strided 2-D CUDA tensors of one dtype): include/hz_tree.h
+        hz_tree_backprop_nets."""
+        dt = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[value_logits.dtype]
+        for t in (reward_logits, value_logits, policy_logits):
+            assert t.dtype == value_logits.dtype and t.stride(1) == 1 and t.shape[0] == self.root_num
+        check(lib.hz_tree_backprop_nets(self._h, int(hidden_state_index_x), reward_logits.data_ptr(),
+                                        reward_logits.stride(0), value_logits.data_ptr(), value_logits.stride(0),
+                                        int(support_size), int(support_min), policy_logits.data_ptr(),
+                                        policy_logits.stride(0), dt,
+                                        None if out_rewards is None else out_rewards.data_ptr(),
+                                        None if out_values is None else out_values.data_ptr(), _stream()),
+              "hz_tree_backprop_nets")
 
     def distributions_tensor(self):
         out = torch.empty((self.root_num, self.action_num), dtype=torch.int32, device=self.device)

@@ -34,12 +34,14 @@ class MCTS(object):
             if pool is None:
                 pool = torch.empty((S, num, H), dtype=model.dtype, device=roots.device)
             pool[0].copy_(h0)
-            net_in = torch.empty((num, H), dtype=model.dtype, device=roots.device)
+            oh = model.onehot_cols
+            net_in = torch.empty((num, H + oh), dtype=model.dtype, device=roots.device)
             for index_simulation in range(S - 1):
-                _, _, last_actions = roots.traverse_tensors(pool, net_in)
-                value, reward, logits, _ = model.recurrent(net_in, last_actions, hidden_out=pool[index_simulation + 1])
-                logits = torch.nan_to_num_(logits, nan=0.0, posinf=float("inf"), neginf=float("-inf"))
-                roots.backprop_tensors(index_simulation + 1, reward, value, logits)
+                # select + gather + one-hot (1 kernel) -> dynamics/prediction GEMMs -> scalar transform + NaN
+                # clearing + expand + backup + min-max (1 kernel)
+                roots.traverse_tensors(pool, net_in, onehot_cols=oh)
+                r_log, v_log, p_log = model.recurrent_heads(net_in, pool[index_simulation + 1])
+                roots.backprop_nets_tensors(index_simulation + 1, r_log, v_log, model.V, -model.support, p_log)
 
     def _run_multi_compat(self, roots, model, hidden_state_roots):
         """The reference loop verbatim in structure (lists / numpy through the drop-in cytree API): lets an unmodified

@@ -182,13 +182,16 @@ class MuZeroNetFull(_HanabiNet):
 
 
 # ------------------------------------------------------------------------------------------------ inference engine
-def _fold(linear, bn):
+def _fold(linear, bn=None):
     """eval-mode BatchNorm1d(Linear(x)) == x @ W'^T + b' (fp32 fold)."""
     w, b = linear.weight.detach().float(), linear.bias.detach().float()
     if bn is None:
         return w, b
     s = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
     return w * s[:, None], (b - bn.running_mean.detach().float()) * s + bn.bias.detach().float()
+
+
+_FUSED_ACT = hasattr(torch, "_addmm_activation")
 
 
 class _Lin:
@@ -199,6 +202,8 @@ class _Lin:
         self.b = b.to(device=device, dtype=dtype)
 
     def __call__(self, x, relu=False, out=None):
+        if relu and out is None and _FUSED_ACT:
+            return torch._addmm_activation(self.b, x, self.wt, use_gelu=False)  # bias + ReLU in the GEMM epilogue
         y = torch.addmm(self.b, x, self.wt, out=out) if out is not None else torch.addmm(self.b, x, self.wt)
         return torch.relu_(y) if relu else y
 
@@ -232,6 +237,11 @@ class InferenceEngine:
         w1, b1 = _fold(dyn.fc1, dyn.bn1)
         self.dyn1 = _Lin(w1[:, :self.H], b1, self.dtype, self.device)
         self.dyn1_act = w1[:, self.H:].t().contiguous().to(device=self.device, dtype=self.dtype)  # [A, H]
+        # ... and the same layer over the [state | one-hot | 0-pad] rows the traverse kernel writes (K padded to 32)
+        self.onehot_cols = ((self.A + 31) // 32) * 32
+        w1p = torch.zeros(w1.shape[0], self.H + self.onehot_cols)
+        w1p[:, :w1.shape[1]] = w1
+        self.dyn1p = _Lin(w1p, b1, self.dtype, self.device)
         self.dyn2, self.dyn3 = L(dyn.fc2, dyn.bn2), L(dyn.fc3, dyn.bn3)
         # the three heads' first layers share their input: one GEMM [512 -> 3h] (reward | actor | value)
         ws, bs = zip(_fold(rw[0], rw[1]), _fold(ac[0], ac[1]), _fold(va[0], va[1]))
@@ -242,8 +252,28 @@ class InferenceEngine:
             self.rw_tail = [L(rw[3], rw[4]), L(rw[6])]
             self.ac_tail = [L(ac[3].fc1, ac[3].bn1), L(ac[3].fc2, ac[3].bn2), L(ac[4])]
             self.va_tail = [L(va[3], va[4]), L(va[6])]
+            # batched tails (reward | actor | value): layer 2 = three [h -> h] GEMMs, layer 3 = three [h -> h]
+            # GEMMs with the 2*support+1 wide outputs zero-padded to h
+            self.bw2, self.bb2 = self._stack([_fold(rw[3], rw[4]), _fold(ac[3].fc1, ac[3].bn1), _fold(va[3], va[4])], self.h)
+            self.bw3, self.bb3 = self._stack([_fold(rw[6]), _fold(ac[3].fc2, ac[3].bn2), _fold(va[6])], self.h)
         else:
             self.rw_tail, self.ac_tail, self.va_tail = [L(rw[3])], [L(ac[3])], [L(va[3])]
+            self.out_pad = ((max(2 * self.support + 1, self.A) + 31) // 32) * 32
+            self.bw3, self.bb3 = self._stack([_fold(rw[3]), _fold(ac[3]), _fold(va[3])], self.out_pad)
+        self.V = 2 * self.support + 1
+
+    def _stack(self, folded, out_pad):
+        """[(W [o,i], b [o])] * 3 -> Wt [3, i, out_pad], b [3, 1, out_pad] (zero padded) in the engine dtype."""
+        ws, bs = [], []
+        for w, b in folded:
+            wp = torch.zeros(out_pad, w.shape[1])
+            wp[:w.shape[0]] = w
+            bp = torch.zeros(out_pad)
+            bp[:b.shape[0]] = b
+            ws.append(wp.t().contiguous())
+            bs.append(bp[None, :])
+        return (torch.stack(ws).to(device=self.device, dtype=self.dtype),
+                torch.stack(bs).to(device=self.device, dtype=self.dtype))
 
     # -- pieces ---------------------------------------------------------------------------------------
     def _scalar(self, logits):
@@ -297,6 +327,52 @@ class InferenceEngine:
         state = self._dynamics(hidden, action.long(), out=hidden_out)
         logits, value, reward = self._tails(self.heads1(state, relu=True), with_reward=True)
         return self._scalar(value), self._scalar(reward), logits, state
+
+    def support_to_scalar(self, logits):
+        """inverse_value/reward_transform of [N, >=V] head outputs by the HIP kernel the fused backup uses."""
+        import ctypes as C
+        from ._lib import check, lib
+        dt = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[logits.dtype]
+        out = torch.empty(logits.shape[0], dtype=torch.float32, device=logits.device)
+        check(lib.hz_support_to_scalar(logits.data_ptr(), logits.stride(0), self.V, -self.support, dt, out.data_ptr(),
+                                       logits.shape[0], C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+              "hz_support_to_scalar")
+        return out
+
+    def _add_relu(self, y, res):
+        """y = relu(y + res) in place: one HIP kernel (include/hz_netglue.h) on the GPU."""
+        if y.device.type != "cuda":
+            return torch.relu_(y.add_(res))
+        import ctypes as C
+        from ._lib import check, lib
+        dt = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[y.dtype]
+        assert y.stride(1) == 1 and res.stride(1) == 1 and y.shape == res.shape
+        check(lib.hz_add_relu(y.data_ptr(), y.stride(0), res.data_ptr(), res.stride(0), y.shape[0], y.shape[1], dt,
+                              C.c_void_p(torch.cuda.current_stream().cuda_stream)), "hz_add_relu")
+        return y
+
+    @torch.no_grad()
+    def recurrent_heads(self, net_in, hidden_out):
+        """The search loop's form of recurrent_inference: `net_in` [N, H + onehot_cols] rows = [state | one-hot action
+        | 0] as written by hz_tree_traverse_gather; the next hidden state goes to `hidden_out` [N, H] (its slot of the
+        pool).  Returns RAW head outputs (reward_logits, value_logits, policy_logits) as strided views in the engine
+        dtype, rows of width >= V / V / A -- hz_tree_backprop_nets turns them into scalars and sanitises NaNs."""
+        N, H, h = net_in.shape[0], self.H, self.h
+        state_in = net_in[:, :H]
+        if self.full:  # NewDynamicNet
+            y = self.dyn2(self.dyn1p(net_in, relu=True), relu=True)
+            s = self._add_relu(self.dyn3(y, out=hidden_out), state_in)
+            z = self.heads1(s, relu=True)
+            t2 = torch.relu_(torch.baddbmm(self.bb2, z.view(N, 3, h).transpose(0, 1), self.bw2))
+            t3 = torch.baddbmm(self.bb3, t2, self.bw3)
+            ya = self._add_relu(t3[1], z[:, h:2 * h])  # NewResMLP skip of the actor head
+            return t3[0], t3[2], self.ac_tail[2](ya)
+        y = self._add_relu(self.dyn1p(net_in), state_in)  # DynamicNet: skip after the first layer
+        y = self.dyn2(y, relu=True)
+        s = torch.relu_(self.dyn3(y, out=hidden_out))
+        z = self.heads1(s, relu=True)
+        t3 = torch.baddbmm(self.bb3, z.view(N, 3, h).transpose(0, 1), self.bw3)
+        return t3[0], t3[2], t3[1]
 
     def flops_per_sample(self):
         """MACs*2 of one recurrent inference (for the MFMA roofline line in bench.py)."""

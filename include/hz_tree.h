@@ -63,12 +63,15 @@ int hz_tree_traverse(hz_tree_t* t, int sim, int32_t* out_ix, int32_t* out_iy, in
                      void* stream);
 
 /* hz_tree_traverse fused with the hidden-state gather of core/mcts.py:31-36: additionally copies
- * pool[ix][tree][0:hidden] into net_in[tree][0:hidden] (row stride net_in_stride elements).
+ * pool[ix][tree][0:hidden] into net_in[tree][0:hidden] (row stride net_in_stride elements) and, when
+ * action_onehot_cols > 0, writes one_hot(last_action) into net_in[tree][hidden : hidden+action_onehot_cols]
+ * (the concat of MuZeroNet.dynamics, config/hanabi_control/model.py:215-219; columns >= num_actions are zeroed
+ * so the caller can pad the first dynamics layer's K to a GEMM-friendly size).
  *   pool   [num_simulations][N][hidden] elements of `dtype` (entry e = hidden state written after sim e-1;
  *          entry 0 = root states), resident in HBM for the whole move. */
 int hz_tree_traverse_gather(hz_tree_t* t, int sim, int32_t* out_ix, int32_t* out_iy, int32_t* out_last_action,
                             const void* pool, int hidden, int dtype, void* net_in, int net_in_stride,
-                            void* stream);
+                            int action_onehot_cols, void* stream);
 
 /* multi_back_propagate (cytree.pyx:87-94 -> cmulti_back_propagate cnode.cpp:337-344): expand each leaf
  * (all-legal mask) with (hidden_state_index_x, tree) / reward / policy logits, back up `values` along the
@@ -77,6 +80,26 @@ int hz_tree_traverse_gather(hz_tree_t* t, int sim, int32_t* out_ix, int32_t* out
  *   core/mcts.py:48-49; hz_tree_backprop treats them exactly as the reference's expand does). */
 int hz_tree_backprop(hz_tree_t* t, int hidden_state_index_x, const float* rewards, const float* values,
                      const float* policy_logits, void* stream);
+
+/* hz_tree_backprop fed straight from the network heads (what core/mcts.py:44-50 + core/model.py:79-80 do on the
+ * host between recurrent_inference and multi_back_propagate):
+ *   reward_logits / value_logits [N] rows of `support_size` categorical logits over the integers
+ *       support_min .. support_min+support_size-1, row strides in elements, element type `dtype`;
+ *       scalar = inverse_scalar_transform (core/config.py:210-232), NaN -> 0;
+ *   policy_logits [N] rows of num_actions logits (dtype, stride), NaN -> 0 (core/mcts.py:48-49);
+ *   out_rewards / out_values [N] f32 (may be NULL): the scalars that entered the tree, for inspection.
+ * The scalar transform is a network output (tolerance 1e-3); the tree update that consumes it is the same exact
+ * arithmetic as hz_tree_backprop. */
+int hz_tree_backprop_nets(hz_tree_t* t, int hidden_state_index_x, const void* reward_logits, int64_t reward_stride,
+                          const void* value_logits, int64_t value_stride, int support_size, int support_min,
+                          const void* policy_logits, int64_t policy_stride, int dtype, float* out_rewards,
+                          float* out_values, void* stream);
+
+/* The scalar transform of hz_tree_backprop_nets alone (inverse_value_transform / inverse_reward_transform,
+ * core/config.py:204-232): logits [num_rows] rows of support_size (stride elements, dtype) -> out [num_rows] f32.
+ * Same device code as the fused kernel, hence bit-identical to what entered the tree. */
+int hz_support_to_scalar(const void* logits, int64_t stride, int support_size, int support_min, int dtype, float* out,
+                         int num_rows, void* stream);
 
 /* Roots.get_distributions / get_values / get_trajectories (cytree.pyx:53-60 -> cnode.cpp:266-292). */
 int hz_tree_get_distributions(hz_tree_t* t, int32_t* out /* [N][A] */, void* stream);

@@ -134,3 +134,72 @@ def test_traverse_gather_moves_the_right_rows():
             assert torch.equal(net_in[:, :H], want)
             assert (net_in[:, H:] == 0).all()
             roots.backprop_tensors(sim + 1, c["rewards"][sim], c["values"][sim], c["logits"][sim])
+
+
+def test_traverse_gather_writes_one_hot_action():
+    from hanabizero_amd import cytree as tree
+    N, A, S, H, OH = 128, 20, 8, 512, 32
+    c = _random_case(N, A, S, 43)
+    for dtype in (torch.bfloat16, torch.float16, torch.float32):
+        roots = tree.Roots(N, A, S, tie_seed=4)
+        roots.prepare(0.25, c["noises"], np.zeros(N), c["logits0"], c["legal"])
+        roots.set_params(19652, 1.25, 0.999, 0.006)
+        pool = torch.randn(S, N, H, device="cuda").to(dtype)
+        net_in = torch.full((N, H + OH), 5.0, device="cuda", dtype=dtype)
+        for sim in range(S - 1):
+            ix, iy, la = roots.traverse_tensors(pool, net_in, onehot_cols=OH)
+            assert torch.equal(net_in[:, :H], pool[ix.long(), torch.arange(N, device="cuda")])
+            want = torch.zeros(N, OH, device="cuda", dtype=dtype)
+            want[torch.arange(N, device="cuda"), la.long()] = 1
+            assert torch.equal(net_in[:, H:], want)
+            roots.backprop_tensors(sim + 1, c["rewards"][sim], c["values"][sim], c["logits"][sim])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_backprop_nets_scalar_transform_and_exact_tree(dtype):
+    """hz_tree_backprop_nets: (i) the in-kernel scalar transform agrees with core/config.py:210-232 evaluated by
+    torch in fp32 to 1e-4 (a net output: north-star tolerance 1e-3); (ii) fed those scalars and the NaN-cleared
+    logits, the plain-C oracle ends in the identical tree."""
+    from hanabizero_amd import cytree as tree
+    from hanabizero_amd.model import inverse_scalar_transform
+    from oracle.cport import OracleTree
+    N, A, S, V, PAD = 192, 20, 30, 201, 256
+    c = _random_case(N, A, S, 44)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    roots, orc = tree.Roots(N, A, S, tie_seed=6), OracleTree(N, A, S, seed=6)
+    roots.prepare(0.25, c["noises"], np.zeros(N), c["logits0"], c["legal"])
+    orc.prepare(0.25, c["noises"], np.zeros(N, np.float32), c["logits0"], c["legal"])
+    roots.set_params(19652, 1.25, 0.999, 0.006)
+    for sim in range(S - 1):
+        ix, iy, la = roots.traverse_tensors()
+        oix, _, ola = orc.traverse(sim, 19652, 1.25, 0.999)
+        assert (ix.cpu().numpy() == oix).all() and (la.cpu().numpy() == ola).all(), sim
+        heads = (torch.randn(3, N, PAD, device="cuda", generator=g) * 3).to(dtype)  # rows wider than V / A: strided views
+        if sim == 3:
+            heads[1, :7, 2] = float("nan")      # NaN policy logits are cleared (core/mcts.py:48-49)
+            heads[0, 5, :] = float("nan")       # a NaN reward row becomes 0 (config.py:229-232)
+        out_r = torch.empty(N, device="cuda")
+        out_v = torch.empty(N, device="cuda")
+        roots.backprop_nets_tensors(sim + 1, heads[0], heads[2], V, -100, heads[1], out_r, out_v)
+        for got, src in ((out_r, heads[0]), (out_v, heads[2])):
+            want = inverse_scalar_transform(src[:, :V].float(), -100, 100).reshape(-1)
+            assert float((got - want).abs().max()) <= 1e-4 * max(1.0, float(want.abs().max()))
+        lg = torch.nan_to_num(heads[1][:, :A].float(), nan=0.0, posinf=float("inf"), neginf=float("-inf"))
+        orc.backprop(sim + 1, 0.999, out_r.cpu().numpy(), out_v.cpu().numpy(), lg.cpu().numpy())
+        (omn, omx), (hmn, hmx) = orc.minmax(), roots.minmax_tensors()
+        assert (omn == hmn.cpu().numpy()).all() and (omx == hmx.cpu().numpy()).all()
+    assert (roots.distributions_tensor().cpu().numpy() == orc.distributions()).all()
+    assert (bits(roots.values_tensor().cpu().numpy()) == bits(orc.values())).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_add_relu_glue_kernel(dtype):
+    from hanabizero_amd._lib import check, lib
+    torch.manual_seed(0)
+    y = torch.randn(300, 512, device="cuda").to(dtype)
+    big = torch.randn(300, 544, device="cuda").to(dtype)
+    res = big[:, :512]  # strided residual, like net_in[:, :H]
+    want = torch.relu(y + res)
+    dt = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[dtype]
+    check(lib.hz_add_relu(y.data_ptr(), y.stride(0), res.data_ptr(), res.stride(0), 300, 512, dt, torch.cuda.current_stream().cuda_stream), "x")
+    assert torch.equal(y, want)

@@ -59,6 +59,24 @@ def test_inference_engine_fp32_cpu_within_1e3(game):
     assert torch.equal(pool_slot, h1)
 
 
+@pytest.mark.parametrize("game", ["Hanabi-Small", "Hanabi-Full"])
+def test_fused_recurrent_heads_equals_unfused_cpu(game):
+    """[state | one-hot | 0] rows through the padded first layer + batched head tails == the layer-by-layer path."""
+    from hanabizero_amd.model import InferenceEngine, inverse_scalar_transform
+    net, fx, sup = build(game)
+    eng = InferenceEngine(net, sup, dtype=torch.float32, device="cpu")
+    hid, act = torch.from_numpy(fx["init_hidden"]), torch.from_numpy(fx["action"]).reshape(-1)
+    N = hid.shape[0]
+    net_in = torch.zeros(N, eng.H + eng.onehot_cols)
+    net_in[:, :eng.H] = hid
+    net_in[torch.arange(N), eng.H + act] = 1
+    out = torch.empty(N, eng.H)
+    r_log, v_log, p_log = eng.recurrent_heads(net_in, out)
+    assert _close(out, fx["rec_hidden"], 1e-4) and _close(p_log[:, :eng.A], fx["rec_logits"], 1e-4)
+    assert _close(inverse_scalar_transform(v_log[:, :eng.V], -sup, sup), fx["rec_value"], 1e-4)
+    assert _close(inverse_scalar_transform(r_log[:, :eng.V], -sup, sup), fx["rec_reward"], 1e-4)
+
+
 def test_zero_initialised_heads_like_the_reference():
     from hanabizero_amd.model import MuZeroNetFull
     net = MuZeroNetFull(785 * 4, 20, 201, 201, None, None)
@@ -81,6 +99,15 @@ def test_inference_engine_on_gpu(game):
         eng = InferenceEngine(net, sup, dtype=dtype, device="cuda")
         v0, l0, h0 = eng.initial(obs)
         v1, r1, l1, h1 = eng.recurrent(hid.to(dtype), act)
+        # the search loop's fused form: HIP residual/ReLU glue, batched head tails, HIP scalar transform
+        N = hid.shape[0]
+        net_in = torch.zeros(N, eng.H + eng.onehot_cols, dtype=dtype, device="cuda")
+        net_in[:, :eng.H] = hid.to(dtype)
+        net_in[torch.arange(N), eng.H + act] = 1
+        h2 = torch.empty(N, eng.H, dtype=dtype, device="cuda")
+        r_log, v_log, p_log = eng.recurrent_heads(net_in, h2)
+        v2, r2 = eng.support_to_scalar(v_log), eng.support_to_scalar(r_log)
         for got, want in [(v0, fx["init_value"]), (l0, fx["init_logits"]), (h0, fx["init_hidden"]), (v1, fx["rec_value"]),
-                          (r1, fx["rec_reward"]), (l1, fx["rec_logits"]), (h1, fx["rec_hidden"])]:
+                          (r1, fx["rec_reward"]), (l1, fx["rec_logits"]), (h1, fx["rec_hidden"]),
+                          (v2, fx["rec_value"]), (r2, fx["rec_reward"]), (p_log[:, :eng.A], fx["rec_logits"]), (h2, fx["rec_hidden"])]:
             assert _close(got.float().cpu().numpy(), want, tol), (dtype, float(np.max(np.abs(got.float().cpu().numpy().reshape(-1) - np.asarray(want).reshape(-1)))))

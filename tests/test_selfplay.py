@@ -66,9 +66,15 @@ def test_actor_matches_oracle_replay(game, N, sims, stack, steps):
         for sim in range(sims - 1):
             ix, iy, la = tree.traverse(sim, cfg.pb_c_base, cfg.pb_c_init, cfg.discount)
             hid = torch.stack([pool[x][y] for x, y in zip(ix, iy)])
-            v, r, lg, h = eng.recurrent(hid, torch.from_numpy(la).cuda())
+            net_in = torch.zeros(N, eng.H + eng.onehot_cols, dtype=eng.dtype, device="cuda")
+            net_in[:, :eng.H] = hid
+            net_in[torch.arange(N), eng.H + torch.from_numpy(la).long()] = 1
+            h = torch.empty(N, eng.H, dtype=eng.dtype, device="cuda")
+            r_log, v_log, p_log = eng.recurrent_heads(net_in, h)  # the same GEMM sequence the actor's search runs
             pool.append(h)
-            tree.backprop(sim + 1, cfg.discount, r.cpu().numpy(), v.cpu().numpy(), torch.nan_to_num(lg).cpu().numpy())
+            r, v = eng.support_to_scalar(r_log), eng.support_to_scalar(v_log)
+            lg = torch.nan_to_num(p_log[:, :A].float(), nan=0.0, posinf=float("inf"), neginf=float("-inf"))
+            tree.backprop(sim + 1, cfg.discount, r.cpu().numpy(), v.cpu().numpy(), lg.cpu().numpy())
         dist, vals = tree.distributions(), tree.values()
         acts = np.zeros(N, np.int32)
         for i in range(N):
