@@ -46,40 +46,73 @@ def build_engine(cfg, dtype, device):
     return InferenceEngine(net, cfg.value_support.max, dtype=dtype, device=device)
 
 
-def instrumented_search(actor, moves=2):
-    """Eager (non-graph) lock-steps with a HIP event pair around every tree-kernel launch, on the launch stream.
-    Returns per-kernel average duration (s), launches, and the measured mean path length."""
+def kernel_timing(actor, sample_sims=(4, 16, 28, 40), clones=8, replays=5):
+    """Average launch duration of the two hand-written tree kernels on LIVE search states, with HIP events.
+
+    An eager search of the actor's current position is run; at each sampled simulation the tree state is snapshotted
+    into `clones` independent handles (hz_tree_copy) and a hipGraph of `clones` back-to-back launches -- one per
+    snapshot, so no launch sees data the previous one left in cache -- is replayed between two HIP events on the
+    launch stream (torch's current stream).  An eager launch cannot be timed this way: on this stack an empty event
+    pair already reads ~26 us.  The figure includes the ~1-2 us dependent-launch boundary between graph nodes, which
+    rocprofv3's per-dispatch durations (profiles/) exclude.
+    Returns {kernel: (avg seconds per launch, launches)}, mean path edges, mean expanded entries."""
     import torch
     cfg, roots, eng = actor.cfg, actor.roots, actor.engine
-    N, S = actor.N, actor.S
+    N, S, oh = actor.N, actor.S, eng.onehot_cols
+    actor._draw()
+    value0, logits0, hidden0 = eng.initial(actor.stack_buf.view(N, actor.stack * actor.D))
+    roots.prepare(cfg.root_exploration_fraction, actor.noise, actor.zeros_n, logits0, actor.legal)
+    actor.pool[0].copy_(hidden0)
+    net_in = torch.empty((N, eng.H + oh), dtype=eng.dtype, device=actor.device)
+    tot = {"k_traverse": 0.0, "k_backprop": 0.0}
+    launches, depth, entries = 0, 0.0, 0.0
     ev = lambda: torch.cuda.Event(enable_timing=True)
-    t_trav, t_back, depth_sum, n_launch = 0.0, 0.0, 0.0, 0
-    for _ in range(moves):
-        actor._draw()
-        value0, logits0, hidden0 = eng.initial(actor.stack_buf.view(N, actor.stack * actor.D))
-        roots.prepare(cfg.root_exploration_fraction, actor.noise, actor.zeros_n, logits0, actor.legal)
-        actor.pool[0].copy_(hidden0)
-        net_in = torch.empty((N, eng.H), dtype=eng.dtype, device=actor.device)
-        pairs = []
-        for sim in range(S - 1):
-            a, b, c, d = ev(), ev(), ev(), ev()
-            a.record()
-            _, _, la = roots.traverse_tensors(actor.pool, net_in)
-            b.record()
-            value, reward, logits, _ = eng.recurrent(net_in, la, hidden_out=actor.pool[sim + 1])
-            logits = torch.nan_to_num_(logits, nan=0.0)
-            c.record()
-            roots.backprop_tensors(sim + 1, reward, value, logits)
-            d.record()
-            pairs.append((a, b, c, d))
-            depth_sum += float(roots.path_len_tensor().float().mean()) - 1.0  # edges root->leaf
-        torch.cuda.synchronize()
-        for a, b, c, d in pairs:
-            t_trav += a.elapsed_time(b) * 1e-3
-            t_back += c.elapsed_time(d) * 1e-3
-            n_launch += 1
-        actor._step_body()  # advance the real state so the next instrumented move sees fresh positions
-    return t_trav / n_launch, t_back / n_launch, n_launch, depth_sum / n_launch
+
+    def timed_graph(body):
+        side = torch.cuda.Stream(device=actor.device)
+        side.wait_stream(torch.cuda.current_stream())
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            body()
+        return g
+
+    for sim in range(S - 1):
+        sampled = sim in sample_sims
+        if sampled:
+            snaps = [roots.clone() for _ in range(clones)]
+            ins = [torch.empty_like(net_in) for _ in range(clones)]
+            torch.cuda.synchronize()
+            g = timed_graph(lambda: [c.traverse_tensors(actor.pool, b, onehot_cols=oh) for c, b in zip(snaps, ins)])
+        roots.traverse_tensors(actor.pool, net_in, onehot_cols=oh)
+        if sampled:
+            best = 1e9
+            for _ in range(replays):
+                a, b = ev(), ev()
+                a.record(); g.replay(); b.record()
+                torch.cuda.synchronize()
+                best = min(best, a.elapsed_time(b) * 1e-3 / clones)
+            tot["k_traverse"] += best
+            depth += float(roots.path_len_tensor().float().mean()) - 1.0
+            entries += sim + 1
+        r_log, v_log, p_log = eng.recurrent_heads(net_in, actor.pool[sim + 1])
+        if sampled:
+            # each snapshot must expand entry sim+1 exactly once per replay: re-snapshot before every replay
+            best = 1e9
+            for _ in range(replays):
+                snaps2 = [c.clone() for c in snaps]
+                torch.cuda.synchronize()
+                g2 = timed_graph(lambda: [c.backprop_nets_tensors(sim + 1, r_log, v_log, eng.V, -eng.support, p_log) for c in snaps2])
+                a, b = ev(), ev()
+                a.record(); g2.replay(); b.record()
+                torch.cuda.synchronize()
+                best = min(best, a.elapsed_time(b) * 1e-3 / clones)
+                del g2, snaps2
+            tot["k_backprop"] += best
+            launches += 1
+            del g, snaps, ins
+        roots.backprop_nets_tensors(sim + 1, r_log, v_log, eng.V, -eng.support, p_log)
+    torch.cuda.synchronize()
+    return {k: v / launches for k, v in tot.items()}, launches * clones * replays, depth / launches, entries / launches
 
 
 def cpu_baseline(game, A, S, sample_trees, moves):
@@ -129,8 +162,8 @@ def main():
     ap.add_argument("--flush-every", type=int, default=10, help="drain + gather finished games every this many steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-sample-trees", type=int, default=1024)
-    ap.add_argument("--cpu-sample-moves", type=int, default=4)
+    ap.add_argument("--cpu-sample-trees", type=int, default=4096)
+    ap.add_argument("--cpu-sample-moves", type=int, default=24)
     args = ap.parse_args()
 
     import numpy as np
@@ -210,13 +243,15 @@ def main():
     }
 
     if rank == 0 and not args.no_roofline:
-        t_trav, t_back, launches, dbar = instrumented_search(actor, moves=2)
+        times, launches, dbar, sbar = kernel_timing(actor)
         A, H, e = cfg.action_space_size, engine.H, (4 if dtype == torch.float32 else 2)
-        sbar = (S - 1) / 2.0
-        b_trav = N * (16 * A * dbar + 2 * H * e)                                  # child rows per level + hidden row in/out
-        b_back = N * (4 * A + 16 * A + 16 + 16 * (dbar + 1) + 12 * sbar)          # logits in, child rows out, backup, min-max
-        dom = "k_traverse" if t_trav >= t_back else "k_backprop"
-        byt, dur = (b_trav, t_trav) if dom == "k_traverse" else (b_back, t_back)
+        V = engine.V
+        # algorithmic bytes per launch (SURVEY.md 8d per-tree figures x N trees per launch)
+        b_trav = N * (16 * A * dbar + 2 * H * e)                          # child rows per level + hidden row in and out
+        b_back = N * (4 * A + 16 * A + 16 + 16 * (dbar + 1) + 12 * sbar)  # logits in, child rows out, header, backup, min-max
+        kern = {"k_traverse": (b_trav, times["k_traverse"]), "k_backprop": (b_back, times["k_backprop"])}
+        dom = max(kern, key=lambda k: kern[k][1])
+        byt, dur = kern[dom]
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
@@ -227,9 +262,10 @@ def main():
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": byt / dur / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": byt / dur / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                            "bytes_per_launch": byt, "avg_launch_us": dur * 1e6, "launches_timed": launches,
-                           "mean_path_edges": dbar,
-                           "other": {"k_traverse": {"avg_launch_us": t_trav * 1e6, "GBps": b_trav / t_trav / 1e9},
-                                     "k_backprop": {"avg_launch_us": t_back * 1e6, "GBps": b_back / t_back / 1e9}}}
+                           "mean_path_edges": dbar, "mean_expanded_entries": sbar,
+                           "method": "HIP events around hipGraph replays of 8 launches on independent snapshots of live search states",
+                           "other": {k: {"avg_launch_us": t * 1e6, "bytes_per_launch": b, "GBps": b / t / 1e9}
+                                     for k, (b, t) in kern.items()}}
         flops = engine.flops_per_sample() * N
         out["nets"] = {"recurrent_flop_per_launch": flops, "note": "GEMMs via hipBLASLt/rocBLAS (MFMA); see profiles/"}
 

@@ -33,6 +33,7 @@ def _load():
         "hz_tree_backprop_nets": [V, I, V, I64, V, I64, I, I, V, I64, I, V, V, V],
         "hz_tree_backprop": [V, I, V, V, V, V],
         "hz_support_to_scalar": [V, I64, I, I, I, V, I, V],
+        "hz_tree_copy": [V, V, V],
         "hz_tree_get_distributions": [V, V, V],
         "hz_tree_get_values": [V, V, V],
         "hz_tree_get_trajectories": [V, V, I, V],

@@ -693,6 +693,23 @@ extern "C" int hz_tree_get_root_priors(hz_tree_t* t, float* out, void* stream) {
 
 extern "C" int64_t hz_tree_hbm_bytes(const hz_tree_t* t) { return t ? t->bytes : 0; }
 
+extern "C" int hz_tree_copy(hz_tree_t* dst, const hz_tree_t* src, void* stream) {
+  HZ_REQUIRE(dst && src, "hz_tree_copy: NULL handle");
+  HZ_REQUIRE(dst->N == src->N && dst->A == src->A && dst->S == src->S && dst->device == src->device,
+             "hz_tree_copy: handles must have the same shape and device");
+  const size_t N = src->N, A = src->A, S = src->S;
+  hipStream_t st = (hipStream_t)stream;
+#define HZ_CP(f, n) HZ_HIP(hipMemcpyAsync(dst->f, src->f, (n) * sizeof(*src->f), hipMemcpyDeviceToDevice, st))
+  HZ_CP(rec, N * S * A); HZ_CP(qsa, N * S); HZ_CP(ref, N * S); HZ_CP(path, N * (S + 1)); HZ_CP(path_len, N);
+  HZ_CP(root_visit, N); HZ_CP(root_vsum, N); HZ_CP(mm_min, N); HZ_CP(mm_max, N); HZ_CP(best_action, N * S);
+  HZ_CP(pbc_tab, S + 1);
+#undef HZ_CP
+  dst->pb_c_base = src->pb_c_base; dst->pb_c_init = src->pb_c_init; dst->discount = src->discount;
+  dst->delta = src->delta; dst->seed = src->seed; dst->id_base = src->id_base; dst->params_set = src->params_set;
+  dst->next_entry = src->next_entry;
+  return 0;
+}
+
 // the scalar transform of hz_tree_backprop_nets on its own (same device function, hence bit-identical to it)
 __global__ __launch_bounds__(256) void k_support_to_scalar(const uint8_t* __restrict__ logits, long long stride_bytes,
                                                            int V, int support_min, int dtype, float* __restrict__ out,

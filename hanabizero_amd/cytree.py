@@ -123,6 +123,14 @@ class Roots:
     def hbm_bytes(self):
         return int(lib.hz_tree_hbm_bytes(self._h))
 
+    def clone(self):
+        """A second Roots holding a device-side copy of this one's complete search state (hz_tree_copy)."""
+        other = Roots(self.root_num, self.action_num, self.tree_nodes, device=self.device, tie_seed=self.tie_seed,
+                      tree_id_base=self.tree_id_base)
+        check(lib.hz_tree_copy(other._h, self._h, _stream()), "hz_tree_copy")
+        other._params, other._sim = self._params, self._sim
+        return other
+
     # -- parameters the reference passes per call --------------------------------------------------
     def set_params(self, pb_c_base, pb_c_init, discount, value_delta_max):
         p = (int(pb_c_base), float(pb_c_init), float(discount), float(value_delta_max), self.tie_seed,

@@ -111,10 +111,13 @@ int hz_tree_get_minmax(hz_tree_t* t, float* out_min /* [N] */, float* out_max /*
 int hz_tree_get_root_priors(hz_tree_t* t, float* out /* [N][A] */, void* stream);
 int hz_tree_get_path_len(hz_tree_t* t, int32_t* out /* [N] nodes on the last path incl. root and leaf */, void* stream);
 
-/* Bytes of HBM held by the handle, and algorithmic bytes moved by the last traverse+backprop pair
- * (SURVEY.md section 8d formula, summed over trees from the recorded path lengths; host-side helper for bench.py:
- * synchronises the stream it is given). */
+/* Bytes of HBM held by the handle. */
 int64_t hz_tree_hbm_bytes(const hz_tree_t* t);
+
+/* Device-to-device snapshot of a handle's whole search state and parameters into another handle of the same
+ * shape (the reference can copy-construct a CRoots; used by bench.py to time one kernel on independent copies of
+ * a live mid-search state). */
+int hz_tree_copy(hz_tree_t* dst, const hz_tree_t* src, void* stream);
 
 #ifdef __cplusplus
 }
