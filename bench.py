@@ -29,11 +29,14 @@ WORKLOADS = {
     "full4096": ("Hanabi-Full", 4096, 50, 4),     # BASELINE.json metric: Hanabi-Full 2p, 50 sims, 4096 envs
     "small4096": ("Hanabi-Small", 4096, 50, 4),   # BASELINE.json configs[1]
     "full8192": ("Hanabi-Full", 8192, 50, 4),     # BASELINE.json configs[2] (and [3] at --gpus 8)
+    "full16384": ("Hanabi-Full", 16384, 50, 4),   # scaling probes beyond the named configs (288 GB HBM has room)
+    "full32768": ("Hanabi-Full", 32768, 50, 4),
 }
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # same guide: ~2.5 PFLOP/s dense bf16
 
 
-def build_engine(cfg, dtype, device):
+def build_engine(cfg, dtype, device, fused=None):
     import torch
     from hanabizero_amd.model import InferenceEngine
     torch.manual_seed(0)
@@ -43,7 +46,7 @@ def build_engine(cfg, dtype, device):
             head[-1].weight.normal_(0, 0.1)
             head[-1].bias.normal_(0, 0.1)
     net.eval()
-    return InferenceEngine(net, cfg.value_support.max, dtype=dtype, device=device)
+    return InferenceEngine(net, cfg.value_support.max, dtype=dtype, device=device, fused=fused)
 
 
 def kernel_timing(actor, sample_sims=(4, 16, 28, 40), clones=8, replays=5):
@@ -64,7 +67,11 @@ def kernel_timing(actor, sample_sims=(4, 16, 28, 40), clones=8, replays=5):
     roots.prepare(cfg.root_exploration_fraction, actor.noise, actor.zeros_n, logits0, actor.legal)
     actor.pool[0].copy_(hidden0)
     net_in = torch.empty((N, eng.H + oh), dtype=eng.dtype, device=actor.device)
-    tot = {"k_traverse": 0.0, "k_backprop": 0.0}
+    fused = getattr(eng, "fused", None)
+    tot = {"k_traverse": 0.0, "k_backprop": 0.0, "k_mlp_recurrent": 0.0}
+    rew = torch.empty(N, dtype=torch.float32, device=actor.device)
+    val = torch.empty(N, dtype=torch.float32, device=actor.device)
+    pol = torch.empty((N, actor.A), dtype=torch.float32, device=actor.device)
     launches, depth, entries = 0, 0.0, 0.0
     ev = lambda: torch.cuda.Event(enable_timing=True)
 
@@ -94,14 +101,32 @@ def kernel_timing(actor, sample_sims=(4, 16, 28, 40), clones=8, replays=5):
             tot["k_traverse"] += best
             depth += float(roots.path_len_tensor().float().mean()) - 1.0
             entries += sim + 1
-        r_log, v_log, p_log = eng.recurrent_heads(net_in, actor.pool[sim + 1])
+        if fused is not None:
+            fused(net_in, actor.pool[sim + 1], rew, val, pol)
+            back = lambda c: c.backprop_tensors(sim + 1, rew, val, pol)
+        else:
+            r_log, v_log, p_log = eng.recurrent_heads(net_in, actor.pool[sim + 1])
+            back = lambda c: c.backprop_nets_tensors(sim + 1, r_log, v_log, eng.V, -eng.support, p_log)
+        if sampled and fused is not None:
+            # the MFMA kernel: 8 launches on 8 different input / output buffers
+            outs = [torch.empty_like(actor.pool[0]) for _ in range(clones)]
+            torch.cuda.synchronize()
+            g3 = timed_graph(lambda: [fused(b, o, rew, val, pol) for b, o in zip(ins, outs)])
+            best = 1e9
+            for _ in range(replays):
+                a, b = ev(), ev()
+                a.record(); g3.replay(); b.record()
+                torch.cuda.synchronize()
+                best = min(best, a.elapsed_time(b) * 1e-3 / clones)
+            tot["k_mlp_recurrent"] += best
+            del g3, outs
         if sampled:
             # each snapshot must expand entry sim+1 exactly once per replay: re-snapshot before every replay
             best = 1e9
             for _ in range(replays):
                 snaps2 = [c.clone() for c in snaps]
                 torch.cuda.synchronize()
-                g2 = timed_graph(lambda: [c.backprop_nets_tensors(sim + 1, r_log, v_log, eng.V, -eng.support, p_log) for c in snaps2])
+                g2 = timed_graph(lambda: [back(c) for c in snaps2])
                 a, b = ev(), ev()
                 a.record(); g2.replay(); b.record()
                 torch.cuda.synchronize()
@@ -110,7 +135,7 @@ def kernel_timing(actor, sample_sims=(4, 16, 28, 40), clones=8, replays=5):
             tot["k_backprop"] += best
             launches += 1
             del g, snaps, ins
-        roots.backprop_nets_tensors(sim + 1, r_log, v_log, eng.V, -eng.support, p_log)
+        back(roots)
     torch.cuda.synchronize()
     return {k: v / launches for k, v in tot.items()}, launches * clones * replays, depth / launches, entries / launches
 
@@ -158,8 +183,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="full4096", choices=sorted(WORKLOADS))
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--no-fused-mlp", action="store_true", help="hipBLASLt GEMM chain instead of the fused MFMA kernel")
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
     ap.add_argument("--flush-every", type=int, default=10, help="drain + gather finished games every this many steps")
+    ap.add_argument("--actors-per-gpu", type=int, default=1,
+                    help="split this GPU's envs over this many concurrent actors (own hipGraph + stream each)")
+    ap.add_argument("--branch-graph", action="store_true", help="with --actors-per-gpu > 1: one hipGraph with a branch per actor")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-sample-trees", type=int, default=4096)
@@ -187,8 +216,26 @@ def main():
     game, N, S, stack = WORKLOADS[args.workload]
     cfg = make_config(game, simulations=S, stack=stack, p_mcts_num=N)
     dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype]
-    engine = build_engine(cfg, dtype, device)
-    actor = SelfPlayActor(cfg, engine, N, rank=rank, seed=0, device=device, use_graph=not args.no_graph)
+    engine = build_engine(cfg, dtype, device, fused=False if args.no_fused_mlp else None)
+    K = args.actors_per_gpu
+    assert N % K == 0
+    actors = [SelfPlayActor(cfg, engine, N // K, seed=0, device=device, use_graph=not args.no_graph,
+                            env_id_base=rank * N + k * (N // K),
+                            stream=torch.cuda.Stream(device=device) if K > 1 else None) for k in range(K)]
+    actor = actors[0]
+    group = None
+    if args.branch_graph and K > 1:
+        from hanabizero_amd.selfplay import ActorGroup
+        for a in actors:
+            a.stream = None
+        group = ActorGroup(actors)
+
+    def step_all():
+        if group is not None:
+            group.step()
+        else:
+            for a in actors:
+                a.step()
 
     def barrier():
         if world > 1:
@@ -196,23 +243,29 @@ def main():
 
     games, rec_bytes = 0, 0
 
+    flush_s = 0.0
+
     def flush():
-        nonlocal games, rec_bytes
-        rec = actor.drain()
-        got = gather_records(rec, dst=0)
-        if rank == 0 and got is not None:
-            games += int(got["meta"].shape[0])
-            rec_bytes += record_nbytes(got)
+        nonlocal games, rec_bytes, flush_s
+        tf = time.perf_counter()
+        torch.cuda.synchronize()
+        tf0 = time.perf_counter()
+        for a in actors:
+            got = gather_records(a.drain(), dst=0)
+            if rank == 0 and got is not None:
+                games += int(got["meta"].shape[0])
+                rec_bytes += record_nbytes(got)
+        flush_s += time.perf_counter() - tf0
 
     for _ in range(args.warmup):  # includes graph capture (2 eager steps + capture) on the first call
-        actor.step()
+        step_all()
     flush()
     torch.cuda.synchronize()
     barrier()
-    games, rec_bytes = 0, 0
+    games, rec_bytes, flush_s = 0, 0, 0.0
     t0 = time.perf_counter()
     for k in range(args.steps):
-        actor.step()
+        step_all()
         if (k + 1) % args.flush_every == 0:
             flush()
     flush()
@@ -223,7 +276,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    assert int(actor.illegal_steps) == 0, "the actor produced an illegal move"
+    assert all(int(a.illegal_steps) == 0 for a in actors), "an actor produced an illegal move"
 
     moves = world * N * args.steps
     out = {
@@ -238,8 +291,9 @@ def main():
         "data": "synthetic",
         "config": {"workload": "%s 2p, %d envs/GPU, %d sims/move (%d run, as the reference), stack %d, random-init "
                                "nets (heads N(0,0.1)), global obs" % (game, N, S, S - 1, stack),
-                   "envs_per_gpu": N, "simulations": S, "hipgraph": not args.no_graph, "parallelism": "actor-per-GPU x%d" % world,
-                   "games_finished": games, "record_bytes_gathered": rec_bytes},
+                   "envs_per_gpu": N, "actors_per_gpu": K, "simulations": S, "hipgraph": not args.no_graph, "parallelism": "actor-per-GPU x%d" % world,
+                   "games_finished": games, "record_bytes_gathered": rec_bytes,
+                   "drain_gather_ms_total": 1e3 * flush_s},
     }
 
     if rank == 0 and not args.no_roofline:
@@ -247,27 +301,41 @@ def main():
         A, H, e = cfg.action_space_size, engine.H, (4 if dtype == torch.float32 else 2)
         V = engine.V
         # algorithmic bytes per launch (SURVEY.md 8d per-tree figures x N trees per launch)
-        b_trav = N * (16 * A * dbar + 2 * H * e)                          # child rows per level + hidden row in and out
-        b_back = N * (4 * A + 16 * A + 16 + 16 * (dbar + 1) + 12 * sbar)  # logits in, child rows out, header, backup, min-max
+        Nk = actor.N  # trees per launch (per actor)
+        b_trav = Nk * (16 * A * dbar + 2 * H * e)                          # child rows per level + hidden row in and out
+        # fused backup: policy logits + the two categorical head rows in (net dtype), child rows out, header, backup, min-max
+        b_back = Nk * (A * e + 2 * V * e + 16 * A + 16 + 16 * (dbar + 1) + 12 * sbar)
+        fused_on = engine.fused is not None
+        if fused_on:  # plain backup: fp32 reward/value/policy in (SURVEY 8d formula)
+            b_back = Nk * (4 * A + 16 * A + 16 + 8 + 16 * (dbar + 1) + 12 * sbar)
         kern = {"k_traverse": (b_trav, times["k_traverse"]), "k_backprop": (b_back, times["k_backprop"])}
-        dom = max(kern, key=lambda k: kern[k][1])
-        byt, dur = kern[dom]
-        traffic = None
+        other = {k: {"bound": "hbm", "avg_launch_us": t * 1e6, "bytes_per_launch": b, "GBps": b / t / 1e9, "frac": b / t / 1e9 / HBM_PEAK_GBS}
+                 for k, (b, t) in kern.items()}
+        flops = engine.flops_per_sample() * Nk
+        if fused_on:
+            t = times["k_mlp_recurrent"]
+            other["k_mlp_recurrent"] = {"bound": "mfma", "avg_launch_us": t * 1e6, "flop_per_launch": flops,
+                                        "TFLOPps": flops / t / 1e12, "frac": flops / t / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                                        "weight_bytes_per_wg": int(engine.fused.weights.numel() * 2)}
+        traffic_all = {}
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(args.workload, {}).get(dom)
+                traffic_all = json.load(open(pmc)).get(args.workload, {})
             except Exception:
-                traffic = None
-        out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": byt / dur / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": byt / dur / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-                           "bytes_per_launch": byt, "avg_launch_us": dur * 1e6, "launches_timed": launches,
-                           "mean_path_edges": dbar, "mean_expanded_entries": sbar,
-                           "method": "HIP events around hipGraph replays of 8 launches on independent snapshots of live search states",
-                           "other": {k: {"avg_launch_us": t * 1e6, "bytes_per_launch": b, "GBps": b / t / 1e9}
-                                     for k, (b, t) in kern.items()}}
-        flops = engine.flops_per_sample() * N
-        out["nets"] = {"recurrent_flop_per_launch": flops, "note": "GEMMs via hipBLASLt/rocBLAS (MFMA); see profiles/"}
+                traffic_all = {}
+        dom = max(other, key=lambda k: other[k]["avg_launch_us"])
+        d = other[dom]
+        if d["bound"] == "hbm":
+            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": d["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": d["frac"], "traffic": traffic_all.get(dom)}
+        else:
+            out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": d["TFLOPps"], "peak": MFMA_BF16_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": d["frac"], "traffic": traffic_all.get(dom)}
+        out["roofline"].update({"avg_launch_us": d["avg_launch_us"], "launches_timed": launches,
+                                "mean_path_edges": dbar, "mean_expanded_entries": sbar,
+                                "method": "HIP events around hipGraph replays of 8 launches on independent snapshots of live search states",
+                                "other": other})
 
     if rank == 0 and not args.no_cpu_baseline:
         v, dt = cpu_baseline(game, cfg.action_space_size, S, args.cpu_sample_trees, args.cpu_sample_moves)

@@ -304,14 +304,31 @@ __device__ __forceinline__ float hz_wave_sum(float v) {
 // logits over the integer support [support_min, support_min + V), by one wave.  Tolerance-level arithmetic (this is
 // a network output, north-star tolerance 1e-3); the tree arithmetic that consumes the scalar stays exact.
 __device__ __forceinline__ float support_to_scalar(const void* row, int V, int support_min, int dtype, int lane) {
-  float m = -INFINITY;
-  for (int i = lane; i < V; i += 64) m = fmaxf(m, load_as_f32(row, i, dtype));
-  m = hz_wave_max(m);
-  float se = 0.0f, sw = 0.0f;
-  for (int i = lane; i < V; i += 64) {
-    const float e = __expf(load_as_f32(row, i, dtype) - m);
-    se += e;
-    sw += e * (float)(support_min + i);
+  float m = -INFINITY, se = 0.0f, sw = 0.0f;
+  if (V <= 256) {  // the Hanabi supports (51 / 201 bins): every logit is read once and kept in registers
+    float x[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = lane + 64 * k;
+      x[k] = (i < V) ? load_as_f32(row, i, dtype) : -INFINITY;
+      m = fmaxf(m, x[k]);
+    }
+    m = hz_wave_max(m);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = lane + 64 * k;
+      const float e = (i < V) ? __expf(x[k] - m) : 0.0f;
+      se += e;
+      sw += e * (float)(support_min + i);
+    }
+  } else {
+    for (int i = lane; i < V; i += 64) m = fmaxf(m, load_as_f32(row, i, dtype));
+    m = hz_wave_max(m);
+    for (int i = lane; i < V; i += 64) {
+      const float e = __expf(load_as_f32(row, i, dtype) - m);
+      se += e;
+      sw += e * (float)(support_min + i);
+    }
   }
   se = hz_wave_sum(se);
   sw = hz_wave_sum(sw);

@@ -36,6 +36,17 @@ class MCTS(object):
             pool[0].copy_(h0)
             oh = model.onehot_cols
             net_in = torch.empty((num, H + oh), dtype=model.dtype, device=roots.device)
+            fused = getattr(model, "fused", None)
+            if fused is not None:
+                # traverse+gather (HIP) -> whole recurrent inference as one MFMA kernel (HIP) -> expand/backup (HIP)
+                rew = torch.empty(num, dtype=torch.float32, device=roots.device)
+                val = torch.empty(num, dtype=torch.float32, device=roots.device)
+                pol = torch.empty((num, roots.action_num), dtype=torch.float32, device=roots.device)
+                for index_simulation in range(S - 1):
+                    roots.traverse_tensors(pool, net_in, onehot_cols=oh)
+                    fused(net_in, pool[index_simulation + 1], rew, val, pol)
+                    roots.backprop_tensors(index_simulation + 1, rew, val, pol)
+                return
             for index_simulation in range(S - 1):
                 # select + gather + one-hot (1 kernel) -> dynamics/prediction GEMMs -> scalar transform + NaN
                 # clearing + expand + backup + min-max (1 kernel)

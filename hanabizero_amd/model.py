@@ -216,11 +216,15 @@ class InferenceEngine:
     `hidden_out=` lets the caller point the new hidden state at its slot of the search's hidden-state pool.
     """
 
-    def __init__(self, net, support, dtype=torch.bfloat16, device="cuda"):
+    def __init__(self, net, support, dtype=torch.bfloat16, device="cuda", fused=None):
+        """fused: run the search loop's recurrent inference as the single hand-written MFMA kernel of
+        include/hz_mlp.h (default: whenever the engine is bf16 on a GPU); False keeps the hipBLASLt GEMM chain."""
         self.dtype, self.device = dtype, torch.device(device)
         self.A, self.H = net.action_space_n, net.feature_size
         self.support = int(support)
         self.full = isinstance(net, MuZeroNetFull)
+        self.use_fused = (dtype == torch.bfloat16 and self.device.type == "cuda") if fused is None else bool(fused)
+        self.fused = None
         self.load(net)
 
     def load(self, net):
@@ -248,32 +252,42 @@ class InferenceEngine:
         self.h = ws[0].shape[0]
         self.heads1 = _Lin(torch.cat(ws, 0), torch.cat(bs, 0), self.dtype, self.device)
         self.pred1 = _Lin(torch.cat(ws[1:], 0), torch.cat(bs[1:], 0), self.dtype, self.device)
+        # search-loop form: each head block is h real columns + 32 pad columns whose first one is a constant 1
+        # (zero weights, bias 1, ReLU(1) = 1): it carries the next layers' biases through plain batched GEMMs
+        self.hp = self.h + 32
+        wpad, bpad = [], []
+        for w, b in zip(ws, bs):
+            wpad.append(torch.cat((w, torch.zeros(32, w.shape[1])), 0))
+            one = torch.zeros(32)
+            one[0] = 1.0
+            bpad.append(torch.cat((b, one), 0))
+        self.heads1p = _Lin(torch.cat(wpad, 0), torch.cat(bpad, 0), self.dtype, self.device)
         if self.full:
             self.rw_tail = [L(rw[3], rw[4]), L(rw[6])]
             self.ac_tail = [L(ac[3].fc1, ac[3].bn1), L(ac[3].fc2, ac[3].bn2), L(ac[4])]
             self.va_tail = [L(va[3], va[4]), L(va[6])]
             # batched tails (reward | actor | value): layer 2 = three [h -> h] GEMMs, layer 3 = three [h -> h]
             # GEMMs with the 2*support+1 wide outputs zero-padded to h
-            self.bw2, self.bb2 = self._stack([_fold(rw[3], rw[4]), _fold(ac[3].fc1, ac[3].bn1), _fold(va[3], va[4])], self.h)
-            self.bw3, self.bb3 = self._stack([_fold(rw[6]), _fold(ac[3].fc2, ac[3].bn2), _fold(va[6])], self.h)
+            self.bw2 = self._stack([_fold(rw[3], rw[4]), _fold(ac[3].fc1, ac[3].bn1), _fold(va[3], va[4])], self.hp, True)
+            self.bw3 = self._stack([_fold(rw[6]), _fold(ac[3].fc2, ac[3].bn2), _fold(va[6])], self.h, False)
         else:
             self.rw_tail, self.ac_tail, self.va_tail = [L(rw[3])], [L(ac[3])], [L(va[3])]
             self.out_pad = ((max(2 * self.support + 1, self.A) + 31) // 32) * 32
-            self.bw3, self.bb3 = self._stack([_fold(rw[3]), _fold(ac[3]), _fold(va[3])], self.out_pad)
+            self.bw3 = self._stack([_fold(rw[3]), _fold(ac[3]), _fold(va[3])], self.out_pad, False)
         self.V = 2 * self.support + 1
+        self.fused = FusedRecurrent(net, self) if self.use_fused else None
 
-    def _stack(self, folded, out_pad):
-        """[(W [o,i], b [o])] * 3 -> Wt [3, i, out_pad], b [3, 1, out_pad] (zero padded) in the engine dtype."""
-        ws, bs = [], []
-        for w, b in folded:
-            wp = torch.zeros(out_pad, w.shape[1])
-            wp[:w.shape[0]] = w
-            bp = torch.zeros(out_pad)
-            bp[:b.shape[0]] = b
-            ws.append(wp.t().contiguous())
-            bs.append(bp[None, :])
-        return (torch.stack(ws).to(device=self.device, dtype=self.dtype),
-                torch.stack(bs).to(device=self.device, dtype=self.dtype))
+    def _stack(self, folded, out_width, carry_one):
+        """[(W [o, h], b [o])] * 3 -> Wt [3, hp, out_width] in the engine dtype for torch.bmm over the three head
+        blocks: rows 0..h-1 = W^T, row h = b (multiplied by the constant-one input column), other rows 0; with
+        carry_one the output keeps a constant-one column at index h for the next layer's bias."""
+        out = torch.zeros(3, self.hp, out_width)
+        for k, (w, b) in enumerate(folded):
+            out[k, :w.shape[1], :w.shape[0]] = w.t()
+            out[k, self.h, :b.shape[0]] = b
+            if carry_one:
+                out[k, self.h, self.h] = 1.0
+        return out.to(device=self.device, dtype=self.dtype)
 
     # -- pieces ---------------------------------------------------------------------------------------
     def _scalar(self, logits):
@@ -357,24 +371,135 @@ class InferenceEngine:
         | 0] as written by hz_tree_traverse_gather; the next hidden state goes to `hidden_out` [N, H] (its slot of the
         pool).  Returns RAW head outputs (reward_logits, value_logits, policy_logits) as strided views in the engine
         dtype, rows of width >= V / V / A -- hz_tree_backprop_nets turns them into scalars and sanitises NaNs."""
-        N, H, h = net_in.shape[0], self.H, self.h
+        N, H, h, hp = net_in.shape[0], self.H, self.h, self.hp
         state_in = net_in[:, :H]
         if self.full:  # NewDynamicNet
             y = self.dyn2(self.dyn1p(net_in, relu=True), relu=True)
             s = self._add_relu(self.dyn3(y, out=hidden_out), state_in)
-            z = self.heads1(s, relu=True)
-            t2 = torch.relu_(torch.baddbmm(self.bb2, z.view(N, 3, h).transpose(0, 1), self.bw2))
-            t3 = torch.baddbmm(self.bb3, t2, self.bw3)
-            ya = self._add_relu(t3[1], z[:, h:2 * h])  # NewResMLP skip of the actor head
+            z = self.heads1p(s, relu=True)  # [N, 3*hp]: (reward | actor | value) blocks, each [h real | 1 | 0...]
+            t2 = torch.relu_(torch.bmm(z.view(N, 3, hp).transpose(0, 1), self.bw2))
+            t3 = torch.bmm(t2, self.bw3)
+            ya = self._add_relu(t3[1], z[:, hp:hp + h])  # NewResMLP skip of the actor head
             return t3[0], t3[2], self.ac_tail[2](ya)
         y = self._add_relu(self.dyn1p(net_in), state_in)  # DynamicNet: skip after the first layer
         y = self.dyn2(y, relu=True)
         s = torch.relu_(self.dyn3(y, out=hidden_out))
-        z = self.heads1(s, relu=True)
-        t3 = torch.baddbmm(self.bb3, z.view(N, 3, h).transpose(0, 1), self.bw3)
+        z = self.heads1p(s, relu=True)
+        t3 = torch.bmm(z.view(N, 3, hp).transpose(0, 1), self.bw3)
         return t3[0], t3[2], t3[1]
 
     def flops_per_sample(self):
         """MACs*2 of one recurrent inference (for the MFMA roofline line in bench.py)."""
-        mats = [self.dyn1.wt, self.dyn2.wt, self.dyn3.wt, self.heads1.wt] + [l.wt for l in self.rw_tail + self.ac_tail + self.va_tail]
+        mats = [self.dyn1.wt, self.dyn2.wt, self.dyn3.wt, self.heads1.wt] + [l.wt for l in self.rw_tail + self.ac_tail + self.va_tail]  # un-padded
         return 2 * sum(int(m.numel()) for m in mats)
+
+
+# ------------------------------------------------------------------------------------------------ fused MFMA kernel
+_MLP_KINDS = {(8, 1, 17): 0, (8, 1, 16): 1, (12, 1, 16): 2, (12, 3, 8): 3, (1, 1, 8): 4, (6, 1, 16): 5, (3, 3, 4): 6,
+              (8, 1, 18): 7}  # (tiles per wave, groups, k-steps) instantiated in csrc/hz_mlp.hip
+
+
+def _pack_layer(groups_wb, K, nout_pad_per_group):
+    """[(W [o, K], b [o])] per group -> (packed bf16-to-be weights as a flat fp32 tensor, bias fp32 [G * nout_pad]).
+    Packed order [wave 0..3][k-step][tile][lane 0..63][8]: lane l of tile t holds W[n = 16*tile + (l & 15)]
+    [k = 32*s + 8*(l >> 4) + j], the A-operand fragment of v_mfma_f32_16x16x32_bf16 (csrc/hz_mlp.hip)."""
+    G = len(groups_wb)
+    TG = nout_pad_per_group // 64  # tiles per wave per group
+    TW, KS = TG * G, K // 32
+    Wp = torch.zeros(G, nout_pad_per_group, K)
+    bias = torch.zeros(G, nout_pad_per_group)
+    for g, (w, b) in enumerate(groups_wb):
+        assert w.shape[1] <= K
+        Wp[g, :w.shape[0], :w.shape[1]] = w
+        bias[g, :b.shape[0]] = b
+    wave = torch.arange(4).view(4, 1, 1, 1, 1)
+    s = torch.arange(KS).view(1, KS, 1, 1, 1)
+    t = torch.arange(TW).view(1, 1, TW, 1, 1)
+    lane = torch.arange(64).view(1, 1, 1, 64, 1)
+    j = torch.arange(8).view(1, 1, 1, 1, 8)
+    g = t // TG
+    n = 16 * (wave * TG + t % TG) + (lane & 15)
+    k = 32 * s + 8 * (lane >> 4) + j
+    packed = Wp[g.expand(4, KS, TW, 64, 8), n.expand(4, KS, TW, 64, 8), k.expand(4, KS, TW, 64, 8)]
+    return packed.reshape(-1), bias.reshape(-1), _MLP_KINDS[(TW, G, KS)]
+
+
+class FusedRecurrent:
+    """recurrent_inference of an InferenceEngine's network as ONE hand-written MFMA kernel (include/hz_mlp.h).
+    __call__(net_in [N, H + onehot_cols] bf16, hidden_out [N, H] bf16) -> (reward [N], value [N], policy [N, A]) f32."""
+
+    def __init__(self, net, engine):
+        from ._lib import MlpLayer, MlpProgram
+        assert engine.dtype == torch.bfloat16, "the fused kernel computes in bf16 (fp32 accumulate)"
+        self.engine, self.device = engine, engine.device
+        H, A, h, full = engine.H, engine.A, engine.h, engine.full
+        oh = engine.onehot_cols
+        KX = H + oh
+        dyn = net._dynamics_state
+        rw, ac, va = net._dynamics_reward, net._prediction_actor, net._prediction_value
+        V = engine.V
+        layers, packed, biases = [], [], []
+
+        def add(groups_wb, K, nout_g, src_off, dst_off, src_gstride=0, res_off=-1, res_group=-1, relu_mask=0, store_hidden=0):
+            w, b, kind = _pack_layer(groups_wb, K, nout_g)
+            L = MlpLayer(K=K, nout=nout_g * len(groups_wb), groups=len(groups_wb), src_off=src_off, src_gstride=src_gstride,
+                         dst_off=dst_off, res_off=res_off, res_group=res_group, relu_mask=relu_mask,
+                         store_hidden=store_hidden, w_off=sum(x.numel() for x in packed),
+                         b_off=sum(x.numel() for x in biases), kind=kind)
+            layers.append(L)
+            packed.append(w)
+            biases.append(b)
+
+        X, Y1, Y0 = 0, KX, KX + H          # LDS columns: [state|one-hot] , second dynamics buffer, first dynamics buffer
+        Z = Y0 + H                          # head hidden block(s)
+        w1, b1 = _fold(dyn.fc1, dyn.bn1)    # [H, H + A] -> K padded to KX with zero columns
+        if full:
+            add([(w1, b1)], KX, H, X, Y0, relu_mask=1)
+            add([_fold(dyn.fc2, dyn.bn2)], H, H, Y0, Y1, relu_mask=1)
+            add([_fold(dyn.fc3, dyn.bn3)], H, H, Y1, Y0, res_off=X, relu_mask=1, store_hidden=1)
+            add([(torch.cat([_fold(rw[0], rw[1])[0], _fold(ac[0], ac[1])[0], _fold(va[0], va[1])[0]], 0),
+                  torch.cat([_fold(rw[0], rw[1])[1], _fold(ac[0], ac[1])[1], _fold(va[0], va[1])[1]], 0))],
+                H, 3 * h, Y0, Z, relu_mask=1)
+            T = 0                           # X and Y1 are dead: second head layer [T, T + 3h)
+            add([_fold(rw[3], rw[4]), _fold(ac[3].fc1, ac[3].bn1), _fold(va[3], va[4])], h, h, Z, T, src_gstride=h,
+                relu_mask=0b111)
+            O = Y0                          # third head layer over Y0 and the dead reward block of Z
+            # the actor group (layer columns h..2h) adds Z's actor block: residual column = res_off + layer column
+            add([_fold(rw[6]), _fold(ac[3].fc2, ac[3].bn2), _fold(va[6])], h, h, T, O, src_gstride=h,
+                res_off=Z, res_group=1, relu_mask=0b010)
+            add([_fold(ac[4])], h, 64, O + h, 0)
+            off_r, off_v, off_p = O, O + 2 * h, 0
+            width = Z + 3 * h
+        else:
+            add([(w1, b1)], KX, H, X, Y0, res_off=X, relu_mask=1)
+            add([_fold(dyn.fc2, dyn.bn2)], H, H, Y0, Y1, relu_mask=1)
+            add([_fold(dyn.fc3, dyn.bn3)], H, H, Y1, Y0, relu_mask=1, store_hidden=1)
+            Z = Y1                          # Y1 is dead after the third dynamics layer
+            add([(torch.cat([_fold(rw[0], rw[1])[0], _fold(ac[0], ac[1])[0], _fold(va[0], va[1])[0]], 0),
+                  torch.cat([_fold(rw[0], rw[1])[1], _fold(ac[0], ac[1])[1], _fold(va[0], va[1])[1]], 0))],
+                H, 3 * h, Y0, Z, relu_mask=1)
+            assert V <= 64 and A <= 64
+            add([_fold(rw[3]), _fold(ac[3]), _fold(va[3])], h, 64, Z, 0, src_gstride=h)
+            off_r, off_p, off_v = 0, 64, 128
+            width = Y0 + H
+        rs = width + ((8 - width) % 128)    # row stride = 8 (mod 128) elements: conflict-free ds_read_b128 over 16 rows
+        P = MlpProgram(n_layers=len(layers), row_stride=rs, in_width=KX, hidden=H, off_reward=off_r, off_value=off_v,
+                       off_policy=off_p, support_size=V, support_min=-engine.support, num_actions=A)
+        for i, L in enumerate(layers):
+            P.layer[i] = L
+        self.program = P
+        self.weights = torch.cat(packed).to(device=self.device, dtype=torch.bfloat16).contiguous()
+        self.biases = torch.cat(biases).to(device=self.device, dtype=torch.float32).contiguous()
+        self.rows_per_wg = 16
+        self.lds_bytes = lambda mt: mt * rs * 2
+
+    def __call__(self, net_in, hidden_out, out_reward, out_value, out_policy):
+        import ctypes as C
+        from ._lib import check, lib
+        N = net_in.shape[0]
+        mt = 16 if N <= 16 * 256 or self.lds_bytes(32) > 160 * 1024 else 32
+        check(lib.hz_mlp_recurrent(C.byref(self.program), net_in.data_ptr(), net_in.stride(0), self.weights.data_ptr(),
+                                   self.biases.data_ptr(), hidden_out.data_ptr(), out_reward.data_ptr(),
+                                   out_value.data_ptr(), out_policy.data_ptr(), N, mt,
+                                   C.c_void_p(torch.cuda.current_stream().cuda_stream)), "hz_mlp_recurrent")
+        return out_reward, out_value, out_policy

@@ -39,11 +39,14 @@ def _stream():
 
 class SelfPlayActor:
     def __init__(self, config, engine, num_envs, rank=0, seed=0, device=None, use_graph=True, outbox_games=None,
-                 deterministic=False):
+                 deterministic=False, env_id_base=None, stream=None):
         self.cfg, self.engine, self.N = config, engine, int(num_envs)
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         d, N = self.device, self.N
-        self.env_id_base = rank * N
+        # global id of this actor's env 0: keys the env seeds and the tie-break stream, so results do not depend on
+        # how the envs are sharded over GPUs or over concurrent actors of one GPU
+        self.env_id_base = rank * N if env_id_base is None else int(env_id_base)
+        self.stream = stream  # optional side stream: several actors of one GPU overlap their (latency-bound) kernels
         self.deterministic = deterministic
         seeds = seed + self.env_id_base + np.arange(N)
         self.env = HanabiVecEnv(config.env_name, seeds, device=d, mdp=config.mdp)
@@ -88,7 +91,7 @@ class SelfPlayActor:
         self._graph = None
         self.use_graph = use_graph
         self.gen = torch.Generator(device=d)
-        self.gen.manual_seed(int(seed) * 1000003 + rank)
+        self.gen.manual_seed(int(seed) * 1000003 + self.env_id_base)
         self._alpha = torch.full((N, self.A), float(config.root_dirichlet_alpha), dtype=torch.float64, device=d)
         self._start()
 
@@ -179,7 +182,14 @@ class SelfPlayActor:
         self._graph = g
 
     def step(self):
-        """Advance every env by one move."""
+        """Advance every env by one move (enqueue only; on `self.stream` when one was given)."""
+        if self.stream is not None:
+            with torch.cuda.stream(self.stream):
+                self._step()
+        else:
+            self._step()
+
+    def _step(self):
         if self.use_graph and self._graph is None:
             self._capture()
         self._draw()
@@ -193,6 +203,8 @@ class SelfPlayActor:
     def drain(self):
         """Packed records of the games finished since the last drain (synchronises).  Returns a dict of numpy arrays
         with a leading games axis, or None.  Must be called at least once per `cap` finished games."""
+        if self.stream is not None:
+            self.stream.synchronize()
         count = int(self.out_count.item())
         n = count - self._drained
         if n <= 0:
@@ -200,10 +212,59 @@ class SelfPlayActor:
         if n > self.cap:
             raise RuntimeError("outbox overflow: %d games finished since the last drain, capacity %d" % (n, self.cap))
         idx = torch.arange(self._drained, count, device=self.device) % self.cap
-        rec = {k: v.index_select(0, idx).cpu().numpy() for k, v in self.out.items()}
-        rec["meta"] = self.out_meta.index_select(0, idx).cpu().numpy()
+        meta = self.out_meta.index_select(0, idx)
+        tmax = int(meta[:, 0].max().item())  # longest finished game: only that many time slots leave the device
+        rec = {}
+        for k, v in self.out.items():
+            t = tmax + 1 if k in ("legal", "obs") else tmax
+            rec[k] = v.index_select(0, idx)[:, :t].contiguous().cpu().numpy()
+        rec["meta"] = meta.cpu().numpy()
         self._drained = count
         return rec
+
+
+class ActorGroup:
+    """Several SelfPlayActors of one GPU stepped by ONE hipGraph whose branches (one per actor, forked onto side streams
+    inside the capture) have no edges between them, so the runtime may overlap one actor's latency-bound tree kernels
+    with another's GEMMs.  Results are those of the actors run one after the other (disjoint state)."""
+
+    def __init__(self, actors):
+        self.actors = list(actors)
+        self.device = self.actors[0].device
+        self._graph = None
+
+    def _capture(self):
+        for a in self.actors:
+            a.roots.set_params(a.cfg.pb_c_base, a.cfg.pb_c_init, a.cfg.discount, a.cfg.value_delta_max)
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                for a in self.actors:
+                    a._draw()
+                    a._step_body()
+                    a.total_moves += a.N
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        branches = [torch.cuda.Stream(device=self.device) for _ in self.actors]
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            root = torch.cuda.current_stream()
+            for a, b in zip(self.actors, branches):
+                b.wait_stream(root)
+                with torch.cuda.stream(b):
+                    a._step_body()
+            for b in branches:
+                root.wait_stream(b)
+        self._graph = g
+
+    def step(self):
+        if self._graph is None:
+            self._capture()
+        for a in self.actors:
+            a._draw()
+            a.total_moves += a.N
+        self._graph.replay()
 
 
 def unpack_record(rec, i):

@@ -111,3 +111,60 @@ def test_inference_engine_on_gpu(game):
                           (r1, fx["rec_reward"]), (l1, fx["rec_logits"]), (h1, fx["rec_hidden"]),
                           (v2, fx["rec_value"]), (r2, fx["rec_reward"]), (p_log[:, :eng.A], fx["rec_logits"]), (h2, fx["rec_hidden"])]:
             assert _close(got.float().cpu().numpy(), want, tol), (dtype, float(np.max(np.abs(got.float().cpu().numpy().reshape(-1) - np.asarray(want).reshape(-1)))))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("game", ["Hanabi-Small", "Hanabi-Full"])
+@pytest.mark.parametrize("N", [32, 100, 4096, 8192])
+def test_fused_mfma_recurrent_kernel(game, N):
+    """hz_mlp_recurrent (one hand-written MFMA kernel) against the layer-by-layer bf16 PyTorch path it replaces
+    (same rounding points: a few bf16 ulps apart) and, on the golden inputs, against the reference's fp32 outputs."""
+    from hanabizero_amd.model import FusedRecurrent, InferenceEngine
+    net, fx, sup = build(game)
+    eng = InferenceEngine(net, sup, dtype=torch.bfloat16, device="cuda")
+    fused = FusedRecurrent(net, eng)
+    g = torch.Generator(device="cuda").manual_seed(N)
+    B = fx["init_hidden"].shape[0]
+    hid = torch.from_numpy(fx["init_hidden"]).cuda().to(torch.bfloat16)
+    act = torch.from_numpy(fx["action"]).reshape(-1).cuda()
+    if N > B:
+        hid = torch.cat([hid, (torch.rand(N - B, eng.H, device="cuda", generator=g) * 2).to(torch.bfloat16)])
+        act = torch.cat([act, torch.randint(0, eng.A, (N - B,), device="cuda", generator=g)])
+    net_in = torch.zeros(N, eng.H + eng.onehot_cols, dtype=torch.bfloat16, device="cuda")
+    net_in[:, :eng.H] = hid
+    net_in[torch.arange(N), eng.H + act] = 1
+    h_ref = torch.empty(N, eng.H, dtype=torch.bfloat16, device="cuda")
+    r_log, v_log, p_log = eng.recurrent_heads(net_in, h_ref)
+    r_ref, v_ref = eng.support_to_scalar(r_log), eng.support_to_scalar(v_log)
+    h = torch.zeros(N, eng.H, dtype=torch.bfloat16, device="cuda")
+    r, v = torch.empty(N, device="cuda"), torch.empty(N, device="cuda")
+    p = torch.empty(N, eng.A, device="cuda")
+    fused(net_in, h, r, v, p)
+    torch.cuda.synchronize()
+
+    def err(a, b):
+        a, b = a.float(), b.float()
+        return float(((a - b).abs() / b.abs().clamp(min=1.0)).max())
+    # fp32 truth on the same inputs (fp32 engine, torch scalar transform)
+    from hanabizero_amd.model import inverse_scalar_transform
+    e32 = InferenceEngine(net, sup, dtype=torch.float32, device="cuda")
+    h32 = torch.empty(N, eng.H, dtype=torch.float32, device="cuda")
+    r32l, v32l, p32 = e32.recurrent_heads(net_in.float(), h32)
+    r32 = inverse_scalar_transform(r32l[:, :eng.V], -sup, sup).reshape(-1)
+    v32 = inverse_scalar_transform(v32l[:, :eng.V], -sup, sup).reshape(-1)
+    for name, got, torch_bf16, truth in [("hidden", h, h_ref, h32), ("policy", p, p_log[:, :eng.A], p32[:, :eng.A]),
+                                         ("reward", r, r_ref, r32), ("value", v, v_ref, v32)]:
+        e_fused, e_torch = err(got, truth), err(torch_bf16, truth)
+        m_fused = float(((got.float() - truth).abs() / truth.abs().clamp(min=1.0)).mean())
+        m_torch = float(((torch_bf16.float() - truth).abs() / truth.abs().clamp(min=1.0)).mean())
+        # the hand-written kernel is as close to fp32 as the bf16 PyTorch path it replaces (same rounding points):
+        # mean error within 1.3x, worst element within 2.5x (maxima of a few thousand bf16 roundings are noisy)
+        assert m_fused <= 1.3 * m_torch + 1e-4, (name, m_fused, m_torch)
+        assert e_fused <= max(2.5 * e_torch, 2e-2), (name, e_fused, e_torch)
+        if N <= B:  # in-distribution (golden) inputs: absolute bound too
+            assert e_fused < 8e-2, (name, e_fused)
+    # mean error is far below the worst-case ulp bound: no systematic (indexing) error
+    assert float((h.float() - h32).abs().mean()) < 6e-3
+    assert err(h[:B], torch.from_numpy(fx["rec_hidden"]).cuda()) < 6e-2
+    assert err(v[:B], torch.from_numpy(fx["rec_value"]).reshape(-1).cuda()) < 8e-2
+    assert err(p[:B], torch.from_numpy(fx["rec_logits"]).cuda()) < 6e-2
