@@ -39,16 +39,39 @@ __device__ __forceinline__ float hz_readlane_f(float v, int lane) {
 __device__ __forceinline__ int hz_readlane_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 __device__ __forceinline__ int hz_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-// max / min over the 64 lanes ignoring nothing (callers mask with +-inf); butterfly over ds_swizzle/DPP via __shfl_xor
-__device__ __forceinline__ float hz_wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+// ---- DPP reductions (no LDS traffic): after the four steps below every lane of a 16-lane row holds the row's result
+//      quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror
+#define HZ_DPP(v, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (ctrl), 0xf, 0xf, true))
+__device__ __forceinline__ float hz_row16_max(float v) {
+  v = fmaxf(v, HZ_DPP(v, 0xB1));
+  v = fmaxf(v, HZ_DPP(v, 0x4E));
+  v = fmaxf(v, HZ_DPP(v, 0x141));
+  v = fmaxf(v, HZ_DPP(v, 0x140));
   return v;
 }
-__device__ __forceinline__ float hz_wave_min(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+__device__ __forceinline__ float hz_row16_min(float v) {
+  v = fminf(v, HZ_DPP(v, 0xB1));
+  v = fminf(v, HZ_DPP(v, 0x4E));
+  v = fminf(v, HZ_DPP(v, 0x141));
+  v = fminf(v, HZ_DPP(v, 0x140));
   return v;
+}
+__device__ __forceinline__ float hz_row16_sum(float v) {
+  v += HZ_DPP(v, 0xB1);
+  v += HZ_DPP(v, 0x4E);
+  v += HZ_DPP(v, 0x141);
+  v += HZ_DPP(v, 0x140);
+  return v;
+}
+
+// max / min over the 64 lanes (callers mask with +-inf): 16-lane DPP butterflies, then the four row results
+__device__ __forceinline__ float hz_wave_max(float v) {
+  v = hz_row16_max(v);
+  return fmaxf(fmaxf(hz_readlane_f(v, 0), hz_readlane_f(v, 16)), fmaxf(hz_readlane_f(v, 32), hz_readlane_f(v, 48)));
+}
+__device__ __forceinline__ float hz_wave_min(float v) {
+  v = hz_row16_min(v);
+  return fminf(fminf(hz_readlane_f(v, 0), hz_readlane_f(v, 16)), fminf(hz_readlane_f(v, 32), hz_readlane_f(v, 48)));
 }
 
 // ---- expf, bit-identical to glibc >= 2.27 expf (sysdeps/ieee754/flt-32/e_expf.c, the x86-64 FMA ifunc

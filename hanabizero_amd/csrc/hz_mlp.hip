@@ -24,59 +24,83 @@ __device__ __forceinline__ uint16_t f2bf(float f) {  // round-to-nearest-even; N
   return (uint16_t)(u >> 16);
 }
 
-// One layer for this wave.  TW = output tiles (16 columns) per wave, G = groups, KS = k-steps (K/32), RT = row tiles.
-template <int TW, int G, int KS, int RT>
+// One layer for this wave.  TW = output tiles (16 columns) per wave, G = groups, RT = row tiles; ks = K/32 at run time.
+// The k-loop is ROLLED (4 k-steps per trip, a 4-slot register ring for the weight fragments: prefetch distance 3
+// k-steps, >= 24 KiB in flight per wave for TW = 8) so that the whole layer chain stays instruction-cache resident;
+// a fully unrolled chain is ~100 KiB of straight-line code executed once per launch and runs at I-fetch speed.
+template <int TW, int G, int RT>
 __device__ __forceinline__ void run_layer(const hz_mlp_layer_t& L, const uint16_t* __restrict__ W,
                                           const float* __restrict__ bias, uint16_t* lds, int rs, int wave, int lane) {
   constexpr int TG = TW / G;
-  constexpr int D = (KS >= 4) ? 4 : 2;  // weight prefetch distance in k-steps (>= 32 KiB in flight per wave)
+  constexpr int R = 4;  // ring slots; prefetch distance R - 1
+  const int ks = L.K >> 5;
+  const int r0 = lane & 15, kq = (lane >> 4) * 8;
+  const int ng = L.nout / G;
+  // this wave's biases: issued first so their latency hides under the k-loop
+  float4 bv[TW];
+#pragma unroll
+  for (int t = 0; t < TW; ++t)
+    bv[t] = *reinterpret_cast<const float4*>(bias + L.b_off + (t / TG) * ng + 16 * (wave * TG + (t % TG)) + 4 * (lane >> 4));
   f32x4 acc[TW][RT];
 #pragma unroll
   for (int t = 0; t < TW; ++t)
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) acc[t][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const bf16x8* wp = reinterpret_cast<const bf16x8*>(W + L.w_off) + (size_t)wave * KS * TW * 64 + lane;
-  bf16x8 wf[D + 1][TW];
+  const bf16x8* wp = reinterpret_cast<const bf16x8*>(W + L.w_off) + (size_t)wave * ks * TW * 64 + lane;
+  const uint16_t* src = lds + (size_t)r0 * rs + L.src_off + kq;
+  bf16x8 wf[R][TW];
 #pragma unroll
-  for (int d = 0; d < D; ++d)
-    if (d < KS) {
+  for (int d = 0; d < R - 1; ++d)
+    if (d < ks) {
 #pragma unroll
       for (int t = 0; t < TW; ++t) wf[d][t] = wp[(d * TW + t) * 64];
     }
-  const int r0 = lane & 15, kq = (lane >> 4) * 8;
+  bf16x8 b[G][RT], bn[G][RT];
 #pragma unroll
-  for (int s = 0; s < KS; ++s) {
-    if (s + D < KS) {
+  for (int g = 0; g < G; ++g)
 #pragma unroll
-      for (int t = 0; t < TW; ++t) wf[(s + D) % (D + 1)][t] = wp[((s + D) * TW + t) * 64];
-    }
-    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch D k-steps ahead of its use (the scheduler would sink it)
-    bf16x8 b[G][RT];
-#pragma unroll
-    for (int g = 0; g < G; ++g)
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt)
-        b[g][rt] = *reinterpret_cast<const bf16x8*>(lds + (size_t)(16 * rt + r0) * rs + L.src_off + g * L.src_gstride + 32 * s + kq);
-#pragma unroll
-    for (int t = 0; t < TW; ++t)
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt)
-        acc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s % (D + 1)][t], b[t / TG][rt], acc[t][rt], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
+    for (int rt = 0; rt < RT; ++rt) b[g][rt] = *reinterpret_cast<const bf16x8*>(src + (size_t)(16 * rt) * rs + g * L.src_gstride);
+  __builtin_amdgcn_sched_barrier(0);
+
+#define HZ_MLP_STEP(S, U)                                                                                              \
+  {                                                                                                                    \
+    if ((S) + R - 1 < ks) {                                                                                            \
+      _Pragma("unroll") for (int t = 0; t < TW; ++t) wf[((U) + R - 1) % R][t] = wp[(((S) + R - 1) * TW + t) * 64];    \
+    }                                                                                                                  \
+    if ((S) + 1 < ks) {                                                                                                \
+      _Pragma("unroll") for (int g = 0; g < G; ++g) _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                 \
+          bn[g][rt] = *reinterpret_cast<const bf16x8*>(src + (size_t)(16 * rt) * rs + g * L.src_gstride + 32 * ((S) + 1)); \
+    }                                                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    _Pragma("unroll") for (int t = 0; t < TW; ++t) _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                  \
+        acc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[(U) % R][t], b[t / TG][rt], acc[t][rt], 0, 0, 0);     \
+    _Pragma("unroll") for (int g = 0; g < G; ++g) _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) b[g][rt] = bn[g][rt]; \
+    __builtin_amdgcn_sched_barrier(0);                                                                                 \
   }
+
+  const int ks_main = ks & ~3;
+  for (int s = 0; s < ks_main; s += 4) {
+    HZ_MLP_STEP(s, 0)
+    HZ_MLP_STEP(s + 1, 1)
+    HZ_MLP_STEP(s + 2, 2)
+    HZ_MLP_STEP(s + 3, 3)
+  }
+  if (ks - ks_main >= 1) HZ_MLP_STEP(ks_main, 0)
+  if (ks - ks_main >= 2) HZ_MLP_STEP(ks_main + 1, 1)
+  if (ks - ks_main >= 3) HZ_MLP_STEP(ks_main + 2, 2)
+#undef HZ_MLP_STEP
+
   // epilogue: bias (+ residual) (+ ReLU) in fp32, round to bf16, 4 consecutive columns per lane
-  const int ng = L.nout / G;
 #pragma unroll
   for (int t = 0; t < TW; ++t) {
     const int g = t / TG;
     const int col = g * ng + 16 * (wave * TG + (t % TG)) + 4 * (lane >> 4);
-    const float4 bv = *reinterpret_cast<const float4*>(bias + L.b_off + col);
     const bool relu = (L.relu_mask >> g) & 1;
     const bool res = L.res_off >= 0 && (L.res_group < 0 || L.res_group == g);
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
       const size_t rowbase = (size_t)(16 * rt + r0) * rs;
-      float v[4] = {acc[t][rt][0] + bv.x, acc[t][rt][1] + bv.y, acc[t][rt][2] + bv.z, acc[t][rt][3] + bv.w};
+      float v[4] = {acc[t][rt][0] + bv[t].x, acc[t][rt][1] + bv[t].y, acc[t][rt][2] + bv[t].z, acc[t][rt][3] + bv[t].w};
       if (res) {
         const uint2 rr = *reinterpret_cast<const uint2*>(lds + rowbase + L.res_off + col);
         v[0] += bf2f((uint16_t)(rr.x & 0xffffu)); v[1] += bf2f((uint16_t)(rr.x >> 16));
@@ -97,36 +121,31 @@ __device__ __forceinline__ void run_layer(const hz_mlp_layer_t& L, const uint16_
 template <int RT>
 __device__ __forceinline__ void dispatch_layer(const hz_mlp_layer_t& L, const uint16_t* W, const float* bias,
                                                uint16_t* lds, int rs, int wave, int lane) {
-  switch (L.kind) {  // (tiles per wave, groups, k-steps)
-    case 0: run_layer<8, 1, 17, RT>(L, W, bias, lds, rs, wave, lane); break;   // 544 -> 512
-    case 1: run_layer<8, 1, 16, RT>(L, W, bias, lds, rs, wave, lane); break;   // 512 -> 512
-    case 2: run_layer<12, 1, 16, RT>(L, W, bias, lds, rs, wave, lane); break;  // 512 -> 768
-    case 3: run_layer<12, 3, 8, RT>(L, W, bias, lds, rs, wave, lane); break;   // 3 x (256 -> 256)
-    case 4: run_layer<1, 1, 8, RT>(L, W, bias, lds, rs, wave, lane); break;    // 256 -> 64
-    case 5: run_layer<6, 1, 16, RT>(L, W, bias, lds, rs, wave, lane); break;   // 512 -> 384
-    case 6: run_layer<3, 3, 4, RT>(L, W, bias, lds, rs, wave, lane); break;    // 3 x (128 -> 64)
-    case 7: run_layer<8, 1, 18, RT>(L, W, bias, lds, rs, wave, lane); break;   // 576 -> 512
+  switch (L.kind) {  // (tiles per wave, groups); the k-step count is a run-time value
+    case 0: case 1: case 7: run_layer<8, 1, RT>(L, W, bias, lds, rs, wave, lane); break;  // 544|512|576 -> 512
+    case 2: run_layer<12, 1, RT>(L, W, bias, lds, rs, wave, lane); break;                 // 512 -> 768
+    case 3: run_layer<12, 3, RT>(L, W, bias, lds, rs, wave, lane); break;                 // 3 x (256 -> 256)
+    case 4: run_layer<1, 1, RT>(L, W, bias, lds, rs, wave, lane); break;                  // 256 -> 64
+    case 5: run_layer<6, 1, RT>(L, W, bias, lds, rs, wave, lane); break;                  // 512 -> 384
+    case 6: run_layer<3, 3, RT>(L, W, bias, lds, rs, wave, lane); break;                  // 3 x (128 -> 64)
     default: break;
   }
 }
 
-// inverse_scalar_transform of one LDS row of bf16 logits by one wave (same maths as hz_tree.hip support_to_scalar)
-__device__ __forceinline__ float lds_support_to_scalar(const uint16_t* row, int V, int support_min, int lane) {
+// inverse_scalar_transform of LDS rows of bf16 logits, one (row, head) pair per 16-lane row of the wave (DPP
+// reductions, no shuffles through LDS).  Same maths as hz_tree.hip support_to_scalar.
+__device__ __forceinline__ float row16_support_to_scalar(const uint16_t* row, int V, int support_min, int l16) {
   float m = -INFINITY;
-  for (int i = lane; i < V; i += 64) m = fmaxf(m, bf2f(row[i]));
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  for (int i = l16; i < V; i += 16) m = fmaxf(m, bf2f(row[i]));
+  m = hz_row16_max(m);
   float se = 0.0f, sw = 0.0f;
-  for (int i = lane; i < V; i += 64) {
+  for (int i = l16; i < V; i += 16) {
     const float e = __expf(bf2f(row[i]) - m);
     se += e;
     sw += e * (float)(support_min + i);
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    se += __shfl_xor(se, o, 64);
-    sw += __shfl_xor(sw, o, 64);
-  }
+  se = hz_row16_sum(se);
+  sw = hz_row16_sum(sw);
   const float v = sw / se;
   const float eps = 0.001f;
   const float t = (sqrtf(1.0f + 4.0f * eps * (fabsf(v) + 1.0f + eps)) - 1.0f) / (2.0f * eps);
@@ -173,20 +192,24 @@ __global__ __launch_bounds__(256, 1) void k_mlp_recurrent(hz_mlp_program_t P, co
       }
     }
   }
-  // heads -> scalars / policy logits: one wave per row, rows round-robin over the 4 waves
-  for (int r = wave; r < MT; r += 4) {
-    if (row0 + r >= n_rows) break;
-    const uint16_t* row = lds + (size_t)r * rs;
-    const float rew = lds_support_to_scalar(row + P.off_reward, P.support_size, P.support_min, lane);
-    const float val = lds_support_to_scalar(row + P.off_value, P.support_size, P.support_min, lane);
-    if (lane == 0) {
-      out_reward[row0 + r] = rew;
-      out_value[row0 + r] = val;
+  // heads -> scalars / policy logits: 16 lanes per (row, head) pair, 16 pairs in flight per workgroup pass
+  {
+    const int l16 = tid & 15, slot = tid >> 4;  // 16 slots of 16 lanes
+    for (int pair = slot; pair < 2 * MT; pair += 16) {
+      const int r = pair >> 1, head = pair & 1;
+      if (row0 + r < n_rows) {
+        const uint16_t* row = lds + (size_t)r * rs;
+        const float x = row16_support_to_scalar(row + (head ? P.off_value : P.off_reward), P.support_size, P.support_min, l16);
+        if (l16 == 0) (head ? out_value : out_reward)[row0 + r] = x;
+      }
     }
-    if (lane < P.num_actions) {
-      float x = bf2f(row[P.off_policy + lane]);
-      if (x != x) x = 0.0f;  // core/mcts.py:48-49
-      out_policy[(size_t)(row0 + r) * P.num_actions + lane] = x;
+    for (int i = tid; i < MT * P.num_actions; i += 256) {
+      const int r = i / P.num_actions, a = i % P.num_actions;
+      if (row0 + r < n_rows) {
+        float x = bf2f(lds[(size_t)r * rs + P.off_policy + a]);
+        if (x != x) x = 0.0f;  // core/mcts.py:48-49
+        out_policy[(size_t)(row0 + r) * P.num_actions + a] = x;
+      }
     }
   }
 }

@@ -295,9 +295,8 @@ __device__ __forceinline__ float load_as_f32(const void* p, long long i, int dty
 }
 
 __device__ __forceinline__ float hz_wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v = hz_row16_sum(v);
+  return (hz_readlane_f(v, 0) + hz_readlane_f(v, 16)) + (hz_readlane_f(v, 32) + hz_readlane_f(v, 48));
 }
 
 // inverse_scalar_transform (core/config.py:210-232, delta = 1, epsilon = 0.001) of one row of V categorical
