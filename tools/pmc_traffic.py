@@ -11,8 +11,9 @@ import json
 import os
 import sys
 
-KERNELS = {"k_traverse": "k_traverse", "k_backprop": "k_backprop", "k_env_observe": "k_env_observe",
-           "k_env_rules": "k_env_rules", "k_add_relu": "k_add_relu_vec", "k_prepare": "k_prepare"}
+KERNELS = {"k_traverse": "k_traverse", "k_backprop": "k_backprop", "k_mlp_recurrent": "k_mlp_recurrent",
+           "k_env_observe": "k_env_observe", "k_env_rules": "k_env_rules", "k_prepare": "k_prepare",
+           "k_select_action": "k_select_action", "k_rows_scatter": "k_rows_scatter"}
 
 
 def mean_by_kernel(path):
