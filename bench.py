@@ -89,8 +89,14 @@ def kernel_timing(actor, sample_sims=(4, 16, 28, 40), clones=8, replays=5):
             snaps = [roots.clone() for _ in range(clones)]
             ins = [torch.empty_like(net_in) for _ in range(clones)]
             torch.cuda.synchronize()
-            g = timed_graph(lambda: [c.traverse_tensors(actor.pool, b, onehot_cols=oh) for c, b in zip(snaps, ins)])
-        roots.traverse_tensors(actor.pool, net_in, onehot_cols=oh)
+            if fused is not None:
+                g = timed_graph(lambda: [c.traverse_tensors() for c in snaps])
+            else:
+                g = timed_graph(lambda: [c.traverse_tensors(actor.pool, b, onehot_cols=oh) for c, b in zip(snaps, ins)])
+        if fused is not None:
+            roots.traverse_tensors()
+        else:
+            roots.traverse_tensors(actor.pool, net_in, onehot_cols=oh)
         if sampled:
             best = 1e9
             for _ in range(replays):
@@ -102,7 +108,8 @@ def kernel_timing(actor, sample_sims=(4, 16, 28, 40), clones=8, replays=5):
             depth += float(roots.path_len_tensor().float().mean()) - 1.0
             entries += sim + 1
         if fused is not None:
-            fused(net_in, actor.pool[sim + 1], rew, val, pol)
+            ix_t, la_t = roots._ix, roots._la
+            fused(actor.pool, ix_t, la_t, actor.pool[sim + 1], rew, val, pol)
             back = lambda c: c.backprop_tensors(sim + 1, rew, val, pol)
         else:
             r_log, v_log, p_log = eng.recurrent_heads(net_in, actor.pool[sim + 1])
@@ -111,7 +118,7 @@ def kernel_timing(actor, sample_sims=(4, 16, 28, 40), clones=8, replays=5):
             # the MFMA kernel: 8 launches on 8 different input / output buffers
             outs = [torch.empty_like(actor.pool[0]) for _ in range(clones)]
             torch.cuda.synchronize()
-            g3 = timed_graph(lambda: [fused(b, o, rew, val, pol) for b, o in zip(ins, outs)])
+            g3 = timed_graph(lambda: [fused(actor.pool, ix_t, la_t, o, rew, val, pol) for o in outs])
             best = 1e9
             for _ in range(replays):
                 a, b = ev(), ev()
@@ -302,7 +309,7 @@ def main():
         V = engine.V
         # algorithmic bytes per launch (SURVEY.md 8d per-tree figures x N trees per launch)
         Nk = actor.N  # trees per launch (per actor)
-        b_trav = Nk * (16 * A * dbar + 2 * H * e)                          # child rows per level + hidden row in and out
+        b_trav = Nk * (16 * A * dbar + (0 if engine.fused is not None else 2 * H * e))                          # child rows per level + hidden row in and out
         # fused backup: policy logits + the two categorical head rows in (net dtype), child rows out, header, backup, min-max
         b_back = Nk * (A * e + 2 * V * e + 16 * A + 16 + 16 * (dbar + 1) + 12 * sbar)
         fused_on = engine.fused is not None
@@ -316,7 +323,7 @@ def main():
             t = times["k_mlp_recurrent"]
             other["k_mlp_recurrent"] = {"bound": "mfma", "avg_launch_us": t * 1e6, "flop_per_launch": flops,
                                         "TFLOPps": flops / t / 1e12, "frac": flops / t / 1e12 / MFMA_BF16_PEAK_TFLOPS,
-                                        "weight_bytes_per_wg": int(engine.fused.weights.numel() * 2)}
+                                        "weight_bytes_per_wg": engine.fused.weight_bytes_per_wg}
         traffic_all = {}
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):

@@ -13,18 +13,16 @@ class HzError(RuntimeError):
     pass
 
 
-class MlpLayer(C.Structure):  # include/hz_mlp.h hz_mlp_layer_t
-    _fields_ = [("K", C.c_int32), ("nout", C.c_int32), ("groups", C.c_int32), ("src_off", C.c_int32),
-                ("src_gstride", C.c_int32), ("dst_off", C.c_int32), ("res_off", C.c_int32), ("res_group", C.c_int32),
-                ("relu_mask", C.c_int32), ("store_hidden", C.c_int32), ("w_off", C.c_int64), ("b_off", C.c_int32),
-                ("kind", C.c_int32)]
+class MlpJob(C.Structure):  # include/hz_mlp.h hz_mlp_job_t
+    _fields_ = [("ks", C.c_int32), ("src_off", C.c_int32), ("dst_off", C.c_int32), ("res_off", C.c_int32),
+                ("bias_off", C.c_int32), ("flags", C.c_int32), ("reserved0", C.c_int32), ("reserved1", C.c_int32)]
 
 
-class MlpProgram(C.Structure):  # include/hz_mlp.h hz_mlp_program_t
-    _fields_ = [("n_layers", C.c_int32), ("row_stride", C.c_int32), ("in_width", C.c_int32), ("hidden", C.c_int32),
-                ("off_reward", C.c_int32), ("off_value", C.c_int32), ("off_policy", C.c_int32),
+class MlpHeader(C.Structure):  # include/hz_mlp.h hz_mlp_header_t
+    _fields_ = [("n_jobs", C.c_int32), ("row_stride", C.c_int32), ("hidden", C.c_int32), ("state_off", C.c_int32),
+                ("hidden_off", C.c_int32), ("off_reward", C.c_int32), ("off_value", C.c_int32), ("off_policy", C.c_int32),
                 ("support_size", C.c_int32), ("support_min", C.c_int32), ("num_actions", C.c_int32),
-                ("layer", MlpLayer * 12)]
+                ("action_table_stride", C.c_int32), ("wave_stream_off", C.c_int64 * 4)]
 
 
 def _load():
@@ -66,7 +64,7 @@ def _load():
         "hz_select_action": [I, I, V, V, V, F, I, V, V, V],
         "hz_rows_scatter": [V, V, I64, V, I, V],
         # include/hz_mlp.h
-        "hz_mlp_recurrent": [C.POINTER(MlpProgram), V, I64, V, V, V, V, V, V, I, I, V],
+        "hz_mlp_recurrent": [C.POINTER(MlpHeader), V, V, V, V, V, I64, V, I64, V, V, V, V, V, I, I, V],
         # include/hz_netglue.h
         "hz_add_relu": [V, I64, V, I64, I, I, I, V],
         "hz_test_expf": [V, V, I64, V],

@@ -43,8 +43,8 @@ class MCTS(object):
                 val = torch.empty(num, dtype=torch.float32, device=roots.device)
                 pol = torch.empty((num, roots.action_num), dtype=torch.float32, device=roots.device)
                 for index_simulation in range(S - 1):
-                    roots.traverse_tensors(pool, net_in, onehot_cols=oh)
-                    fused(net_in, pool[index_simulation + 1], rew, val, pol)
+                    ix, _, la = roots.traverse_tensors()  # the MFMA kernel gathers pool[ix, tree] itself
+                    fused(pool, ix, la, pool[index_simulation + 1], rew, val, pol)
                     roots.backprop_tensors(index_simulation + 1, rew, val, pol)
                 return
             for index_simulation in range(S - 1):

@@ -395,111 +395,176 @@ class InferenceEngine:
 
 
 # ------------------------------------------------------------------------------------------------ fused MFMA kernel
-_MLP_KINDS = {(8, 1, 17): 0, (8, 1, 16): 1, (12, 1, 16): 2, (12, 3, 8): 3, (1, 1, 8): 4, (6, 1, 16): 5, (3, 3, 4): 6,
-              (8, 1, 18): 7}  # (tiles per wave, groups, k-steps) instantiated in csrc/hz_mlp.hip
+MLP_RELU, MLP_ACTION_ROW, MLP_BARRIER, MLP_STORE_HIDDEN = 1, 2, 4, 8  # include/hz_mlp.h flags
 
 
-def _pack_layer(groups_wb, K, nout_pad_per_group):
-    """[(W [o, K], b [o])] per group -> (packed bf16-to-be weights as a flat fp32 tensor, bias fp32 [G * nout_pad]).
-    Packed order [wave 0..3][k-step][tile][lane 0..63][8]: lane l of tile t holds W[n = 16*tile + (l & 15)]
-    [k = 32*s + 8*(l >> 4) + j], the A-operand fragment of v_mfma_f32_16x16x32_bf16 (csrc/hz_mlp.hip)."""
-    G = len(groups_wb)
-    TG = nout_pad_per_group // 64  # tiles per wave per group
-    TW, KS = TG * G, K // 32
-    Wp = torch.zeros(G, nout_pad_per_group, K)
-    bias = torch.zeros(G, nout_pad_per_group)
-    for g, (w, b) in enumerate(groups_wb):
-        assert w.shape[1] <= K
-        Wp[g, :w.shape[0], :w.shape[1]] = w
-        bias[g, :b.shape[0]] = b
-    wave = torch.arange(4).view(4, 1, 1, 1, 1)
-    s = torch.arange(KS).view(1, KS, 1, 1, 1)
-    t = torch.arange(TW).view(1, 1, TW, 1, 1)
-    lane = torch.arange(64).view(1, 1, 1, 64, 1)
-    j = torch.arange(8).view(1, 1, 1, 1, 8)
-    g = t // TG
-    n = 16 * (wave * TG + t % TG) + (lane & 15)
-    k = 32 * s + 8 * (lane >> 4) + j
-    packed = Wp[g.expand(4, KS, TW, 64, 8), n.expand(4, KS, TW, 64, 8), k.expand(4, KS, TW, 64, 8)]
-    return packed.reshape(-1), bias.reshape(-1), _MLP_KINDS[(TW, G, KS)]
+def _pack_fragments(w64, ks):
+    """W [<=64, <=32*ks] fp32 -> [ks][4 tiles][64 lanes][8] (the A-operand fragments of v_mfma_f32_16x16x32_bf16:
+    lane l of tile t at k-step s holds W[16t + (l & 15)][32s + 8(l >> 4) + j], j = 0..7), flattened."""
+    Wp = torch.zeros(64, 32 * ks)
+    Wp[:w64.shape[0], :w64.shape[1]] = w64
+    s = torch.arange(ks).view(ks, 1, 1, 1)
+    t = torch.arange(4).view(1, 4, 1, 1)
+    lane = torch.arange(64).view(1, 1, 64, 1)
+    j = torch.arange(8).view(1, 1, 1, 8)
+    n = (16 * t + (lane & 15)).expand(ks, 4, 64, 8)
+    k = (32 * s + 8 * (lane >> 4) + j).expand(ks, 4, 64, 8)
+    return Wp[n, k].reshape(-1)
 
 
 class FusedRecurrent:
-    """recurrent_inference of an InferenceEngine's network as ONE hand-written MFMA kernel (include/hz_mlp.h).
-    __call__(net_in [N, H + onehot_cols] bf16, hidden_out [N, H] bf16) -> (reward [N], value [N], policy [N, A]) f32."""
+    """The search loop's recurrent_inference as ONE hand-written MFMA kernel (include/hz_mlp.h): gathers the parent
+    hidden states from the pool, runs dynamics + reward/value/policy heads with every activation in LDS, applies the
+    scalar transforms, writes the next hidden state into its pool slot.
+
+    __call__(pool [S, N, H] bf16, ix [N] i32, actions [N] i32, hidden_out [N, H] bf16, out_reward [N], out_value [N],
+             out_policy [N, A])   (fp32 outputs; buffers supplied by the caller, nothing is allocated)"""
 
     def __init__(self, net, engine):
-        from ._lib import MlpLayer, MlpProgram
+        from ._lib import MlpHeader, MlpJob
         assert engine.dtype == torch.bfloat16, "the fused kernel computes in bf16 (fp32 accumulate)"
         self.engine, self.device = engine, engine.device
-        H, A, h, full = engine.H, engine.A, engine.h, engine.full
-        oh = engine.onehot_cols
-        KX = H + oh
-        dyn = net._dynamics_state
-        rw, ac, va = net._dynamics_reward, net._prediction_actor, net._prediction_value
-        V = engine.V
-        layers, packed, biases = [], [], []
+        H, A, h, full, V = engine.H, engine.A, engine.h, engine.full, 2 * engine.support + 1
+        dyn, rw, ac, va = net._dynamics_state, net._dynamics_reward, net._prediction_actor, net._prediction_value
+        jobs = []              # [pass][wave] -> dict or None
+        streams = [[], [], [], []]
+        bias_chunks = []       # 64-float chunks
+        act_rows = []          # (bias chunk index, [A, 64] block)
 
-        def add(groups_wb, K, nout_g, src_off, dst_off, src_gstride=0, res_off=-1, res_group=-1, relu_mask=0, store_hidden=0):
-            w, b, kind = _pack_layer(groups_wb, K, nout_g)
-            L = MlpLayer(K=K, nout=nout_g * len(groups_wb), groups=len(groups_wb), src_off=src_off, src_gstride=src_gstride,
-                         dst_off=dst_off, res_off=res_off, res_group=res_group, relu_mask=relu_mask,
-                         store_hidden=store_hidden, w_off=sum(x.numel() for x in packed),
-                         b_off=sum(x.numel() for x in biases), kind=kind)
-            layers.append(L)
-            packed.append(w)
-            biases.append(b)
+        def add_dense(w, b, K, src_off, dst_off, relu, res_off=None, barrier=True, store_hidden=False, act_w=None):
+            """out[:, dst_off:dst_off+nout] = act(in[:, src_off:src_off+K] @ w^T + b ...), nout split into 64-column
+            wave jobs, 4 per pass."""
+            nout = w.shape[0]
+            chunks = [(c, min(64, nout - c)) for c in range(0, nout, 64)]
+            for p0 in range(0, len(chunks), 4):
+                row = []
+                for wave in range(4):
+                    if p0 + wave >= len(chunks):
+                        row.append(None)
+                        continue
+                    c, n = chunks[p0 + wave]
+                    row.append(dict(w=w[c:c + n], b=b[c:c + n], ks=K // 32, src=src_off, dst=dst_off + c,
+                                    res=None if res_off is None else res_off + c, relu=relu,
+                                    act=None if act_w is None else act_w[c:c + n]))
+                jobs.append(dict(entries=row, barrier=barrier and p0 == 0, store_hidden=store_hidden and p0 == 0))
 
-        X, Y1, Y0 = 0, KX, KX + H          # LDS columns: [state|one-hot] , second dynamics buffer, first dynamics buffer
-        Z = Y0 + H                          # head hidden block(s)
-        w1, b1 = _fold(dyn.fc1, dyn.bn1)    # [H, H + A] -> K padded to KX with zero columns
-        if full:
-            add([(w1, b1)], KX, H, X, Y0, relu_mask=1)
-            add([_fold(dyn.fc2, dyn.bn2)], H, H, Y0, Y1, relu_mask=1)
-            add([_fold(dyn.fc3, dyn.bn3)], H, H, Y1, Y0, res_off=X, relu_mask=1, store_hidden=1)
-            add([(torch.cat([_fold(rw[0], rw[1])[0], _fold(ac[0], ac[1])[0], _fold(va[0], va[1])[0]], 0),
-                  torch.cat([_fold(rw[0], rw[1])[1], _fold(ac[0], ac[1])[1], _fold(va[0], va[1])[1]], 0))],
-                H, 3 * h, Y0, Z, relu_mask=1)
-            T = 0                           # X and Y1 are dead: second head layer [T, T + 3h)
-            add([_fold(rw[3], rw[4]), _fold(ac[3].fc1, ac[3].bn1), _fold(va[3], va[4])], h, h, Z, T, src_gstride=h,
-                relu_mask=0b111)
-            O = Y0                          # third head layer over Y0 and the dead reward block of Z
-            # the actor group (layer columns h..2h) adds Z's actor block: residual column = res_off + layer column
-            add([_fold(rw[6]), _fold(ac[3].fc2, ac[3].bn2), _fold(va[6])], h, h, T, O, src_gstride=h,
-                res_off=Z, res_group=1, relu_mask=0b010)
-            add([_fold(ac[4])], h, 64, O + h, 0)
-            off_r, off_v, off_p = O, O + 2 * h, 0
-            width = Z + 3 * h
-        else:
-            add([(w1, b1)], KX, H, X, Y0, res_off=X, relu_mask=1)
-            add([_fold(dyn.fc2, dyn.bn2)], H, H, Y0, Y1, relu_mask=1)
-            add([_fold(dyn.fc3, dyn.bn3)], H, H, Y1, Y0, relu_mask=1, store_hidden=1)
-            Z = Y1                          # Y1 is dead after the third dynamics layer
-            add([(torch.cat([_fold(rw[0], rw[1])[0], _fold(ac[0], ac[1])[0], _fold(va[0], va[1])[0]], 0),
-                  torch.cat([_fold(rw[0], rw[1])[1], _fold(ac[0], ac[1])[1], _fold(va[0], va[1])[1]], 0))],
-                H, 3 * h, Y0, Z, relu_mask=1)
-            assert V <= 64 and A <= 64
-            add([_fold(rw[3]), _fold(ac[3]), _fold(va[3])], h, 64, Z, 0, src_gstride=h)
-            off_r, off_p, off_v = 0, 64, 128
-            width = Y0 + H
-        rs = width + ((8 - width) % 128)    # row stride = 8 (mod 128) elements: conflict-free ds_read_b128 over 16 rows
-        P = MlpProgram(n_layers=len(layers), row_stride=rs, in_width=KX, hidden=H, off_reward=off_r, off_value=off_v,
-                       off_policy=off_p, support_size=V, support_min=-engine.support, num_actions=A)
-        for i, L in enumerate(layers):
-            P.layer[i] = L
-        self.program = P
-        self.weights = torch.cat(packed).to(device=self.device, dtype=torch.bfloat16).contiguous()
-        self.biases = torch.cat(biases).to(device=self.device, dtype=torch.float32).contiguous()
-        self.rows_per_wg = 16
-        self.lds_bytes = lambda mt: mt * rs * 2
+        def add_group(items, K, barrier=True):
+            """one pass: wave g runs its own (w [<=64.., K], b, src, dst, res, relu) job; items may hold > 4 jobs."""
+            for p0 in range(0, len(items), 4):
+                row = [None] * 4
+                for wave, it in enumerate(items[p0:p0 + 4]):
+                    w, b, src, dst, res, relu = it
+                    row[wave] = dict(w=w, b=b, ks=K // 32, src=src, dst=dst, res=res, relu=relu, act=None)
+                jobs.append(dict(entries=row, barrier=barrier and p0 == 0, store_hidden=False))
 
-    def __call__(self, net_in, hidden_out, out_reward, out_value, out_policy):
+        X, Y0, Y1 = 0, H, 2 * H
+        w1, b1 = _fold(dyn.fc1, dyn.bn1)          # [H, H + A]: state block | action block
+        w1s, w1a = w1[:, :H], w1[:, H:]           # the one-hot product = a row of w1a^T added in the epilogue
+        w2, b2 = _fold(dyn.fc2, dyn.bn2)
+        w3, b3 = _fold(dyn.fc3, dyn.bn3)
+        wh = torch.cat([_fold(rw[0], rw[1])[0], _fold(ac[0], ac[1])[0], _fold(va[0], va[1])[0]], 0)
+        bh = torch.cat([_fold(rw[0], rw[1])[1], _fold(ac[0], ac[1])[1], _fold(va[0], va[1])[1]], 0)
+        if full:   # NewDynamicNet + 3-layer heads (config/hanabi_control/model.py:93-125, 250-269)
+            Z = 3 * H
+            add_dense(w1s, b1, H, X, Y0, relu=True, barrier=False, act_w=w1a)
+            add_dense(w2, b2, H, Y0, Y1, relu=True)
+            add_dense(w3, b3, H, Y1, Y0, relu=True, res_off=X)
+            add_dense(wh, bh, H, Y0, Z, relu=True, store_hidden=True)
+            Tr, Ta, Tv = X, X + h, Y1                       # X and Y1 are dead: second head layers land there
+            heads2 = [(_fold(rw[3], rw[4]), Z, Tr), (_fold(ac[3].fc1, ac[3].bn1), Z + h, Ta), (_fold(va[3], va[4]), Z + 2 * h, Tv)]
+            first = True
+            for (w, b), src, dst in heads2:
+                add_dense(w, b, h, src, dst, relu=True, barrier=first)
+                first = False
+            R3, U, V3 = Y1 + h, Y0, Y0 + h                  # reward logits | actor hidden | value logits
+            wr3, br3 = _fold(rw[6])
+            wa3, ba3 = _fold(ac[3].fc2, ac[3].bn2)
+            wv3, bv3 = _fold(va[6])
+            add_dense(wr3, br3, h, Tr, R3, relu=False, barrier=True)
+            add_dense(wa3, ba3, h, Ta, U, relu=True, res_off=Z + h, barrier=False)
+            add_dense(wv3, bv3, h, Tv, V3, relu=False, barrier=False)
+            wp4, bp4 = _fold(ac[4])
+            add_dense(wp4, bp4, h, U, Z, relu=False, barrier=True)
+            off_r, off_v, off_p, width = R3, V3, Z, Z + 3 * h
+        else:      # DynamicNet + 2-layer heads (model.py:61-91, 138-149)
+            Z = Y1
+            add_dense(w1s, b1, H, X, Y0, relu=True, res_off=X, barrier=False, act_w=w1a)
+            add_dense(w2, b2, H, Y0, Y1, relu=True)
+            add_dense(w3, b3, H, Y1, Y0, relu=True)
+            add_dense(wh, bh, H, Y0, Z, relu=True, store_hidden=True)
+            assert V <= 64 and A <= 64 and 2 * h <= 256
+            kpad = 256                                      # K = h padded to 8 k-steps with zero weights
+            outs = [(_fold(rw[3]), Z, X), (_fold(ac[3]), Z + h, X + 64), (_fold(va[3]), Z + 2 * h, X + 128)]
+            add_group([(w, b, src, dst, None, False) for (w, b), src, dst in outs], kpad)
+            off_r, off_p, off_v, width = X, X + 64, X + 128, 3 * H
+        rs = width + ((8 - width) % 128)
+        # flatten: job table, per-wave weight streams, biases, action table
+        table = []
+        for job in jobs:
+            for wave, e in enumerate(job["entries"]):
+                flags = (MLP_BARRIER if job["barrier"] else 0) | (MLP_STORE_HIDDEN if job["store_hidden"] else 0)
+                if e is None:
+                    table.append(MlpJob(ks=0, src_off=0, dst_off=0, res_off=-1, bias_off=0, flags=flags))
+                    continue
+                assert e["ks"] % 8 == 0, "K must be a multiple of 256 (8 k-steps)"
+                streams[wave].append(_pack_fragments(e["w"], e["ks"]))
+                bias_off = 64 * len(bias_chunks)
+                bc = torch.zeros(64)
+                bc[:e["b"].shape[0]] = e["b"]
+                bias_chunks.append(bc)
+                if e["act"] is not None:
+                    act_rows.append((bias_off, e["act"]))
+                    flags |= MLP_ACTION_ROW
+                if e["relu"]:
+                    flags |= MLP_RELU
+                table.append(MlpJob(ks=e["ks"], src_off=e["src"], dst_off=e["dst"],
+                                    res_off=-1 if e["res"] is None else e["res"], bias_off=bias_off, flags=flags))
+        biases = torch.cat(bias_chunks)
+        act_table = torch.zeros(A + 1, biases.numel())      # row A stays zero: what jobs without an action row add
+        for off, blk in act_rows:                           # blk [n <= 64, A] = columns of the action block
+            act_table[:A, off:off + blk.shape[0]] = blk.t()
+        pad = torch.zeros(8 * 4 * 64 * 8)                   # 8 k-steps of zeros behind each stream (ring overrun)
+        offs, parts, cur = [], [], 0
+        for wave in range(4):
+            offs.append(cur)
+            st = torch.cat(streams[wave] + [pad])
+            parts.append(st)
+            cur += st.numel()
+        hdr = MlpHeader(n_jobs=len(jobs), row_stride=rs, hidden=H, state_off=X, hidden_off=Y0, off_reward=off_r,
+                        off_value=off_v, off_policy=off_p, support_size=V, support_min=-engine.support, num_actions=A,
+                        action_table_stride=biases.numel())
+        for wave in range(4):
+            hdr.wave_stream_off[wave] = offs[wave]
+        import ctypes as C
+        self.header = hdr
+        self.n_jobs = len(jobs)
+        buf = (MlpJob * len(table))(*table)
+        self.jobs = torch.frombuffer(bytearray(bytes(buf)), dtype=torch.uint8).to(self.device)
+        self.weights = torch.cat(parts).to(device=self.device, dtype=torch.bfloat16).contiguous()
+        self.biases = biases.to(device=self.device, dtype=torch.float32).contiguous()
+        self.act_table = act_table.to(device=self.device, dtype=torch.float32).contiguous()
+        self.row_stride = rs
+        self.weight_bytes_per_wg = int(sum(sum(x.numel() for x in s) for s in streams) * 2)
+
+    def lds_bytes(self, rows_per_wg):
+        return rows_per_wg * self.row_stride * 2
+
+    def rows_per_wg(self, N):
+        return 16 if N <= 16 * 256 or self.lds_bytes(32) > 160 * 1024 else 32
+
+    def __call__(self, pool, ix, actions, hidden_out, out_reward, out_value, out_policy, rows_per_wg=None):
+        """pool [S, N, H] (or a [N, H] matrix of states with ix=None)."""
         import ctypes as C
         from ._lib import check, lib
-        N = net_in.shape[0]
-        mt = 16 if N <= 16 * 256 or self.lds_bytes(32) > 160 * 1024 else 32
-        check(lib.hz_mlp_recurrent(C.byref(self.program), net_in.data_ptr(), net_in.stride(0), self.weights.data_ptr(),
-                                   self.biases.data_ptr(), hidden_out.data_ptr(), out_reward.data_ptr(),
-                                   out_value.data_ptr(), out_policy.data_ptr(), N, mt,
-                                   C.c_void_p(torch.cuda.current_stream().cuda_stream)), "hz_mlp_recurrent")
+        if pool.dim() == 3:
+            N, row_stride, plane_stride = pool.shape[1], pool.stride(1), pool.stride(0)
+        else:
+            N, row_stride, plane_stride = pool.shape[0], pool.stride(0), 0
+        mt = rows_per_wg or self.rows_per_wg(N)
+        check(lib.hz_mlp_recurrent(C.byref(self.header), self.jobs.data_ptr(), self.weights.data_ptr(),
+                                   self.biases.data_ptr(), self.act_table.data_ptr(), pool.data_ptr(), row_stride,
+                                   None if ix is None else ix.data_ptr(), plane_stride, actions.data_ptr(),
+                                   hidden_out.data_ptr(), out_reward.data_ptr(), out_value.data_ptr(),
+                                   out_policy.data_ptr(), N, mt, C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+              "hz_mlp_recurrent")
         return out_reward, out_value, out_policy

@@ -1,15 +1,21 @@
 /* hz_mlp.h -- C ABI of the fused recurrent-inference kernel of the search loop (libhanabizero_hip.so).
  *
  * What it replaces: one call of BaseMuZeroNet.recurrent_inference (/root/reference/core/model.py:74-84) as issued by
- * core/mcts.py:38-42 -- dynamics (config/hanabi_control/model.py:61-125) + reward head + prediction heads
- * (model.py:138-149 / 250-269) + inverse scalar transforms (core/config.py:204-232) + NaN clearing of the policy logits
- * (core/mcts.py:48-49) -- for all N trees at once.  In PyTorch this is a chain of ~10 small GEMMs that are bound by
- * launch latency and by re-reading activations; here ONE kernel keeps each tile of rows' activations in LDS across all
- * layers and streams the (eval-mode, BatchNorm-folded, bf16) weights once per workgroup through MFMA
- * (v_mfma_f32_16x16x32_bf16, fp32 accumulate), i.e. the matrix cores do exactly the net GEMMs and nothing else.
- * The layer sequence is data (a small "program" built by hanabizero_amd/model.py from the module), not code.
- * Numerics: same rounding points as the bf16 PyTorch path (bf16 activations between layers, fp32 accumulation and
- * bias/residual/ReLU epilogue); agreement with the fp32 reference nets is checked at the north-star tolerance.
+ * core/mcts.py:31-50 -- the per-tree gather of the parent hidden state (mcts.py:31-36), dynamics
+ * (config/hanabi_control/model.py:61-125, the one-hot action concat of :215-219 becomes a row of the first layer's
+ * action block added in its epilogue), reward head + prediction heads (model.py:138-149 / 250-269), inverse scalar
+ * transforms (core/config.py:204-232) and NaN clearing of the policy logits (core/mcts.py:48-49) -- for all N trees.
+ * In PyTorch this is a chain of ~10 small GEMMs bound by launch latency and activation reloads; here ONE kernel keeps
+ * each workgroup's rows' activations in LDS across all layers and streams the (eval-mode, BatchNorm-folded, bf16)
+ * weights through v_mfma_f32_16x16x32_bf16 (fp32 accumulate): the matrix cores do exactly the net GEMMs, nothing else.
+ *
+ * The layer chain is DATA: a list of "jobs".  Job j of wave w (4 waves per workgroup) computes 64 output columns
+ *     out[:, dst_off : dst_off+64] = act( in[:, src_off : src_off + 32*ks] @ W_jw^T + b_jw [+ action row] [+ residual] )
+ * over the workgroup's rows, reading and writing one LDS image row per batch row.  Every wave owns ONE contiguous weight
+ * stream (its jobs' fragments in execution order), prefetched 7 k-steps ahead in a register ring across job and layer
+ * boundaries.  hanabizero_amd/model.py::FusedRecurrent builds the job table and the streams from a module.
+ * Numerics: the rounding points of the bf16 PyTorch path (bf16 activations between layers, fp32 accumulation and
+ * epilogue); checked against the reference's fp32 nets at the north-star tolerance (tests/test_model.py).
  * Conventions as include/hz_tree.h.
  */
 #ifndef HZ_MLP_H
@@ -21,45 +27,50 @@
 extern "C" {
 #endif
 
-#define HZ_MLP_MAX_LAYERS 12
+enum {
+  HZ_MLP_RELU = 1,          /* ReLU in the epilogue */
+  HZ_MLP_ACTION_ROW = 2,    /* add action_table[action[row]][bias_off-relative column] (first dynamics layer) */
+  HZ_MLP_BARRIER = 4,       /* workgroup barrier before the job (layer boundary); same for the 4 waves of a job */
+  HZ_MLP_STORE_HIDDEN = 8   /* after that barrier copy LDS columns [hidden_off, hidden_off+hidden) to hidden_out */
+};
 
-/* One fused layer: for each of `groups` independent blocks g, out_g = act(in_g @ W_g^T + b_g [+ residual]).
- * All offsets are ELEMENT offsets inside one row of the workgroup's LDS activation image (bf16 elements). */
+/* One (job, wave) entry; all offsets are bf16-element columns of the LDS row image.  ks == 0: this wave idles. */
 typedef struct {
-  int32_t K;            /* reduction length per group, multiple of 32 */
-  int32_t nout;         /* total padded outputs over all groups, multiple of 64*groups/groups... = multiple of 64 */
-  int32_t groups;       /* 1 or 3 */
-  int32_t src_off;      /* source columns of group g start at src_off + g*src_gstride */
-  int32_t src_gstride;
-  int32_t dst_off;      /* destination columns start at dst_off (group g at dst_off + g*nout/groups) */
-  int32_t res_off;      /* residual columns (same indexing as dst) or -1 */
-  int32_t res_group;    /* group that gets the residual, -1 = every group */
-  int32_t relu_mask;    /* bit g set: ReLU on group g */
-  int32_t store_hidden; /* != 0: after this layer copy dst[0:hidden] of every row to hidden_out */
-  int64_t w_off;        /* element offset of this layer's packed weights */
-  int32_t b_off;        /* element offset of this layer's biases (fp32, indexed by padded output column) */
-  int32_t kind;         /* kernel instantiation id (tiles per wave / groups / k-steps), see hz_mlp.hip */
-} hz_mlp_layer_t;
+  int32_t ks;        /* k-steps of 32 inputs; multiple of 8 (pad K with zero weights) */
+  int32_t src_off;   /* first input column */
+  int32_t dst_off;   /* first of the 64 output columns */
+  int32_t res_off;   /* first residual column (added before the ReLU) or -1 */
+  int32_t bias_off;  /* index of the 64 fp32 biases; also the column of action_table rows when HZ_MLP_ACTION_ROW */
+  int32_t flags;
+  int32_t reserved0, reserved1;
+} hz_mlp_job_t;
 
 typedef struct {
-  int32_t n_layers;
-  int32_t row_stride;   /* LDS elements per row (multiple of 8, chosen to avoid bank conflicts) */
-  int32_t in_width;     /* columns of net_in copied to LDS columns [0, in_width) (state | one-hot | pad) */
-  int32_t hidden;       /* width of the hidden state */
+  int32_t n_jobs;
+  int32_t row_stride;  /* LDS elements per row, multiple of 8, = 8 (mod 128) for conflict-free ds_read_b128 */
+  int32_t hidden;      /* width of the hidden state (multiple of 8) */
+  int32_t state_off;   /* LDS column where the input hidden state is staged */
+  int32_t hidden_off;  /* LDS column of the next hidden state when HZ_MLP_STORE_HIDDEN fires */
   int32_t off_reward, off_value, off_policy; /* LDS columns of the final reward / value / policy logits */
   int32_t support_size, support_min, num_actions;
-  hz_mlp_layer_t layer[HZ_MLP_MAX_LAYERS];
-} hz_mlp_program_t;
+  int32_t action_table_stride;   /* fp32 elements per action row */
+  int64_t wave_stream_off[4];    /* element offset of each wave's weight stream inside `wstream` */
+} hz_mlp_header_t;
 
-/* net_in      [N][net_in_stride] bf16  rows = [state | one_hot(action) | 0] as written by hz_tree_traverse_gather
- * weights     packed bf16 (layout: hanabizero_amd/model.py::pack_mlp_weights), biases fp32
- * hidden_out  [N][hidden] bf16         next hidden state (its slot of the search's pool)
- * out_reward / out_value [N] f32       inverse_scalar_transform of the categorical heads (NaN -> 0)
- * out_policy  [N][num_actions] f32     policy logits, NaN -> 0
- * rows_per_wg: 16 or 32 (rows of one workgroup; N need not be a multiple) */
-int hz_mlp_recurrent(const hz_mlp_program_t* host_program, const void* net_in, int64_t net_in_stride,
-                     const void* weights, const float* biases, void* hidden_out, float* out_reward,
-                     float* out_value, float* out_policy, int num_rows, int rows_per_wg, void* stream);
+/* jobs        [n_jobs][4] hz_mlp_job_t (DEVICE)
+ * wstream     packed bf16 weight streams (DEVICE; each stream followed by >= 8 k-steps of zero padding)
+ * biases      fp32 (DEVICE), action_table [num_actions + 1][action_table_stride] fp32 (DEVICE; last row all zero)
+ * state rows  row i is read from state_src + plane_index[i]*plane_stride + i*row_stride (bf16 elements);
+ *             plane_index may be NULL (= 0).  With the search's pool [S][N][H]: plane_index = hz_tree_traverse's
+ *             out_ix, plane_stride = N*H, row_stride = H -> the gather of core/mcts.py:31-36 happens here.
+ * actions     [N] i32 (hz_tree_traverse's out_last_action)
+ * hidden_out  [N][hidden] bf16; out_reward / out_value [N] f32 (inverse scalar transform, NaN -> 0);
+ * out_policy  [N][num_actions] f32 (NaN -> 0).  rows_per_wg: 16 or 32. */
+int hz_mlp_recurrent(const hz_mlp_header_t* host_header, const hz_mlp_job_t* jobs, const void* wstream,
+                     const float* biases, const float* action_table, const void* state_src, int64_t row_stride,
+                     const int32_t* plane_index, int64_t plane_stride, const int32_t* actions, void* hidden_out,
+                     float* out_reward, float* out_value, float* out_policy, int num_rows, int rows_per_wg,
+                     void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""tools/mlp_profile.py -- diagnostic build of the fused MLP kernel (-DHZ_MLP_PROFILE): where a workgroup's cycles go.
+Builds scratch copies with hipcc, runs them on the GPU, prints per-phase shader cycles of workgroup 100 (s_memtime).
+Never quote the run time of this build: the stamps serialise what the real kernel overlaps."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    out = os.path.join(ROOT, "gpurun_out", "libmlp_prof.so")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    src = os.path.join(ROOT, "hanabizero_amd", "csrc")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+                           "-ffp-contract=off", "-w", "-DHZ_MLP_PROFILE", "-I" + src, "-I" + os.path.join(ROOT, "include"),
+                           "-o", out, os.path.join(src, "hz_mlp.hip"), os.path.join(src, "hz_tree.hip")])
+    import bench
+    from hanabizero_amd._lib import MlpHeader
+    from hanabizero_amd.config import make_config
+    game = sys.argv[1] if len(sys.argv) > 1 else "Hanabi-Full"
+    N = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+    cfg = make_config(game, simulations=50, stack=4)
+    eng = bench.build_engine(cfg, torch.bfloat16, "cuda")
+    f = eng.fused
+    hid = torch.rand(N, eng.H, device="cuda").to(torch.bfloat16)
+    act = torch.randint(0, eng.A, (N,), device="cuda", dtype=torch.int32)
+    h = torch.empty(N, eng.H, dtype=torch.bfloat16, device="cuda")
+    r, v, p = torch.empty(N, device="cuda"), torch.empty(N, device="cuda"), torch.empty(N, eng.A, device="cuda")
+    V, I, I64 = C.c_void_p, C.c_int, C.c_int64
+    lib = C.CDLL(out)
+    lib.hz_mlp_recurrent.argtypes = [C.POINTER(MlpHeader), V, V, V, V, V, I64, V, I64, V, V, V, V, V, I, I, V]
+    lib.hz_mlp_profile_read.argtypes = [V]
+    mt = f.rows_per_wg(N)
+    for _ in range(5):
+        rc = lib.hz_mlp_recurrent(C.byref(f.header), f.jobs.data_ptr(), f.weights.data_ptr(), f.biases.data_ptr(),
+                                  f.act_table.data_ptr(), hid.data_ptr(), eng.H, None, 0, act.data_ptr(), h.data_ptr(),
+                                  r.data_ptr(), v.data_ptr(), p.data_ptr(), N, mt, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0
+    torch.cuda.synchronize()
+    prof = np.zeros(32, np.uint64)
+    lib.hz_mlp_profile_read(prof.ctypes.data_as(V))
+    print("%s N=%d rows/WG=%d  (shader cycles of workgroup 100)" % (game, N, mt))
+    for w in range(4):
+        o = prof[w * 8:w * 8 + 8]
+        print("  wave %d: staging %6d | barriers %6d | job prologues %6d | k-loops %6d | epilogues %6d | final %6d | total %6d" % (
+            w, o[0], o[1], o[2], o[3], o[4], o[5], o[6]))
+
+
+if __name__ == "__main__":
+    main()
