@@ -68,7 +68,7 @@ def kernel_timing(actor, sample_sims=(4, 16, 28, 40), clones=8, replays=5):
     actor.pool[0].copy_(hidden0)
     net_in = torch.empty((N, eng.H + oh), dtype=eng.dtype, device=actor.device)
     fused = getattr(eng, "fused", None)
-    tot = {"k_traverse": 0.0, "k_backprop": 0.0, "k_mlp_recurrent": 0.0}
+    tot = {"k_traverse": 0.0, "k_backprop": 0.0, "k_mlp_recurrent": 0.0, "k_backprop_traverse": 0.0}
     rew = torch.empty(N, dtype=torch.float32, device=actor.device)
     val = torch.empty(N, dtype=torch.float32, device=actor.device)
     pol = torch.empty((N, actor.A), dtype=torch.float32, device=actor.device)
@@ -140,6 +140,19 @@ def kernel_timing(actor, sample_sims=(4, 16, 28, 40), clones=8, replays=5):
                 best = min(best, a.elapsed_time(b) * 1e-3 / clones)
                 del g2, snaps2
             tot["k_backprop"] += best
+            if fused is not None and sim < S - 2:
+                # the kernel the fused search actually launches: backup of this simulation + descent of the next
+                best = 1e9
+                for _ in range(replays):
+                    snaps2 = [c.clone() for c in snaps]
+                    torch.cuda.synchronize()
+                    g4 = timed_graph(lambda: [c.backprop_traverse_tensors(sim + 1, rew, val, pol) for c in snaps2])
+                    a, b = ev(), ev()
+                    a.record(); g4.replay(); b.record()
+                    torch.cuda.synchronize()
+                    best = min(best, a.elapsed_time(b) * 1e-3 / clones)
+                    del g4, snaps2
+                tot["k_backprop_traverse"] += best
             launches += 1
             del g, snaps, ins
         back(roots)
@@ -325,6 +338,8 @@ def main():
         if fused_on:  # plain backup: fp32 reward/value/policy in (SURVEY 8d formula)
             b_back = Nk * (4 * A + 16 * A + 16 + 8 + 16 * (dbar + 1) + 12 * sbar)
         kern = {"k_traverse": (b_trav, times["k_traverse"]), "k_backprop": (b_back, times["k_backprop"])}
+        if fused_on and times.get("k_backprop_traverse", 0) > 0:
+            kern["k_backprop_traverse"] = (b_trav + b_back, times["k_backprop_traverse"])
         other = {k: {"bound": "hbm", "avg_launch_us": t * 1e6, "bytes_per_launch": b, "GBps": b / t / 1e9, "frac": b / t / 1e9 / HBM_PEAK_GBS}
                  for k, (b, t) in kern.items()}
         flops = engine.flops_per_sample() * Nk

@@ -42,6 +42,7 @@ def _load():
         "hz_tree_prepare": [V, F, V, V, V, V, V],
         "hz_tree_traverse": [V, I, V, V, V, V],
         "hz_tree_traverse_gather": [V, I, V, V, V, V, I, I, V, I, I, V],
+        "hz_tree_backprop_traverse": [V, I, V, V, V, I, V, V, V, V],
         "hz_tree_backprop_nets": [V, I, V, I64, V, I64, I, I, V, I64, I, V, V, V],
         "hz_tree_backprop": [V, I, V, V, V, V],
         "hz_support_to_scalar": [V, I64, I, I, I, V, I, V],

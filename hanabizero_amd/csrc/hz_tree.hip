@@ -161,24 +161,32 @@ __global__ __launch_bounds__(256) void k_prepare(TreeView tv, float frac, const 
 // cmulti_traverse (cnode.cpp:407-441) with get_mean_q (:144-164), cselect_child (:346-374), cucb_score (:376-405)
 // and CMinMaxStats::normalize (cminimax.cpp:31-44).  Optionally fused with the hidden-state gather of
 // core/mcts.py:31-36.
-__global__ __launch_bounds__(256) void k_traverse(TreeView tv, int sim, int32_t* __restrict__ out_ix,
-                                                  int32_t* __restrict__ out_iy, int32_t* __restrict__ out_la,
-                                                  const uint8_t* __restrict__ pool, int row_bytes,
-                                                  uint8_t* __restrict__ net_in, int net_in_stride_bytes,
-                                                  int onehot_cols, int dtype) {
-  const int lane = threadIdx.x & 63;
-  const int tree = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (tree >= tv.N) return;
+struct TraverseOut {
+  int32_t* ix;
+  int32_t* iy;
+  int32_t* la;
+  const uint8_t* pool;
+  uint8_t* net_in;
+  int row_bytes, net_in_stride_bytes, onehot_cols, dtype;
+};
+
+// one descent of one tree by one wave; mn / mx / root_visit are passed in registers so that the fused
+// backup+descent kernel does not have to re-read what it has just computed
+__device__ __forceinline__ void traverse_body(const TreeView& tv, int tree, int lane, int sim, float mn, float mx,
+                                              int root_visit, const TraverseOut& to) {
   const int A = tv.A, S = tv.S;
   const bool on = lane < A;
   const float discount = tv.discount;
-  const float mn = tv.mm_min[tree], mx = tv.mm_max[tree];
   const float delta = mx - mn;
   const float4* rec = tv.rec + (size_t)tree * S * A;
   int32_t* path = tv.path + (size_t)tree * (S + 1);
+  // pb_c's first factor for every possible parent visit count, one per lane (S + 1 <= 64: no dependent table load
+  // on the critical path of a level); larger S falls back to the table in memory
+  const bool tab_in_regs = S < 64;
+  const float pbc_reg = (tab_in_regs && lane <= S) ? tv.pbc_tab[lane] : 0.0f;
 
   int e = 0;
-  int pvc = tv.root_visit[tree];
+  int pvc = root_visit;
   bool is_root = true;
   float parent_q = 0.0f;  // cnode.cpp:414 (0 whenever it is read, see oracle/ref_tree_harness.cpp)
   int depth = 0;
@@ -208,7 +216,7 @@ __global__ __launch_bounds__(256) void k_traverse(TreeView tv, int sim, int32_t*
     is_root = false;
     parent_q = mean_q;
     // cucb_score
-    float pb_c = tv.pbc_tab[pvc];                                  // logf((n+base+1)/base) + pb_c_init
+    float pb_c = tab_in_regs ? hz_readlane_f(pbc_reg, pvc) : tv.pbc_tab[pvc];  // logf((n+base+1)/base) + pb_c_init
     pb_c = pb_c * (sqrtf((float)pvc + 1.0f) / (float)(visit + 1));  // cnode.cpp:386
     const float prior_score = pb_c * prior;
     float vs = (visit == 0) ? mean_q : qsa;
@@ -248,24 +256,31 @@ __global__ __launch_bounds__(256) void k_traverse(TreeView tv, int sim, int32_t*
     pvc = child_visit;
   }
   if (lane == 0) {
-    out_ix[tree] = e;     // parent->hidden_state_index_x (entry index == hidden_state_index_x)
-    out_iy[tree] = tree;  // parent->hidden_state_index_y
-    out_la[tree] = action;
+    to.ix[tree] = e;     // parent->hidden_state_index_x (entry index == hidden_state_index_x)
+    to.iy[tree] = tree;  // parent->hidden_state_index_y
+    to.la[tree] = action;
     tv.path_len[tree] = depth + 1;
   }
-  if (pool != nullptr) {
+  if (to.pool != nullptr) {
     // hidden_states[i] = hidden_state_pool[ix][iy]  (core/mcts.py:31-32), 16 B per lane per trip
-    const uint8_t* src = pool + ((size_t)e * tv.N + tree) * (size_t)row_bytes;
-    uint8_t* dst = net_in + (size_t)tree * (size_t)net_in_stride_bytes;
-    for (int off = lane * 16; off < row_bytes; off += 64 * 16)
+    const uint8_t* src = to.pool + ((size_t)e * tv.N + tree) * (size_t)to.row_bytes;
+    uint8_t* dst = to.net_in + (size_t)tree * (size_t)to.net_in_stride_bytes;
+    for (int off = lane * 16; off < to.row_bytes; off += 64 * 16)
       *reinterpret_cast<uint4*>(dst + off) = *reinterpret_cast<const uint4*>(src + off);
     // action_one_hot of MuZeroNet.dynamics (config/hanabi_control/model.py:215-219), appended after the state
-    for (int c = lane; c < onehot_cols; c += 64) {
+    for (int c = lane; c < to.onehot_cols; c += 64) {
       const bool hot = (c == action);
-      if (dtype == HZ_F32) reinterpret_cast<float*>(dst + row_bytes)[c] = hot ? 1.0f : 0.0f;
-      else reinterpret_cast<uint16_t*>(dst + row_bytes)[c] = hot ? (dtype == HZ_BF16 ? 0x3f80u : 0x3c00u) : 0u;
+      if (to.dtype == HZ_F32) reinterpret_cast<float*>(dst + to.row_bytes)[c] = hot ? 1.0f : 0.0f;
+      else reinterpret_cast<uint16_t*>(dst + to.row_bytes)[c] = hot ? (to.dtype == HZ_BF16 ? 0x3f80u : 0x3c00u) : 0u;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void k_traverse(TreeView tv, int sim, TraverseOut to) {
+  const int lane = threadIdx.x & 63;
+  const int tree = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tree >= tv.N) return;
+  traverse_body(tv, tree, lane, sim, tv.mm_min[tree], tv.mm_max[tree], tv.root_visit[tree], to);
 }
 
 // ------------------------------------------------------------------------------------------ backprop
@@ -340,13 +355,10 @@ __device__ __forceinline__ float support_to_scalar(const void* row, int V, int s
   return out;
 }
 
+// one tree's expand + backup + min-max by one wave; returns the new (min, max, root visit count) in registers
 template <bool FUSED>
-__global__ __launch_bounds__(256) void k_backprop(TreeView tv, int e_new, NetOut no) {
-  extern __shared__ float lds_q[];  // [4 waves][S]
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int tree = blockIdx.x * 4 + wave;
-  if (tree >= tv.N) return;
+__device__ __forceinline__ void backprop_body(const TreeView& tv, int tree, int lane, int wave, float* lds_q, int e_new,
+                                              const NetOut& no, float& out_mn, float& out_mx, int& out_root_visit) {
   const int A = tv.A, S = tv.S;
   const bool on = lane < A;
   const float discount = tv.discount;
@@ -426,9 +438,11 @@ __global__ __launch_bounds__(256) void k_backprop(TreeView tv, int e_new, NetOut
       tv.qsa[(size_t)tree * S + child] = q;
     }
   }
-  if (lane == 0) {  // the root (search_path[0])
-    tv.root_vsum[tree] += G;
-    tv.root_visit[tree] += 1;
+  const float new_root_vsum = tv.root_vsum[tree] + G;  // the root (search_path[0])
+  out_root_visit = tv.root_visit[tree] + 1;
+  if (lane == 0) {
+    tv.root_vsum[tree] = new_root_vsum;
+    tv.root_visit[tree] = out_root_visit;
   }
   // min_max_stats.clear(); update_tree_q(root): every expanded non-root node contributes (cnode.cpp:332-334)
   float vmax = -INFINITY, vmin = INFINITY;
@@ -439,12 +453,41 @@ __global__ __launch_bounds__(256) void k_backprop(TreeView tv, int e_new, NetOut
       vmin = fminf(vmin, q);
     }
   }
-  vmax = hz_wave_max(vmax);
-  vmin = hz_wave_min(vmin);
+  out_mx = fmaxf(hz_wave_max(vmax), HZ_FLOAT_MIN);  // CMinMaxStats::update from the cleared state (cminimax.cpp:17-29)
+  out_mn = fminf(hz_wave_min(vmin), HZ_FLOAT_MAX);
   if (lane == 0) {
-    tv.mm_max[tree] = fmaxf(vmax, HZ_FLOAT_MIN);  // CMinMaxStats::update from the cleared state (cminimax.cpp:17-29)
-    tv.mm_min[tree] = fminf(vmin, HZ_FLOAT_MAX);
+    tv.mm_max[tree] = out_mx;
+    tv.mm_min[tree] = out_mn;
   }
+}
+
+template <bool FUSED>
+__global__ __launch_bounds__(256) void k_backprop(TreeView tv, int e_new, NetOut no) {
+  extern __shared__ float lds_q[];  // [4 waves][S]
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int tree = blockIdx.x * 4 + wave;
+  if (tree >= tv.N) return;
+  float mn, mx;
+  int rv;
+  backprop_body<FUSED>(tv, tree, lane, wave, lds_q, e_new, no, mn, mx, rv);
+}
+
+// multi_back_propagate of simulation k immediately followed by multi_traverse of simulation k+1 on the same tree by
+// the same wave: one launch instead of two per simulation, and the new min/max and root count never leave registers.
+// The descent reads child records this wave has just stored: a workgroup-scope fence orders them (same CU, same L1).
+template <bool FUSED>
+__global__ __launch_bounds__(256) void k_backprop_traverse(TreeView tv, int e_new, NetOut no, int sim_next, TraverseOut to) {
+  extern __shared__ float lds_q[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int tree = blockIdx.x * 4 + wave;
+  if (tree >= tv.N) return;
+  float mn, mx;
+  int rv;
+  backprop_body<FUSED>(tv, tree, lane, wave, lds_q, e_new, no, mn, mx, rv);
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  traverse_body(tv, tree, lane, sim_next, mn, mx, rv, to);
 }
 
 // ------------------------------------------------------------------------------------------ read-outs
@@ -586,8 +629,10 @@ static int launch_traverse(hz_tree_t* t, int sim, int32_t* ix, int32_t* iy, int3
   HZ_REQUIRE(t->next_entry >= 1, "hz_tree_traverse: call hz_tree_prepare first");
   HZ_REQUIRE(ix && iy && la, "hz_tree_traverse: output pointers must not be NULL");
   HZ_REQUIRE(sim >= 0 && sim < 65536, "hz_tree_traverse: sim out of range (%d)", sim);
-  hipLaunchKernelGGL(k_traverse, tree_grid(t), dim3(256), 0, (hipStream_t)stream, view(t), sim, ix, iy, la,
-                     (const uint8_t*)pool, row_bytes, (uint8_t*)net_in, stride_bytes, onehot_cols, dtype);
+  TraverseOut to;
+  to.ix = ix; to.iy = iy; to.la = la; to.pool = (const uint8_t*)pool; to.net_in = (uint8_t*)net_in;
+  to.row_bytes = row_bytes; to.net_in_stride_bytes = stride_bytes; to.onehot_cols = onehot_cols; to.dtype = dtype;
+  hipLaunchKernelGGL(k_traverse, tree_grid(t), dim3(256), 0, (hipStream_t)stream, view(t), sim, to);
   HZ_HIP(hipGetLastError());
   return 0;
 }
@@ -627,6 +672,31 @@ extern "C" int hz_tree_backprop(hz_tree_t* t, int hidden_state_index_x, const fl
   no.rewards = rewards; no.values = values; no.logits = logits;
   hipLaunchKernelGGL(k_backprop<false>, tree_grid(t), dim3(256), lds, (hipStream_t)stream, view(t),
                      hidden_state_index_x, no);
+  HZ_HIP(hipGetLastError());
+  t->next_entry = hidden_state_index_x + 1;
+  return 0;
+}
+
+extern "C" int hz_tree_backprop_traverse(hz_tree_t* t, int hidden_state_index_x, const float* rewards, const float* values,
+                                        const float* logits, int next_sim, int32_t* ix, int32_t* iy, int32_t* la,
+                                        void* stream) {
+  HZ_REQUIRE(t != nullptr, "hz_tree_backprop_traverse: NULL handle");
+  HZ_REQUIRE(rewards && values && logits && ix && iy && la, "hz_tree_backprop_traverse: pointers must not be NULL");
+  HZ_REQUIRE(hidden_state_index_x >= 1 && hidden_state_index_x < t->S,
+             "hz_tree_backprop_traverse: hidden_state_index_x=%d outside [1, num_simulations=%d)", hidden_state_index_x, t->S);
+  HZ_REQUIRE(hidden_state_index_x == t->next_entry,
+             "hz_tree_backprop_traverse: hidden_state_index_x must advance 1,2,3,... after prepare (expected %d, got %d)",
+             t->next_entry, hidden_state_index_x);
+  HZ_REQUIRE(next_sim >= 0 && next_sim < 65536, "hz_tree_backprop_traverse: next_sim out of range (%d)", next_sim);
+  NetOut no;
+  memset(&no, 0, sizeof(no));
+  no.rewards = rewards; no.values = values; no.logits = logits;
+  TraverseOut to;
+  memset(&to, 0, sizeof(to));
+  to.ix = ix; to.iy = iy; to.la = la;
+  const size_t lds = (size_t)4 * t->S * sizeof(float);
+  hipLaunchKernelGGL(k_backprop_traverse<false>, tree_grid(t), dim3(256), lds, (hipStream_t)stream, view(t),
+                     hidden_state_index_x, no, next_sim, to);
   HZ_HIP(hipGetLastError());
   t->next_entry = hidden_state_index_x + 1;
   return 0;

@@ -189,6 +189,16 @@ class Roots:
                                    _stream()), "hz_tree_backprop")
         self._keep_bp = (rw, vl, lg)
 
+    def backprop_traverse_tensors(self, hidden_state_index_x, rewards, values, policy_logits):
+        """multi_back_propagate of this simulation + multi_traverse of the next one in ONE launch (fp32 CUDA tensors).
+        Returns (ix, iy, last_action) of the next descent."""
+        check(lib.hz_tree_backprop_traverse(self._h, int(hidden_state_index_x), rewards.data_ptr(), values.data_ptr(),
+                                            policy_logits.data_ptr(), self._sim, self._ix.data_ptr(),
+                                            self._iy.data_ptr(), self._la.data_ptr(), _stream()),
+              "hz_tree_backprop_traverse")
+        self._sim += 1
+        return self._ix, self._iy, self._la
+
     def backprop_nets_tensors(self, hidden_state_index_x, reward_logits, value_logits, support_size, support_min,
                               policy_logits, out_rewards=None, out_values=None):
         """multi_back_propagate fed by raw head outputs (strided 2-D CUDA tensors of one dtype): include/hz_tree.h

@@ -42,10 +42,14 @@ class MCTS(object):
                 rew = torch.empty(num, dtype=torch.float32, device=roots.device)
                 val = torch.empty(num, dtype=torch.float32, device=roots.device)
                 pol = torch.empty((num, roots.action_num), dtype=torch.float32, device=roots.device)
+                # 2 launches per simulation: [MFMA recurrent inference] [backup of sim k + descent of sim k+1]
+                ix, _, la = roots.traverse_tensors()  # the MFMA kernel gathers pool[ix, tree] itself
                 for index_simulation in range(S - 1):
-                    ix, _, la = roots.traverse_tensors()  # the MFMA kernel gathers pool[ix, tree] itself
                     fused(pool, ix, la, pool[index_simulation + 1], rew, val, pol)
-                    roots.backprop_tensors(index_simulation + 1, rew, val, pol)
+                    if index_simulation < S - 2:
+                        ix, _, la = roots.backprop_traverse_tensors(index_simulation + 1, rew, val, pol)
+                    else:
+                        roots.backprop_tensors(index_simulation + 1, rew, val, pol)
                 return
             for index_simulation in range(S - 1):
                 # select + gather + one-hot (1 kernel) -> dynamics/prediction GEMMs -> scalar transform + NaN

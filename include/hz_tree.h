@@ -81,6 +81,12 @@ int hz_tree_traverse_gather(hz_tree_t* t, int sim, int32_t* out_ix, int32_t* out
 int hz_tree_backprop(hz_tree_t* t, int hidden_state_index_x, const float* rewards, const float* values,
                      const float* policy_logits, void* stream);
 
+/* hz_tree_backprop of simulation k fused with hz_tree_traverse of simulation k+1 (next_sim): one launch per
+ * simulation; outputs as hz_tree_traverse.  Results are identical to the two separate calls. */
+int hz_tree_backprop_traverse(hz_tree_t* t, int hidden_state_index_x, const float* rewards, const float* values,
+                              const float* policy_logits, int next_sim, int32_t* out_ix, int32_t* out_iy,
+                              int32_t* out_last_action, void* stream);
+
 /* hz_tree_backprop fed straight from the network heads (what core/mcts.py:44-50 + core/model.py:79-80 do on the
  * host between recurrent_inference and multi_back_propagate):
  *   reward_logits / value_logits [N] rows of `support_size` categorical logits over the integers

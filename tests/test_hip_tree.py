@@ -203,3 +203,40 @@ def test_add_relu_glue_kernel(dtype):
     dt = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[dtype]
     check(lib.hz_add_relu(y.data_ptr(), y.stride(0), res.data_ptr(), res.stride(0), 300, 512, dt, torch.cuda.current_stream().cuda_stream), "x")
     assert torch.equal(y, want)
+
+
+@pytest.mark.parametrize("N,A,S,zero", [(700, 20, 50, False), (300, 11, 50, True), (64, 48, 30, False), (40, 20, 90, False)])
+def test_fused_backprop_traverse_equals_separate_calls(N, A, S, zero):
+    """hz_tree_backprop_traverse (one launch per simulation) against hz_tree_backprop + hz_tree_traverse and the oracle."""
+    from hanabizero_amd import cytree as tree
+    from oracle.cport import OracleTree
+    c = _random_case(N, A, S, 51, zero)
+    a, b = tree.Roots(N, A, S, tie_seed=8), tree.Roots(N, A, S, tie_seed=8)
+    orc = OracleTree(N, A, S, seed=8)
+    for r in (a, b):
+        r.prepare(0.25, c["noises"], np.zeros(N), c["logits0"], c["legal"])
+        r.set_params(19652, 1.25, 0.999, 0.006)
+    orc.prepare(0.25, c["noises"], np.zeros(N, np.float32), c["logits0"], c["legal"])
+    dev = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    ia = [t.clone() for t in a.traverse_tensors()]
+    ib = [t.clone() for t in b.traverse_tensors()]
+    for sim in range(S - 1):
+        o = orc.traverse(sim, 19652, 1.25, 0.999)
+        for x, y, z in zip(ia, ib, o):
+            assert torch.equal(x, y) and (x.cpu().numpy() == z).all(), sim
+        assert torch.equal(a.path_len_tensor(), b.path_len_tensor())
+        rw, vl, lg = dev(c["rewards"][sim]), dev(c["values"][sim]), dev(c["logits"][sim])
+        orc.backprop(sim + 1, 0.999, c["rewards"][sim], c["values"][sim], c["logits"][sim])
+        if sim < S - 2:
+            a.backprop_tensors(sim + 1, rw, vl, lg)
+            ia = [t.clone() for t in a.traverse_tensors()]
+            ib = [t.clone() for t in b.backprop_traverse_tensors(sim + 1, rw, vl, lg)]
+        else:
+            a.backprop_tensors(sim + 1, rw, vl, lg)
+            b.backprop_tensors(sim + 1, rw, vl, lg)
+        for x, y in zip(a.minmax_tensors(), b.minmax_tensors()):
+            assert torch.equal(x, y)
+    assert torch.equal(a.distributions_tensor(), b.distributions_tensor())
+    assert (b.distributions_tensor().cpu().numpy() == orc.distributions()).all()
+    assert torch.equal(a.values_tensor(), b.values_tensor())
+    assert torch.equal(a.trajectories_tensor(), b.trajectories_tensor())
