@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhanabizero_hip.so")
+LIB_PATH = os.environ.get("HANABIZERO_HIP_LIB") or os.path.join(_HERE, "libhanabizero_hip.so")  # override: diagnostic builds (tools/)
 
 
 class HzError(RuntimeError):

@@ -45,6 +45,7 @@ struct hz_tree {
   float* qsa;
   int32_t* ref;
   int32_t* path;
+  float4* prec;  // [N][S+1] the child record read at each depth of the last descent (what the backup will update)
   int32_t* path_len;
   int32_t* root_visit;
   float* root_vsum;
@@ -64,6 +65,7 @@ struct TreeView {
   float* qsa;
   int32_t* ref;
   int32_t* path;
+  float4* prec;
   int32_t* path_len;
   int32_t* root_visit;
   float* root_vsum;
@@ -77,7 +79,7 @@ static TreeView view(const hz_tree* t) {
   TreeView v;
   v.N = t->N; v.A = t->A; v.S = t->S;
   v.discount = t->discount; v.delta = t->delta; v.seed = t->seed; v.id_base = t->id_base;
-  v.rec = t->rec; v.qsa = t->qsa; v.ref = t->ref; v.path = t->path; v.path_len = t->path_len;
+  v.rec = t->rec; v.qsa = t->qsa; v.ref = t->ref; v.path = t->path; v.prec = t->prec; v.path_len = t->path_len;
   v.root_visit = t->root_visit; v.root_vsum = t->root_vsum; v.mm_min = t->mm_min; v.mm_max = t->mm_max;
   v.best_action = t->best_action; v.pbc_tab = t->pbc_tab;
   return v;
@@ -172,18 +174,34 @@ struct TraverseOut {
 
 // one descent of one tree by one wave; mn / mx / root_visit are passed in registers so that the fused
 // backup+descent kernel does not have to re-read what it has just computed
+// Diagnostic build only (-DHZ_TREE_PROFILE, tools/tree_profile.py): s_memtime stamps of the wave that owns tree 400.
+#ifdef HZ_TREE_PROFILE
+__device__ unsigned long long hz_tree_prof[16];
+__device__ int hz_tree_prof_on;  // 1 while the wave of tree 400 runs the fused kernel (k_backprop shares the body)
+extern "C" int hz_tree_profile_read(unsigned long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(hz_tree_prof), sizeof(hz_tree_prof));
+}
+#define TP(i) do { if (tree == 400 && lane == 0 && hz_tree_prof_on) hz_tree_prof[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define TP_ON(v) do { if (tree == 400 && lane == 0) hz_tree_prof_on = (v); } while (0)
+#else
+#define TP(i) do { } while (0)
+#define TP_ON(v) do { } while (0)
+#endif
+
 __device__ __forceinline__ void traverse_body(const TreeView& tv, int tree, int lane, int sim, float mn, float mx,
-                                              int root_visit, const TraverseOut& to) {
+                                              int root_visit, const TraverseOut& to, bool have_root, float4 root_row) {
   const int A = tv.A, S = tv.S;
   const bool on = lane < A;
   const float discount = tv.discount;
   const float delta = mx - mn;
   const float4* rec = tv.rec + (size_t)tree * S * A;
   int32_t* path = tv.path + (size_t)tree * (S + 1);
+  float4* prec = tv.prec + (size_t)tree * (S + 1);
   // pb_c's first factor for every possible parent visit count, one per lane (S + 1 <= 64: no dependent table load
   // on the critical path of a level); larger S falls back to the table in memory
   const bool tab_in_regs = S < 64;
   const float pbc_reg = (tab_in_regs && lane <= S) ? tv.pbc_tab[lane] : 0.0f;
+  const float sqrt_reg = sqrtf((float)lane + 1.0f);  // sqrt(parent visits + 1), same trick
 
   int e = 0;
   int pvc = root_visit;
@@ -193,7 +211,8 @@ __device__ __forceinline__ void traverse_body(const TreeView& tv, int tree, int 
   int action = 0;
   while (true) {
     float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (on) r = rec[(size_t)e * A + lane];
+    if (depth == 0 && have_root) r = root_row;  // already in registers (fused backup + descent)
+    else if (on) r = rec[(size_t)e * A + lane];
     const uint32_t w = __float_as_uint(r.w);
     const int visit = (int)(w >> 16);
     const int child = (int)(w & 0xffffu) - 1;
@@ -210,20 +229,17 @@ __device__ __forceinline__ void traverse_body(const TreeView& tv, int tree, int 
       vm &= vm - 1;
       total += hz_readlane_f(qsa, a);
     }
-    float mean_q;
-    if (is_root && nvis > 0) mean_q = total / (float)nvis;
-    else mean_q = (parent_q + total) / (float)(nvis + 1);
+    const bool root_mean = is_root && nvis > 0;  // cnode.cpp:228-236: the root leaves its own q out
+    const float mean_q = (root_mean ? total : parent_q + total) / (float)(root_mean ? nvis : nvis + 1);
     is_root = false;
     parent_q = mean_q;
     // cucb_score
     float pb_c = tab_in_regs ? hz_readlane_f(pbc_reg, pvc) : tv.pbc_tab[pvc];  // logf((n+base+1)/base) + pb_c_init
-    pb_c = pb_c * (sqrtf((float)pvc + 1.0f) / (float)(visit + 1));  // cnode.cpp:386
+    const float sq = tab_in_regs ? hz_readlane_f(sqrt_reg, pvc) : sqrtf((float)pvc + 1.0f);
+    pb_c = pb_c * (sq / (float)(visit + 1));  // cnode.cpp:386
     const float prior_score = pb_c * prior;
     float vs = (visit == 0) ? mean_q : qsa;
-    if (delta > 0.0f) {  // CMinMaxStats::normalize
-      if (delta < tv.delta) vs = (vs - mn) / tv.delta;
-      else vs = (vs - mn) / delta;
-    }
+    if (delta > 0.0f) vs = (vs - mn) / (delta < tv.delta ? tv.delta : delta);  // CMinMaxStats::normalize
     if (vs < 0.0f) vs = 0.0f;
     if (vs > 1.0f) vs = 1.0f;
     const float score = prior_score + vs;
@@ -238,9 +254,11 @@ __device__ __forceinline__ void traverse_body(const TreeView& tv, int tree, int 
       uint64_t cand = __ballot(valid && score >= thr);
       cand &= ~((1ull << first) - 1ull);
       const uint32_t cnt = (uint32_t)__popcll((unsigned long long)cand);
-      const uint32_t rnd = hz_tiebreak_rand(tv.seed, tv.id_base + (uint32_t)tree, (uint32_t)sim, (uint32_t)depth);
-      uint32_t k = rnd % cnt;  // rand() % max_index_lst.size()  (cnode.cpp:369)
-      while (k--) cand &= cand - 1;
+      if (cnt > 1) {  // (x % 1 == 0: the draw only matters when there is a tie)
+        const uint32_t rnd = hz_tiebreak_rand(tv.seed, tv.id_base + (uint32_t)tree, (uint32_t)sim, (uint32_t)depth);
+        uint32_t k = rnd % cnt;  // rand() % max_index_lst.size()  (cnode.cpp:369)
+        while (k--) cand &= cand - 1;
+      }
       action = __ffsll((unsigned long long)cand) - 1;
     }
     action = hz_uniform(action);
@@ -248,9 +266,11 @@ __device__ __forceinline__ void traverse_body(const TreeView& tv, int tree, int 
       tv.best_action[(size_t)tree * S + e] = (int8_t)action;  // node->best_action (cnode.cpp:426)
       path[depth] = (e << 8) | action;
     }
+    if (lane == action) prec[depth] = r;  // the record the coming backup updates: saves it a dependent load
     const int child_e = hz_readlane_i(child, action);
     const int child_visit = hz_readlane_i(visit, action);
     ++depth;
+    TP(5 + (depth < 7 ? depth : 7));
     if (child_e < 0 || depth >= S) break;  // leaf reached (second clause: defensive bound, never true)
     e = child_e;
     pvc = child_visit;
@@ -278,9 +298,10 @@ __device__ __forceinline__ void traverse_body(const TreeView& tv, int tree, int 
 
 __global__ __launch_bounds__(256) void k_traverse(TreeView tv, int sim, TraverseOut to) {
   const int lane = threadIdx.x & 63;
-  const int tree = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int tree = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: SALU addressing
   if (tree >= tv.N) return;
-  traverse_body(tv, tree, lane, sim, tv.mm_min[tree], tv.mm_max[tree], tv.root_visit[tree], to);
+  traverse_body(tv, tree, lane, sim, tv.mm_min[tree], tv.mm_max[tree], tv.root_visit[tree], to, false,
+                make_float4(0.f, 0.f, 0.f, 0.f));
 }
 
 // ------------------------------------------------------------------------------------------ backprop
@@ -358,7 +379,8 @@ __device__ __forceinline__ float support_to_scalar(const void* row, int V, int s
 // one tree's expand + backup + min-max by one wave; returns the new (min, max, root visit count) in registers
 template <bool FUSED>
 __device__ __forceinline__ void backprop_body(const TreeView& tv, int tree, int lane, int wave, float* lds_q, int e_new,
-                                              const NetOut& no, float& out_mn, float& out_mx, int& out_root_visit) {
+                                              const NetOut& no, float& out_mn, float& out_mx, int& out_root_visit,
+                                              float4& out_first_rec, int& out_first_action) {
   const int A = tv.A, S = tv.S;
   const bool on = lane < A;
   const float discount = tv.discount;
@@ -366,6 +388,16 @@ __device__ __forceinline__ void backprop_body(const TreeView& tv, int tree, int 
   const int32_t* path = tv.path + (size_t)tree * (S + 1);
   float* lq = lds_q + wave * S;
 
+  // the path's first 64 edges and the records the descent read there, fetched before path_len is known (the buffers
+  // hold S+1 slots per tree, so this never leaves them): every load of this function is issued up front, independent
+  int pr0 = 0;
+  float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (lane <= S) {
+    pr0 = path[lane];
+    r0 = tv.prec[(size_t)tree * (S + 1) + lane];  // == rec[entry][action] as the descent read it
+  }
+  const float old_root_vsum = tv.root_vsum[tree];
+  const int old_root_visit = tv.root_visit[tree];
   // stage the cached q of entries 1..e_new-1 in LDS (coalesced), entry e_new is produced below
   for (int e = 1 + lane; e < e_new; e += 64) lq[e] = tv.qsa[(size_t)tree * S + e];
 
@@ -381,6 +413,7 @@ __device__ __forceinline__ void backprop_body(const TreeView& tv, int tree, int 
   }
   const uint64_t all = (A >= 64) ? ~0ull : ((1ull << A) - 1ull);
   const float prior = expand_prior(logit, all, lane, A);
+  TP(1);
   if (on) {
     float4 r;
     r.x = prior; r.y = 0.0f; r.z = 0.0f; r.w = __uint_as_float(pack_vc(0, -1));
@@ -403,14 +436,18 @@ __device__ __forceinline__ void backprop_body(const TreeView& tv, int tree, int 
     G = no.values[tree];
     leaf_reward = no.rewards[tree];
   }
+  TP(2);
+  int pr = 0;
+  float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int base = ((npairs - 1) >> 6) << 6; base >= 0; base -= 64) {
     const int k = base + lane;
     const bool act = k < npairs;
-    int pr = 0;
-    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (act) {
+    if (base == 0) {
+      pr = pr0;
+      r = r0;
+    } else if (act) {
       pr = path[k];
-      r = rec[(size_t)(pr >> 8) * A + (pr & 255)];
+      r = tv.prec[(size_t)tree * (S + 1) + k];
     }
     uint32_t w = __float_as_uint(r.w);
     int visit = (int)(w >> 16);
@@ -438,8 +475,15 @@ __device__ __forceinline__ void backprop_body(const TreeView& tv, int tree, int 
       tv.qsa[(size_t)tree * S + child] = q;
     }
   }
-  const float new_root_vsum = tv.root_vsum[tree] + G;  // the root (search_path[0])
-  out_root_visit = tv.root_visit[tree] + 1;
+  TP(3);
+  // the loop ends with the chunk that holds path edge 0 in lane 0: the root's child record as just stored
+  out_first_rec.x = hz_readlane_f(r.x, 0);
+  out_first_rec.y = hz_readlane_f(r.y, 0);
+  out_first_rec.z = hz_readlane_f(r.z, 0);
+  out_first_rec.w = hz_readlane_f(r.w, 0);
+  out_first_action = __builtin_amdgcn_readfirstlane(pr) & 255;
+  const float new_root_vsum = old_root_vsum + G;  // the root (search_path[0])
+  out_root_visit = old_root_visit + 1;
   if (lane == 0) {
     tv.root_vsum[tree] = new_root_vsum;
     tv.root_visit[tree] = out_root_visit;
@@ -459,18 +503,21 @@ __device__ __forceinline__ void backprop_body(const TreeView& tv, int tree, int 
     tv.mm_max[tree] = out_mx;
     tv.mm_min[tree] = out_mn;
   }
+  TP(4);
 }
 
 template <bool FUSED>
 __global__ __launch_bounds__(256) void k_backprop(TreeView tv, int e_new, NetOut no) {
   extern __shared__ float lds_q[];  // [4 waves][S]
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: SALU addressing and hashing
   const int tree = blockIdx.x * 4 + wave;
   if (tree >= tv.N) return;
+  TP_ON(0);
   float mn, mx;
-  int rv;
-  backprop_body<FUSED>(tv, tree, lane, wave, lds_q, e_new, no, mn, mx, rv);
+  int rv, a0;
+  float4 first;
+  backprop_body<FUSED>(tv, tree, lane, wave, lds_q, e_new, no, mn, mx, rv, first, a0);
 }
 
 // multi_back_propagate of simulation k immediately followed by multi_traverse of simulation k+1 on the same tree by
@@ -480,14 +527,23 @@ template <bool FUSED>
 __global__ __launch_bounds__(256) void k_backprop_traverse(TreeView tv, int e_new, NetOut no, int sim_next, TraverseOut to) {
   extern __shared__ float lds_q[];
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: SALU addressing and hashing
   const int tree = blockIdx.x * 4 + wave;
   if (tree >= tv.N) return;
+  // the root's child row of the coming descent: fetched now, the one record the backup changes is patched in registers
+  TP_ON(1);
+  TP(0);
+  float4 root_row = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (lane < tv.A) root_row = tv.rec[(size_t)tree * tv.S * tv.A + lane];
   float mn, mx;
-  int rv;
-  backprop_body<FUSED>(tv, tree, lane, wave, lds_q, e_new, no, mn, mx, rv);
+  int rv, a0;
+  float4 first;
+  backprop_body<FUSED>(tv, tree, lane, wave, lds_q, e_new, no, mn, mx, rv, first, a0);
+  if (lane == a0) root_row = first;
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-  traverse_body(tv, tree, lane, sim_next, mn, mx, rv, to);
+  TP(5);
+  traverse_body(tv, tree, lane, sim_next, mn, mx, rv, to, true, root_row);
+  TP(13);
 }
 
 // ------------------------------------------------------------------------------------------ read-outs
@@ -558,6 +614,7 @@ extern "C" int hz_tree_create(hz_tree_t** out, int N, int A, int S, int device) 
   rc |= dev_alloc(&t->qsa, (size_t)N * S, &t->bytes);
   rc |= dev_alloc(&t->ref, (size_t)N * S, &t->bytes);
   rc |= dev_alloc(&t->path, (size_t)N * (S + 1), &t->bytes);
+  rc |= dev_alloc(&t->prec, (size_t)N * (S + 1), &t->bytes);
   rc |= dev_alloc(&t->path_len, (size_t)N, &t->bytes);
   rc |= dev_alloc(&t->root_visit, (size_t)N, &t->bytes);
   rc |= dev_alloc(&t->root_vsum, (size_t)N, &t->bytes);
@@ -578,7 +635,7 @@ extern "C" int hz_tree_create(hz_tree_t** out, int N, int A, int S, int device) 
 extern "C" int hz_tree_destroy(hz_tree_t* t) {
   if (!t) return 0;
   (void)hipSetDevice(t->device);
-  void* bufs[] = {t->rec, t->qsa, t->ref, t->path, t->path_len, t->root_visit, t->root_vsum, t->mm_min,
+  void* bufs[] = {t->rec, t->qsa, t->ref, t->path, t->prec, t->path_len, t->root_visit, t->root_vsum, t->mm_min,
                   t->mm_max, t->best_action, t->pbc_tab};
   for (void* b : bufs) (void)hipFree(b);
   delete t;
@@ -786,7 +843,7 @@ extern "C" int hz_tree_copy(hz_tree_t* dst, const hz_tree_t* src, void* stream) 
   const size_t N = src->N, A = src->A, S = src->S;
   hipStream_t st = (hipStream_t)stream;
 #define HZ_CP(f, n) HZ_HIP(hipMemcpyAsync(dst->f, src->f, (n) * sizeof(*src->f), hipMemcpyDeviceToDevice, st))
-  HZ_CP(rec, N * S * A); HZ_CP(qsa, N * S); HZ_CP(ref, N * S); HZ_CP(path, N * (S + 1)); HZ_CP(path_len, N);
+  HZ_CP(rec, N * S * A); HZ_CP(qsa, N * S); HZ_CP(ref, N * S); HZ_CP(path, N * (S + 1)); HZ_CP(prec, N * (S + 1)); HZ_CP(path_len, N);
   HZ_CP(root_visit, N); HZ_CP(root_vsum, N); HZ_CP(mm_min, N); HZ_CP(mm_max, N); HZ_CP(best_action, N * S);
   HZ_CP(pbc_tab, S + 1);
 #undef HZ_CP
