@@ -25,6 +25,14 @@ class MlpHeader(C.Structure):  # include/hz_mlp.h hz_mlp_header_t
                 ("action_table_stride", C.c_int32), ("wave_stream_off", C.c_int64 * 4)]
 
 
+class ActorBufs(C.Structure):  # include/hz_selfplay.h hz_actor_bufs_t
+    _fields_ = [(n, C.c_int32) for n in ("num_envs", "num_actions", "packed_words", "max_moves", "outbox_games",
+                                         "env_id_base")] + \
+               [(n, C.c_void_p) for n in ("action", "reward", "value", "visits", "legal", "obs", "traj_len", "ent_sum",
+                                          "meta", "out_action", "out_reward", "out_value", "out_visits", "out_legal",
+                                          "out_obs", "out_meta", "out_count", "slot", "illegal_steps")]
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
@@ -49,6 +57,7 @@ def _load():
         "hz_tree_copy": [V, V, V],
         "hz_tree_get_distributions": [V, V, V],
         "hz_tree_get_values": [V, V, V],
+        "hz_tree_get_root_stats": [V, V, V, V],
         "hz_tree_get_trajectories": [V, V, I, V],
         "hz_tree_get_minmax": [V, V, V, V],
         "hz_tree_get_root_priors": [V, V, V],
@@ -64,6 +73,10 @@ def _load():
         # include/hz_selfplay.h
         "hz_select_action": [I, I, V, V, V, F, I, V, V, V],
         "hz_rows_scatter": [V, V, I64, V, I, V],
+        "hz_actor_record_search": [C.POINTER(ActorBufs), V, V, V, V, F, I, V, V, V],
+        "hz_actor_record_step": [C.POINTER(ActorBufs), V, V, V, V, V, V, V],
+        "hz_actor_flush": [C.POINTER(ActorBufs), V],
+        "hz_actor_begin_move": [C.POINTER(ActorBufs), V, V, V, V, I64, V, I64, I, I64, V],
         # include/hz_mlp.h
         "hz_mlp_recurrent": [C.POINTER(MlpHeader), V, V, V, V, V, I64, V, I64, V, V, V, V, V, I, I, V],
         # include/hz_netglue.h
@@ -100,4 +113,4 @@ def declared_symbols():
             continue
         text = open(os.path.join(inc, h)).read()
         names += re.findall(r"\b(hz_[a-z0-9_]+)\s*\(", text)
-    return sorted(set(n for n in names if n not in ("hz_tiebreak_rand",)))
+    return sorted(set(n for n in names if n != "hz_tiebreak_rand" and not n.endswith("_t")))  # types are not symbols

@@ -5,13 +5,9 @@
 #include "hz_selfplay.h"
 
 // one lane per env; rows are short (A <= 64) and the kernel is launch-bound, not bandwidth-bound
-__global__ __launch_bounds__(256) void k_select_action(int N, int A, int32_t* __restrict__ counts,
-                                                       const uint8_t* __restrict__ legal,
-                                                       const double* __restrict__ uniform, float temperature,
-                                                       int deterministic, int32_t* __restrict__ out_action,
-                                                       double* __restrict__ out_entropy) {
-  const int env = blockIdx.x * blockDim.x + threadIdx.x;
-  if (env >= N) return;
+__device__ __forceinline__ int select_action_env(int env, int A, int32_t* __restrict__ counts,
+                                                 const uint8_t* __restrict__ legal, const double* __restrict__ uniform,
+                                                 float temperature, int deterministic, double* ent_out) {
   int32_t* c = counts + (size_t)env * A;
   const uint8_t* lg = legal + (size_t)env * A;
   // utils.py:282-284: zero the counts of illegal actions
@@ -32,9 +28,8 @@ __global__ __launch_bounds__(256) void k_select_action(int N, int A, int32_t* __
     total += unit_t ? (double)v : pow((double)v, inv_t);  // utils.py:286-287 (Python sum, left to right)
   }
   if (!(total > 0.0)) {
-    out_action[env] = -1;
-    if (out_entropy) out_entropy[env] = 0.0;
-    return;
+    *ent_out = 0.0;
+    return -1;
   }
   // np.random.choice: cdf = cumsum(p); cdf /= cdf[-1]; idx = searchsorted(cdf, u, side='right')
   double last = 0.0;
@@ -55,7 +50,7 @@ __global__ __launch_bounds__(256) void k_select_action(int N, int A, int32_t* __
     }
     action = idx < A ? idx : A - 1;
   }
-  if (out_entropy) {
+  {
     // scipy.stats.entropy(pk, base=2): pk /= sum(pk); sum(-pk*log(pk)) / log(2)
     double psum = 0.0;
     for (int a = 0; a < A; ++a) psum += (unit_t ? (double)c[a] : pow((double)c[a], inv_t)) / total;
@@ -63,9 +58,21 @@ __global__ __launch_bounds__(256) void k_select_action(int N, int A, int32_t* __
       const double pk = ((unit_t ? (double)c[a] : pow((double)c[a], inv_t)) / total) / psum;
       if (pk > 0.0) ent -= pk * log(pk);
     }
-    out_entropy[env] = ent / log(2.0);
+    *ent_out = ent / log(2.0);
   }
-  out_action[env] = action;
+  return action;
+}
+
+__global__ __launch_bounds__(256) void k_select_action(int N, int A, int32_t* __restrict__ counts,
+                                                       const uint8_t* __restrict__ legal,
+                                                       const double* __restrict__ uniform, float temperature,
+                                                       int deterministic, int32_t* __restrict__ out_action,
+                                                       double* __restrict__ out_entropy) {
+  const int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= N) return;
+  double ent;
+  out_action[env] = select_action_env(env, A, counts, legal, uniform, temperature, deterministic, &ent);
+  if (out_entropy) out_entropy[env] = ent;
 }
 
 extern "C" int hz_select_action(int N, int A, int32_t* counts, const uint8_t* legal, const double* uniform,
@@ -108,6 +115,224 @@ extern "C" int hz_rows_scatter(const void* src, void* dst, int64_t row_bytes, co
   HZ_REQUIRE(num_rows > 0 && row_bytes > 0, "hz_rows_scatter: num_rows and row_bytes must be positive");
   hipLaunchKernelGGL(k_rows_scatter, dim3((num_rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)src,
                      (uint8_t*)dst, (long long)row_bytes, slot, num_rows);
+  HZ_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---- the actor's per-move bookkeeping (include/hz_selfplay.h) ---------------------------------------------------
+__device__ __forceinline__ int actor_t(const hz_actor_bufs_t& b, int env) {
+  const long long len = b.traj_len[env];  // a Hanabi game cannot outlast max_moves; the clamp keeps indices in range
+  return (int)(len < (long long)(b.max_moves - 1) ? len : (long long)(b.max_moves - 1));
+}
+
+__global__ __launch_bounds__(256) void k_actor_record_search(hz_actor_bufs_t b, int32_t* __restrict__ counts,
+                                                             const float* __restrict__ root_values,
+                                                             const uint8_t* __restrict__ legal,
+                                                             const double* __restrict__ uniform, float temperature,
+                                                             int deterministic, int32_t* __restrict__ out_action,
+                                                             double* __restrict__ out_entropy) {
+  const int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= b.num_envs) return;
+  const int A = b.num_actions, T = b.max_moves;
+  double ent;
+  const int action = select_action_env(env, A, counts, legal, uniform, temperature, deterministic, &ent);
+  out_action[env] = action;
+  if (out_entropy) out_entropy[env] = ent;
+  const int t = actor_t(b, env);
+  b.action[(size_t)env * T + t] = (int8_t)action;
+  b.value[(size_t)env * T + t] = root_values[env];
+  int16_t* vrow = b.visits + ((size_t)env * T + t) * A;
+  const int32_t* c = counts + (size_t)env * A;
+  for (int a = 0; a < A; ++a) vrow[a] = (int16_t)c[a];  // masked counts (store_search_stats gets the mutated list)
+  b.ent_sum[env] += ent;
+}
+
+__global__ __launch_bounds__(256) void k_actor_record_step(hz_actor_bufs_t b, const int32_t* __restrict__ reward,
+                                                           const int32_t* __restrict__ score,
+                                                           const int32_t* __restrict__ status,
+                                                           const int32_t* __restrict__ packed,
+                                                           const uint8_t* __restrict__ legal_next) {
+  const int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= b.num_envs) return;
+  const int A = b.num_actions, T = b.max_moves, W = b.packed_words;
+  const int t = actor_t(b, env);
+  b.reward[(size_t)env * T + t] = (int8_t)reward[env];
+  if (status[env] != 0) atomicAdd(reinterpret_cast<unsigned long long*>(b.illegal_steps), 1ull);
+  int32_t* orow = b.obs + ((size_t)env * (T + 1) + t + 1) * W;
+  for (int w = 0; w < W; ++w) orow[w] = packed[(size_t)env * W + w];
+  uint8_t* lrow = b.legal + ((size_t)env * (T + 1) + t + 1) * A;
+  for (int a = 0; a < A; ++a) lrow[a] = legal_next[(size_t)env * A + a];
+  int32_t* m = b.meta + (size_t)env * 4;
+  m[0] = t + 1;
+  m[1] = score[env];
+  m[2] = env + b.env_id_base;
+  m[3] = (int32_t)__float_as_uint((float)b.ent_sum[env]);
+}
+
+// outbox slots of the games that just ended, in env order: one workgroup, ballot prefix counts
+__global__ __launch_bounds__(1024) void k_actor_slots(hz_actor_bufs_t b, const uint8_t* __restrict__ done) {
+  __shared__ int wave_total[16];
+  __shared__ long long base_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) base_s = *b.out_count;
+  __syncthreads();
+  long long base = base_s;
+  for (int start = 0; start < b.num_envs; start += 1024) {
+    const int env = start + tid;
+    const bool d = env < b.num_envs && done[env] != 0;
+    const uint64_t m = __ballot(d);
+    const int before = __popcll((unsigned long long)(m & ((1ull << lane) - 1ull)));
+    if (lane == 0) wave_total[wave] = __popcll((unsigned long long)m);
+    __syncthreads();
+    int off = 0, tot = 0;
+    for (int w = 0; w < 16; ++w) {
+      const int c = wave_total[w];
+      if (w < wave) off += c;
+      tot += c;
+    }
+    if (env < b.num_envs) b.slot[env] = d ? (int32_t)((base + off + before) % (long long)b.outbox_games) : -1;
+    base += tot;
+    __syncthreads();
+  }
+  if (tid == 0) *b.out_count = base;
+}
+
+struct FlushTable {
+  const uint8_t* src[7];
+  uint8_t* dst[7];
+  long long row_bytes[7];
+};
+
+__device__ __forceinline__ void copy_row(const uint8_t* a, uint8_t* b, long long n, int lane) {
+  if ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)n) & 15) == 0) {
+    for (long long off = (long long)lane * 16; off < n; off += 64 * 16)
+      *reinterpret_cast<uint4*>(b + off) = *reinterpret_cast<const uint4*>(a + off);
+  } else if ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)n) & 3) == 0) {
+    for (long long off = (long long)lane * 4; off < n; off += 64 * 4)
+      *reinterpret_cast<uint32_t*>(b + off) = *reinterpret_cast<const uint32_t*>(a + off);
+  } else {
+    for (long long off = lane; off < n; off += 64) b[off] = a[off];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_actor_flush(FlushTable ft, const int32_t* __restrict__ slot, int n) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const int s = slot[row];
+  if (s < 0) return;
+  const int k = blockIdx.y;
+  const long long rb = ft.row_bytes[k];
+  copy_row(ft.src[k] + (size_t)row * (size_t)rb, ft.dst[k] + (size_t)s * (size_t)rb, rb, lane);
+}
+
+// one wave per env: trajectory heads and the model's input window
+template <typename U>
+__global__ __launch_bounds__(256) void k_actor_begin_move(hz_actor_bufs_t b, const uint8_t* __restrict__ done,
+                                                          const int32_t* __restrict__ packed,
+                                                          const uint8_t* __restrict__ legal,
+                                                          const uint8_t* __restrict__ newest, long long newest_row_bytes,
+                                                          uint8_t* __restrict__ stack_buf, long long stack_row_bytes,
+                                                          int stack, long long obs_bytes) {
+  const int lane = threadIdx.x & 63;
+  const int env = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (env >= b.num_envs) return;
+  const int A = b.num_actions, T = b.max_moves, W = b.packed_words;
+  const bool d = done[env] != 0;
+  const int t0 = d ? 0 : actor_t(b, env) + 1;
+  if (lane == 0) {
+    b.traj_len[env] = t0;
+    if (d) b.ent_sum[env] = 0.0;
+  }
+  int32_t* orow = b.obs + ((size_t)env * (T + 1) + t0) * W;
+  for (int w = lane; w < W; w += 64) orow[w] = packed[(size_t)env * W + w];
+  uint8_t* lrow = b.legal + ((size_t)env * (T + 1) + t0) * A;
+  for (int a = lane; a < A; a += 64) lrow[a] = legal[(size_t)env * A + a];
+  // input window in units of U: slot k <- slot k+1 (running game) or <- newest (new game); last slot <- newest
+  const long long n = obs_bytes / (long long)sizeof(U);
+  U* row = reinterpret_cast<U*>(stack_buf + (size_t)env * (size_t)stack_row_bytes);
+  const U* nw = reinterpret_cast<const U*>(newest + (size_t)env * (size_t)newest_row_bytes);
+  for (int k = 0; k < stack; ++k) {
+    const U* src = (d || k == stack - 1) ? nw : row + (size_t)(k + 1) * n;
+    U* dst = row + (size_t)k * n;
+    for (long long i = lane; i < n; i += 64) dst[i] = src[i];
+  }
+}
+
+#define HZ_ACTOR_CHECK(b, who)                                                                                      \
+  HZ_REQUIRE((b) != nullptr, who ": bufs is NULL");                                                                 \
+  HZ_REQUIRE((b)->num_envs > 0 && (b)->num_actions > 0 && (b)->num_actions <= 64 && (b)->packed_words > 0 &&        \
+                 (b)->max_moves > 0 && (b)->outbox_games > 0,                                                       \
+             who ": bad sizes N=%d A=%d W=%d T=%d cap=%d", (b)->num_envs, (b)->num_actions, (b)->packed_words,      \
+             (b)->max_moves, (b)->outbox_games);                                                                    \
+  HZ_REQUIRE((b)->action && (b)->reward && (b)->value && (b)->visits && (b)->legal && (b)->obs && (b)->traj_len &&  \
+                 (b)->ent_sum && (b)->meta && (b)->out_count && (b)->slot && (b)->illegal_steps,                    \
+             who ": NULL buffer in bufs")
+
+extern "C" int hz_actor_record_search(const hz_actor_bufs_t* bufs, int32_t* counts, const float* root_values,
+                                      const uint8_t* legal, const double* uniform, float temperature, int deterministic,
+                                      int32_t* out_action, double* out_entropy, void* stream) {
+  HZ_ACTOR_CHECK(bufs, "hz_actor_record_search");
+  HZ_REQUIRE(counts && root_values && legal && out_action, "hz_actor_record_search: NULL argument");
+  HZ_REQUIRE(deterministic || uniform, "hz_actor_record_search: uniform samples required when sampling");
+  HZ_REQUIRE(temperature > 0.0f, "hz_actor_record_search: temperature must be > 0");
+  hipLaunchKernelGGL(k_actor_record_search, dim3((bufs->num_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, *bufs,
+                     counts, root_values, legal, uniform, temperature, deterministic, out_action, out_entropy);
+  HZ_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int hz_actor_record_step(const hz_actor_bufs_t* bufs, const int32_t* reward, const uint8_t* done,
+                                    const int32_t* score, const int32_t* status, const int32_t* packed,
+                                    const uint8_t* legal_next, void* stream) {
+  HZ_ACTOR_CHECK(bufs, "hz_actor_record_step");
+  HZ_REQUIRE(reward && done && score && status && packed && legal_next, "hz_actor_record_step: NULL argument");
+  hipLaunchKernelGGL(k_actor_record_step, dim3((bufs->num_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, *bufs,
+                     reward, score, status, packed, legal_next);
+  hipLaunchKernelGGL(k_actor_slots, dim3(1), dim3(1024), 0, (hipStream_t)stream, *bufs, done);
+  HZ_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int hz_actor_flush(const hz_actor_bufs_t* bufs, void* stream) {
+  HZ_ACTOR_CHECK(bufs, "hz_actor_flush");
+  HZ_REQUIRE(bufs->out_action && bufs->out_reward && bufs->out_value && bufs->out_visits && bufs->out_legal &&
+                 bufs->out_obs && bufs->out_meta, "hz_actor_flush: NULL outbox buffer");
+  const long long T = bufs->max_moves, A = bufs->num_actions, W = bufs->packed_words;
+  FlushTable ft;
+  const void* src[7] = {bufs->action, bufs->reward, bufs->value, bufs->visits, bufs->legal, bufs->obs, bufs->meta};
+  void* dst[7] = {bufs->out_action, bufs->out_reward, bufs->out_value, bufs->out_visits, bufs->out_legal, bufs->out_obs,
+                  bufs->out_meta};
+  const long long rb[7] = {T, T, 4 * T, 2 * T * A, (T + 1) * A, 4 * (T + 1) * W, 16};
+  for (int k = 0; k < 7; ++k) {
+    ft.src[k] = (const uint8_t*)src[k];
+    ft.dst[k] = (uint8_t*)dst[k];
+    ft.row_bytes[k] = rb[k];
+  }
+  hipLaunchKernelGGL(k_actor_flush, dim3((bufs->num_envs + 3) / 4, 7), dim3(256), 0, (hipStream_t)stream, ft, bufs->slot,
+                     bufs->num_envs);
+  HZ_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int hz_actor_begin_move(const hz_actor_bufs_t* bufs, const uint8_t* done, const int32_t* packed,
+                                   const uint8_t* legal, const void* newest, int64_t newest_row_bytes, void* stack_buf,
+                                   int64_t stack_row_bytes, int stack, int64_t obs_bytes, void* stream) {
+  HZ_ACTOR_CHECK(bufs, "hz_actor_begin_move");
+  HZ_REQUIRE(done && packed && legal && newest && stack_buf, "hz_actor_begin_move: NULL argument");
+  HZ_REQUIRE(stack >= 1 && obs_bytes > 0 && stack_row_bytes >= (int64_t)stack * obs_bytes && newest_row_bytes >= obs_bytes,
+             "hz_actor_begin_move: bad window geometry (stack=%d obs_bytes=%lld)", stack, (long long)obs_bytes);
+  const dim3 grid((bufs->num_envs + 3) / 4), block(256);
+  const uintptr_t al = (uintptr_t)newest | (uintptr_t)stack_buf | (uintptr_t)newest_row_bytes | (uintptr_t)stack_row_bytes |
+                       (uintptr_t)obs_bytes;
+  if ((al & 3) == 0)
+    hipLaunchKernelGGL(k_actor_begin_move<uint32_t>, grid, block, 0, (hipStream_t)stream, *bufs, done, packed, legal,
+                       (const uint8_t*)newest, (long long)newest_row_bytes, (uint8_t*)stack_buf,
+                       (long long)stack_row_bytes, stack, (long long)obs_bytes);
+  else
+    hipLaunchKernelGGL(k_actor_begin_move<uint8_t>, grid, block, 0, (hipStream_t)stream, *bufs, done, packed, legal,
+                       (const uint8_t*)newest, (long long)newest_row_bytes, (uint8_t*)stack_buf,
+                       (long long)stack_row_bytes, stack, (long long)obs_bytes);
   HZ_HIP(hipGetLastError());
   return 0;
 }

@@ -555,6 +555,18 @@ __global__ void k_distributions(TreeView tv, int32_t* __restrict__ out) {  // cn
   out[i] = (int)(__float_as_uint(r.w) >> 16);
 }
 
+__global__ void k_root_stats(TreeView tv, int32_t* __restrict__ counts, float* __restrict__ values) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // get_distributions + get_values in one launch
+  if (i >= tv.N * tv.A) return;
+  const int tree = i / tv.A, a = i % tv.A;
+  const float4 r = tv.rec[((size_t)tree * tv.S) * tv.A + a];
+  counts[i] = (int)(__float_as_uint(r.w) >> 16);
+  if (a == 0) {
+    const int v = tv.root_visit[tree];
+    values[tree] = v == 0 ? 0.0f : tv.root_vsum[tree] / (float)v;
+  }
+}
+
 __global__ void k_values(TreeView tv, float* __restrict__ out) {  // cnode.cpp:286-292
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= tv.N) return;
@@ -792,6 +804,14 @@ extern "C" int hz_tree_get_distributions(hz_tree_t* t, int32_t* out, void* strea
   HZ_REQUIRE(t && out, "hz_tree_get_distributions: NULL argument");
   const int n = t->N * t->A;
   hipLaunchKernelGGL(k_distributions, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, view(t), out);
+  HZ_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int hz_tree_get_root_stats(hz_tree_t* t, int32_t* counts, float* values, void* stream) {
+  HZ_REQUIRE(t && counts && values, "hz_tree_get_root_stats: NULL argument");
+  const int n = t->N * t->A;
+  hipLaunchKernelGGL(k_root_stats, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, view(t), counts, values);
   HZ_HIP(hipGetLastError());
   return 0;
 }

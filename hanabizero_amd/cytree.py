@@ -219,6 +219,16 @@ class Roots:
         check(lib.hz_tree_get_distributions(self._h, out.data_ptr(), _stream()), "hz_tree_get_distributions")
         return out
 
+    def root_stats_tensors(self, counts=None, values=None):
+        """(visit counts [N, A] i32, root values [N] f32) in one launch; optional caller-owned outputs."""
+        if counts is None:
+            counts = torch.empty((self.root_num, self.action_num), dtype=torch.int32, device=self.device)
+        if values is None:
+            values = torch.empty(self.root_num, dtype=torch.float32, device=self.device)
+        check(lib.hz_tree_get_root_stats(self._h, counts.data_ptr(), values.data_ptr(), _stream()),
+              "hz_tree_get_root_stats")
+        return counts, values
+
     def values_tensor(self):
         out = torch.empty(self.root_num, dtype=torch.float32, device=self.device)
         check(lib.hz_tree_get_values(self._h, out.data_ptr(), _stream()), "hz_tree_get_values")

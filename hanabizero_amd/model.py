@@ -291,15 +291,17 @@ class InferenceEngine:
 
     # -- pieces ---------------------------------------------------------------------------------------
     def _scalar(self, logits):
+        if logits.is_cuda and logits.stride(1) == 1:  # one HIP kernel instead of ~25 elementwise launches
+            return self.support_to_scalar(logits)
         return inverse_scalar_transform(logits, -self.support, self.support).reshape(-1)
 
     def _representation(self, x):
         r = self.rep
         if self.full:  # Linear-BN-ReLU, NewResMLP(1024), Linear-BN-ReLU, NewResMLP(512)
             x = r[0](x, relu=True)
-            x = torch.relu_(r[2](r[1](x, relu=True)) + x)
+            x = self._add_relu(r[2](r[1](x, relu=True)), x)
             x = r[3](x, relu=True)
-            return torch.relu_(r[5](r[4](x, relu=True)) + x)
+            return self._add_relu(r[5](r[4](x, relu=True)), x)
         x = r[0](x, relu=True)  # Linear-BN-ReLU, ResMLP(512)
         y = torch.relu_(r[1](x) + x)
         return r[2](y, relu=True)
@@ -320,7 +322,7 @@ class InferenceEngine:
         za, zv = z[:, off:off + h], z[:, off + h:off + 2 * h]
         if self.full:
             a = self.ac_tail
-            ya = torch.relu_(a[1](a[0](za, relu=True)) + za)
+            ya = self._add_relu(a[1](a[0](za, relu=True)), za)
             logits = a[2](ya)
             value = self.va_tail[1](self.va_tail[0](zv, relu=True))
             reward = self.rw_tail[1](self.rw_tail[0](z[:, :h], relu=True)) if with_reward else None

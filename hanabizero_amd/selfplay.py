@@ -28,9 +28,15 @@ import numpy as np
 import torch
 
 from . import cytree
-from ._lib import check, lib
+from ._lib import ActorBufs, check, lib
 from .hanabi_env import HanabiVecEnv
 from .mcts import MCTS
+
+
+def done_dtype_ok(env):
+    """the bookkeeping kernels read the env's step outputs as (i32 reward, u8 done, i32 score, i32 status)"""
+    return (env.reward.dtype, env.done.dtype, env.score.dtype, env.status.dtype) == \
+        (torch.int32, torch.uint8, torch.int32, torch.int32)
 
 
 def _stream():
@@ -86,6 +92,21 @@ class SelfPlayActor:
         self.tmp_packed = z(N, W, dtype=torch.int32)
         self.tmp_legal = z(N, A, dtype=torch.uint8)
         self.illegal_steps = z(1, dtype=torch.int64)
+        self.counts = z(N, A, dtype=torch.int32)
+        self.values = z(N, dtype=torch.float32)
+        assert done_dtype_ok(self.env)
+        tr, o = self.traj, self.out
+        self.bufs = ActorBufs(num_envs=N, num_actions=A, packed_words=W, max_moves=T, outbox_games=self.cap,
+                              env_id_base=self.env_id_base, action=tr["action"].data_ptr(),
+                              reward=tr["reward"].data_ptr(), value=tr["value"].data_ptr(),
+                              visits=tr["visits"].data_ptr(), legal=tr["legal"].data_ptr(), obs=tr["obs"].data_ptr(),
+                              traj_len=self.traj_len.data_ptr(), ent_sum=self.ent_sum.data_ptr(),
+                              meta=self.meta.data_ptr(), out_action=o["action"].data_ptr(),
+                              out_reward=o["reward"].data_ptr(), out_value=o["value"].data_ptr(),
+                              out_visits=o["visits"].data_ptr(), out_legal=o["legal"].data_ptr(),
+                              out_obs=o["obs"].data_ptr(), out_meta=self.out_meta.data_ptr(),
+                              out_count=self.out_count.data_ptr(), slot=self.slot.data_ptr(),
+                              illegal_steps=self.illegal_steps.data_ptr())
         self.total_moves = 0
         self._drained = 0
         self._graph = None
@@ -114,56 +135,30 @@ class SelfPlayActor:
 
     # -- one lock-step, device only --------------------------------------------------------------------------
     def _step_body(self):
-        cfg, N, ar = self.cfg, self.N, self.ar
+        cfg, N = self.cfg, self.N
         value0, logits0, hidden0 = self.engine.initial(self.stack_buf.view(N, self.stack * self.D))
         self.roots.prepare(cfg.root_exploration_fraction, self.noise, self.zeros_n, logits0, self.legal)
         self.mcts.run_multi(self.roots, self.engine, hidden0, pool=self.pool)
-        counts = self.roots.distributions_tensor()
-        values = self.roots.values_tensor()
-        check(lib.hz_select_action(N, self.A, counts.data_ptr(), self.legal.data_ptr(), self.uniform.data_ptr(),
-                                   float(cfg.visit_softmax_temperature_fn(0, 0)), int(self.deterministic),
-                                   self.action.data_ptr(), self.entropy.data_ptr(), _stream()), "hz_select_action")
-        t = self.traj_len.clamp(max=self.T - 1)  # a Hanabi game cannot outlast max_moves; clamp keeps indices in range
-        tr = self.traj
-        tr["action"][ar, t] = self.action.to(torch.int8)
-        tr["visits"][ar, t] = counts.to(torch.int16)  # masked counts (store_search_stats gets the mutated list)
-        tr["value"][ar, t] = values
+        self.roots.root_stats_tensors(self.counts, self.values)
+        b, st = C.byref(self.bufs), _stream()
+        check(lib.hz_actor_record_search(b, self.counts.data_ptr(), self.values.data_ptr(), self.legal.data_ptr(),
+                                         self.uniform.data_ptr(), float(cfg.visit_softmax_temperature_fn(0, 0)),
+                                         int(self.deterministic), self.action.data_ptr(), self.entropy.data_ptr(), st),
+              "hz_actor_record_search")
         reward, done, score, status = self.env.step(self.action)
-        self.illegal_steps += (status != 0).sum()
-        tr["reward"][ar, t] = reward.to(torch.int8)
-        self.ent_sum += self.entropy
-        t1 = t + 1
         # the observation after the move (terminal one included: selfplay_worker.py:308)
         self.env.observe_packed(self.tmp_packed, self.tmp_legal)
-        tr["obs"][ar, t1] = self.tmp_packed
-        tr["legal"][ar, t1] = self.tmp_legal
-        # finished games -> outbox ring
-        db = done.bool()
-        self.meta[:, 0] = t1.to(torch.int32)
-        self.meta[:, 1] = score
-        self.meta[:, 2] = (ar + self.env_id_base).to(torch.int32)
-        self.meta[:, 3] = self.ent_sum.to(torch.float32).view(torch.int32)
-        csum = torch.cumsum(done.to(torch.int64), 0)
-        self.slot.copy_(torch.where(db, (self.out_count + csum - 1) % self.cap, torch.full_like(csum, -1)).to(torch.int32))
-        self.out_count += csum[-1:]
-        for k, v in tr.items():
-            o = self.out[k]
-            check(lib.hz_rows_scatter(v.data_ptr(), o.data_ptr(), v[0].numel() * v.element_size(), self.slot.data_ptr(), N,
-                                      _stream()), "hz_rows_scatter")
-        check(lib.hz_rows_scatter(self.meta.data_ptr(), self.out_meta.data_ptr(), 16, self.slot.data_ptr(), N, _stream()),
-              "hz_rows_scatter")
+        check(lib.hz_actor_record_step(b, reward.data_ptr(), done.data_ptr(), score.data_ptr(), status.data_ptr(),
+                                       self.tmp_packed.data_ptr(), self.tmp_legal.data_ptr(), st), "hz_actor_record_step")
+        check(lib.hz_actor_flush(b, st), "hz_actor_flush")  # finished games -> outbox ring
         # reset finished envs (selfplay_worker.py:230-240) and take everybody's current observation
         self.env.reset(done)
-        self.traj_len.copy_(torch.where(db, torch.zeros_like(t1), t1))
-        self.ent_sum.masked_fill_(db, 0.0)
         self.env.observe(out=self.newest, packed=self.tmp_packed, legal=self.legal)
-        t0 = self.traj_len
-        tr["obs"][ar, t0] = self.tmp_packed
-        tr["legal"][ar, t0] = self.legal
-        # stack window: shift for running games, refill for new ones (selfplay_worker.py:237, 326-327)
-        shifted = torch.cat((self.stack_buf[:, 1:], self.newest[:, None, :]), dim=1)
-        filled = self.newest[:, None, :].expand(-1, self.stack, -1)
-        self.stack_buf.copy_(torch.where(db[:, None, None], filled, shifted))
+        # trajectory heads + stack window: shift for running games, refill for new ones (selfplay_worker.py:237, 326-327)
+        es = self.newest.element_size()
+        check(lib.hz_actor_begin_move(b, done.data_ptr(), self.tmp_packed.data_ptr(), self.legal.data_ptr(),
+                                      self.newest.data_ptr(), self.newest.stride(0) * es, self.stack_buf.data_ptr(),
+                                      self.stack_buf.stride(0) * es, self.stack, self.D * es, st), "hz_actor_begin_move")
 
     def _capture(self):
         self.roots.set_params(self.cfg.pb_c_base, self.cfg.pb_c_init, self.cfg.discount, self.cfg.value_delta_max)

@@ -31,6 +31,59 @@ int hz_select_action(int num_envs, int num_actions, int32_t* counts, const uint8
  * rows are 16-byte aligned (4 B or 1 B per lane otherwise). */
 int hz_rows_scatter(const void* src, void* dst, int64_t row_bytes, const int32_t* slot, int num_rows, void* stream);
 
+/* ---- the actor's per-move bookkeeping (core/selfplay_worker.py:286-347 + GameHistory.append/store_search_stats,
+ * core/game.py:170-200), one launch per phase instead of a Python loop over envs.  The caller owns every buffer. */
+typedef struct {
+  int32_t num_envs, num_actions, packed_words, max_moves; /* N, A, W, T */
+  int32_t outbox_games;                                   /* capacity of the outbox ring */
+  int32_t env_id_base;                                    /* global id of env 0 */
+  /* trajectories under construction, one row per env */
+  int8_t* action;    /* [N][T]      GameHistory.actions */
+  int8_t* reward;    /* [N][T]      GameHistory.rewards */
+  float* value;      /* [N][T]      GameHistory.root_values */
+  int16_t* visits;   /* [N][T][A]   masked root child visit counts (child_visits before normalisation) */
+  uint8_t* legal;    /* [N][T+1][A] legal-move masks */
+  int32_t* obs;      /* [N][T+1][W] bit-packed observations */
+  int64_t* traj_len; /* [N] moves recorded so far */
+  double* ent_sum;   /* [N] running sum of the visit entropies (selfplay_worker.py:303) */
+  int32_t* meta;     /* [N][4] len, final score, global env id, float bits of ent_sum */
+  /* outbox ring of finished games: the same six arrays with `outbox_games` rows, and their meta rows */
+  int8_t* out_action;
+  int8_t* out_reward;
+  float* out_value;
+  int16_t* out_visits;
+  uint8_t* out_legal;
+  int32_t* out_obs;
+  int32_t* out_meta;
+  int64_t* out_count;     /* [1] games finished so far */
+  int32_t* slot;          /* [N] scratch: outbox row of the env's finished game, -1 while it runs */
+  int64_t* illegal_steps; /* [1] env steps that reported an illegal move (stays 0) */
+} hz_actor_bufs_t;
+
+/* After the search: hz_select_action on (counts, legal, uniform) as above, then at t = min(traj_len, T-1):
+ * action[t] = a, visits[t] = masked counts, value[t] = root_values; ent_sum += entropy.  counts IN/OUT as above. */
+int hz_actor_record_search(const hz_actor_bufs_t* bufs, int32_t* counts, const float* root_values,
+                           const uint8_t* legal, const double* uniform, float temperature, int deterministic,
+                           int32_t* out_action, double* out_entropy /* [N] or NULL */, void* stream);
+
+/* After hz_env_step + hz_env_observe(packed, legal_next): reward[t] = reward, obs[t+1] / legal[t+1] = the observation
+ * after the move (the terminal one included, selfplay_worker.py:308), meta row, illegal_steps += #(status != 0);
+ * then the outbox slots of the games that just ended, in env order: slot = (out_count + rank among done) % capacity,
+ * out_count += #done. */
+int hz_actor_record_step(const hz_actor_bufs_t* bufs, const int32_t* reward, const uint8_t* done, const int32_t* score,
+                         const int32_t* status, const int32_t* packed, const uint8_t* legal_next, void* stream);
+
+/* hz_rows_scatter of all six trajectory arrays and the meta rows by bufs->slot, one launch. */
+int hz_actor_flush(const hz_actor_bufs_t* bufs, void* stream);
+
+/* After hz_env_reset(done) + hz_env_observe(newest, packed, legal): traj_len = done ? 0 : t+1, ent_sum = done ? 0 : ent_sum,
+ * obs[traj_len] / legal[traj_len] = the current observation, and the model's input window (selfplay_worker.py:237,
+ * 326-327): rows of `stack` observations of obs_bytes each; running games shift by one and append `newest`,
+ * new games are filled with `newest`.  stack_row_bytes / newest_row_bytes: row strides. */
+int hz_actor_begin_move(const hz_actor_bufs_t* bufs, const uint8_t* done, const int32_t* packed, const uint8_t* legal,
+                        const void* newest, int64_t newest_row_bytes, void* stack_buf, int64_t stack_row_bytes, int stack,
+                        int64_t obs_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

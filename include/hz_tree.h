@@ -110,6 +110,8 @@ int hz_support_to_scalar(const void* logits, int64_t stride, int support_size, i
 /* Roots.get_distributions / get_values / get_trajectories (cytree.pyx:53-60 -> cnode.cpp:266-292). */
 int hz_tree_get_distributions(hz_tree_t* t, int32_t* out /* [N][A] */, void* stream);
 int hz_tree_get_values(hz_tree_t* t, float* out /* [N] */, void* stream);
+/* both of the above in one launch (what the actor reads after every search, selfplay_worker.py:286-288) */
+int hz_tree_get_root_stats(hz_tree_t* t, int32_t* counts /* [N][A] */, float* values /* [N] */, void* stream);
 int hz_tree_get_trajectories(hz_tree_t* t, int32_t* out /* [N][max_len], -1 padded */, int max_len, void* stream);
 
 /* Introspection used by the parity tests (the reference exposes these only inside C++). */
