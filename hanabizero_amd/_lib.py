@@ -30,7 +30,8 @@ class ActorBufs(C.Structure):  # include/hz_selfplay.h hz_actor_bufs_t
                                          "env_id_base")] + \
                [(n, C.c_void_p) for n in ("action", "reward", "value", "visits", "legal", "obs", "traj_len", "ent_sum",
                                           "meta", "out_action", "out_reward", "out_value", "out_visits", "out_legal",
-                                          "out_obs", "out_meta", "out_count", "slot", "illegal_steps")]
+                                          "out_obs", "out_meta", "out_count", "slot", "finished", "num_finished",
+                                          "illegal_steps")]
 
 
 def _load():
@@ -73,6 +74,7 @@ def _load():
         # include/hz_selfplay.h
         "hz_select_action": [I, I, V, V, V, F, I, V, V, V],
         "hz_rows_scatter": [V, V, I64, V, I, V],
+        "hz_actor_draw": [U64, I64, V, I, I, C.c_double, V, V, V],
         "hz_actor_record_search": [C.POINTER(ActorBufs), V, V, V, V, F, I, V, V, V],
         "hz_actor_record_step": [C.POINTER(ActorBufs), V, V, V, V, V, V, V],
         "hz_actor_flush": [C.POINTER(ActorBufs), V],

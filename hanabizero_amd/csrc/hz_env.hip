@@ -99,28 +99,20 @@ __device__ __forceinline__ int player_to_deal(const EnvCfg& g, const St& s) {  /
 }
 
 // ---- std::mt19937 in HBM (libstdc++ bits/random.tcc) ---------------------------------------------------
-__device__ void mt_twist(uint32_t* mt, int N, int env) {
-  const uint32_t upper = 0x80000000u, lower = 0x7fffffffu, a = 0x9908b0dfu;
-#define MT(k) mt[(size_t)(k) * N + env]
-  for (int k = 0; k < 624 - 397; ++k) {
-    const uint32_t y = (MT(k) & upper) | (MT(k + 1) & lower);
-    MT(k) = MT(k + 397) ^ (y >> 1) ^ ((y & 1u) ? a : 0u);
-  }
-  for (int k = 624 - 397; k < 623; ++k) {
-    const uint32_t y = (MT(k) & upper) | (MT(k + 1) & lower);
-    MT(k) = MT(k - 227) ^ (y >> 1) ^ ((y & 1u) ? a : 0u);
-  }
-  const uint32_t y = (MT(623) & upper) | (MT(0) & lower);
-  MT(623) = MT(396) ^ (y >> 1) ^ ((y & 1u) ? a : 0u);
-}
-
+// The generator regenerates its 624 words in one block ("twist", random.tcc:395-431) whenever the position reaches
+// 624, then tempers word after word.  Here the same recurrence runs one word per draw, in place: word i of the new
+// block needs the OLD words i and i+1 and word i+397 -- old for i < 227, already regenerated (i - 227) afterwards;
+// word 623 uses the new word 0 -- which is exactly what is in the array when draw i arrives.  Same output stream,
+// no 624-step stall of one lane while 63 wait (position 624 after seeding == position 0 of the first block).
 __device__ uint32_t mt_next(uint32_t* mt, int N, int env) {
+#define MT(k) mt[(size_t)(k) * N + env]
   uint32_t idx = MT(624);
-  if (idx >= 624u) {
-    mt_twist(mt, N, env);
-    idx = 0;
-  }
-  uint32_t z = MT(idx);
+  if (idx >= 624u) idx = 0;
+  const uint32_t i1 = idx + 1 == 624u ? 0u : idx + 1;
+  const uint32_t im = idx < 227u ? idx + 397u : idx - 227u;
+  const uint32_t y = (MT(idx) & 0x80000000u) | (MT(i1) & 0x7fffffffu);
+  uint32_t z = MT(im) ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+  MT(idx) = z;
   MT(624) = idx + 1;
 #undef MT
   z ^= (z >> 11);

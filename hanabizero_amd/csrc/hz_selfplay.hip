@@ -191,10 +191,14 @@ __global__ __launch_bounds__(1024) void k_actor_slots(hz_actor_bufs_t b, const u
       tot += c;
     }
     if (env < b.num_envs) b.slot[env] = d ? (int32_t)((base + off + before) % (long long)b.outbox_games) : -1;
+    if (d) b.finished[(int)(base - base_s) + off + before] = env;
     base += tot;
     __syncthreads();
   }
-  if (tid == 0) *b.out_count = base;
+  if (tid == 0) {
+    *b.out_count = base;
+    *b.num_finished = (int)(base - base_s);
+  }
 }
 
 struct FlushTable {
@@ -215,15 +219,31 @@ __device__ __forceinline__ void copy_row(const uint8_t* a, uint8_t* b, long long
   }
 }
 
-__global__ __launch_bounds__(256) void k_actor_flush(FlushTable ft, const int32_t* __restrict__ slot, int n) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= n) return;
-  const int s = slot[row];
-  if (s < 0) return;
+__device__ __forceinline__ void copy_row_block(const uint8_t* a, uint8_t* b, long long n, int tid, int nthreads) {
+  if ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)n) & 15) == 0) {
+    for (long long off = (long long)tid * 16; off < n; off += (long long)nthreads * 16)
+      *reinterpret_cast<uint4*>(b + off) = *reinterpret_cast<const uint4*>(a + off);
+  } else if ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)n) & 3) == 0) {
+    for (long long off = (long long)tid * 4; off < n; off += (long long)nthreads * 4)
+      *reinterpret_cast<uint32_t*>(b + off) = *reinterpret_cast<const uint32_t*>(a + off);
+  } else {
+    for (long long off = tid; off < n; off += nthreads) b[off] = a[off];
+  }
+}
+
+// blockIdx.y = array; the workgroups of one array walk the list of finished envs, one whole workgroup per row
+__global__ __launch_bounds__(256) void k_actor_flush(FlushTable ft, const int32_t* __restrict__ slot,
+                                                     const int32_t* __restrict__ finished,
+                                                     const int32_t* __restrict__ num_finished) {
   const int k = blockIdx.y;
   const long long rb = ft.row_bytes[k];
-  copy_row(ft.src[k] + (size_t)row * (size_t)rb, ft.dst[k] + (size_t)s * (size_t)rb, rb, lane);
+  const int n = *num_finished;
+  for (int j = blockIdx.x; j < n; j += gridDim.x) {
+    const int row = finished[j];
+    const int s = slot[row];
+    if (s < 0) continue;
+    copy_row_block(ft.src[k] + (size_t)row * (size_t)rb, ft.dst[k] + (size_t)s * (size_t)rb, rb, threadIdx.x, blockDim.x);
+  }
 }
 
 // one wave per env: trajectory heads and the model's input window
@@ -266,7 +286,8 @@ __global__ __launch_bounds__(256) void k_actor_begin_move(hz_actor_bufs_t b, con
              who ": bad sizes N=%d A=%d W=%d T=%d cap=%d", (b)->num_envs, (b)->num_actions, (b)->packed_words,      \
              (b)->max_moves, (b)->outbox_games);                                                                    \
   HZ_REQUIRE((b)->action && (b)->reward && (b)->value && (b)->visits && (b)->legal && (b)->obs && (b)->traj_len &&  \
-                 (b)->ent_sum && (b)->meta && (b)->out_count && (b)->slot && (b)->illegal_steps,                    \
+                 (b)->ent_sum && (b)->meta && (b)->out_count && (b)->slot && (b)->finished && (b)->num_finished &&        \
+                 (b)->illegal_steps,                    \
              who ": NULL buffer in bufs")
 
 extern "C" int hz_actor_record_search(const hz_actor_bufs_t* bufs, int32_t* counts, const float* root_values,
@@ -309,8 +330,9 @@ extern "C" int hz_actor_flush(const hz_actor_bufs_t* bufs, void* stream) {
     ft.dst[k] = (uint8_t*)dst[k];
     ft.row_bytes[k] = rb[k];
   }
-  hipLaunchKernelGGL(k_actor_flush, dim3((bufs->num_envs + 3) / 4, 7), dim3(256), 0, (hipStream_t)stream, ft, bufs->slot,
-                     bufs->num_envs);
+  const int gx = bufs->num_envs < 256 ? bufs->num_envs : 256;
+  hipLaunchKernelGGL(k_actor_flush, dim3(gx, 7), dim3(256), 0, (hipStream_t)stream, ft, bufs->slot, bufs->finished,
+                     bufs->num_finished);
   HZ_HIP(hipGetLastError());
   return 0;
 }
@@ -325,14 +347,90 @@ extern "C" int hz_actor_begin_move(const hz_actor_bufs_t* bufs, const uint8_t* d
   const dim3 grid((bufs->num_envs + 3) / 4), block(256);
   const uintptr_t al = (uintptr_t)newest | (uintptr_t)stack_buf | (uintptr_t)newest_row_bytes | (uintptr_t)stack_row_bytes |
                        (uintptr_t)obs_bytes;
-  if ((al & 3) == 0)
-    hipLaunchKernelGGL(k_actor_begin_move<uint32_t>, grid, block, 0, (hipStream_t)stream, *bufs, done, packed, legal,
-                       (const uint8_t*)newest, (long long)newest_row_bytes, (uint8_t*)stack_buf,
-                       (long long)stack_row_bytes, stack, (long long)obs_bytes);
-  else
-    hipLaunchKernelGGL(k_actor_begin_move<uint8_t>, grid, block, 0, (hipStream_t)stream, *bufs, done, packed, legal,
-                       (const uint8_t*)newest, (long long)newest_row_bytes, (uint8_t*)stack_buf,
-                       (long long)stack_row_bytes, stack, (long long)obs_bytes);
+#define HZ_BEGIN_MOVE(U)                                                                                          \
+  hipLaunchKernelGGL(k_actor_begin_move<U>, grid, block, 0, (hipStream_t)stream, *bufs, done, packed, legal,      \
+                     (const uint8_t*)newest, (long long)newest_row_bytes, (uint8_t*)stack_buf,                    \
+                     (long long)stack_row_bytes, stack, (long long)obs_bytes)
+  if ((al & 3) == 0) HZ_BEGIN_MOVE(uint32_t);
+  else if ((al & 1) == 0) HZ_BEGIN_MOVE(uint16_t);  // bf16 observations of odd width
+  else HZ_BEGIN_MOVE(uint8_t);
+#undef HZ_BEGIN_MOVE
+  HZ_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---- root noise + sampling uniforms (include/hz_selfplay.h) -----------------------------------------------------
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {  // splitmix64 finaliser
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27; x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return x;
+}
+
+struct CounterRng {  // stream = key, k-th output = mix64(key + k * golden)
+  uint64_t key, k;
+  __device__ double next() {  // (0, 1): 53 bits, never 0
+    const uint64_t r = mix64(key + (++k) * 0x9E3779B97F4A7C15ull);
+    return ((double)(r >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+  }
+};
+
+__device__ double gamma_draw(CounterRng& g, double alpha) {  // Marsaglia & Tsang (2000); alpha < 1 via alpha + 1
+  const double a = alpha < 1.0 ? alpha + 1.0 : alpha;
+  const double d = a - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
+  double out = 0.0;
+  for (int it = 0; it < 64; ++it) {  // acceptance > 95 %: the bound is never the exit in practice
+    const double u1 = g.next(), u2 = g.next();
+    const double x = sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);  // Box-Muller
+    double v = 1.0 + c * x;
+    if (v <= 0.0) continue;
+    v = v * v * v;
+    const double u = g.next();
+    out = d * v;
+    if (log(u) < 0.5 * x * x + d - d * v + d * log(v)) break;
+  }
+  if (alpha < 1.0) out *= pow(g.next(), 1.0 / alpha);
+  return out;
+}
+
+// one wave per env, lane = action
+__global__ __launch_bounds__(256) void k_actor_draw(uint64_t seed, long long env_id_base, long long* __restrict__ move_count,
+                                                    int N, int A, double alpha, float* __restrict__ noise,
+                                                    double* __restrict__ uniform) {
+  __shared__ double g_s[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int env = blockIdx.x * 4 + wave;
+  if (env >= N) return;
+  const long long k = move_count[env];
+  const uint64_t base = mix64(mix64(seed ^ 0x68616e616269ull) + (uint64_t)(env_id_base + env)) + (uint64_t)k * 0xD1B54A32D192ED03ull;
+  CounterRng g;
+  g.key = mix64(base + (uint64_t)(lane + 1));
+  g.k = 0;
+  double x = 0.0;
+  if (lane < A) x = gamma_draw(g, alpha);
+  g_s[wave][lane] = x;
+  __builtin_amdgcn_wave_barrier();
+  double sum = 0.0;
+  for (int a = 0; a < A; ++a) sum += g_s[wave][a];  // same-wave LDS traffic is ordered; action order, like numpy
+  if (lane < A) noise[(size_t)env * A + lane] = sum > 0.0 ? (float)(x / sum) : 1.0f / (float)A;
+  if (lane == 0) {
+    CounterRng gu;
+    gu.key = mix64(base);
+    gu.k = 0;
+    const uint64_t r = mix64(gu.key + 0x9E3779B97F4A7C15ull);
+    uniform[env] = (double)(r >> 11) * (1.0 / 9007199254740992.0);  // [0, 1)
+    move_count[env] = k + 1;
+  }
+}
+
+extern "C" int hz_actor_draw(uint64_t seed, int64_t env_id_base, int64_t* move_count, int num_envs, int num_actions,
+                             double alpha, float* noise, double* uniform, void* stream) {
+  HZ_REQUIRE(num_envs > 0 && num_actions > 0 && num_actions <= 64, "hz_actor_draw: bad sizes N=%d A=%d", num_envs,
+             num_actions);
+  HZ_REQUIRE(move_count && noise && uniform, "hz_actor_draw: NULL argument");
+  HZ_REQUIRE(alpha > 0.0, "hz_actor_draw: alpha must be > 0");
+  hipLaunchKernelGGL(k_actor_draw, dim3((num_envs + 3) / 4), dim3(256), 0, (hipStream_t)stream, seed,
+                     (long long)env_id_base, (long long*)move_count, num_envs, num_actions, alpha, noise, uniform);
   HZ_HIP(hipGetLastError());
   return 0;
 }

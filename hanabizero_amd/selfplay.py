@@ -19,8 +19,9 @@ Reference behaviours kept: num_simulations-1 simulations; illegal root children 
 action selection; child_visits are the MASKED counts normalised by their sum; the terminal observation is stored;
 rewards are raw score deltas (put()'s turn-reward reshape is applied by the consumer: game.reshape_turn_rewards).
 Deliberate deviations: env i is seeded ``seed + global_env_id`` (the reference seeds every env of actor
-rank 0 identically: selfplay_worker.py:102); Dirichlet noise and sampling uniforms come from the device generator
-instead of numpy's global one; tie-breaks from include/hz_tiebreak.h.
+rank 0 identically: selfplay_worker.py:102); Dirichlet noise and sampling uniforms come from a counter-based device
+stream keyed by (seed, global env id, move number) (hz_actor_draw) instead of numpy's global generator; tie-breaks
+from include/hz_tiebreak.h.
 """
 import ctypes as C
 
@@ -92,6 +93,8 @@ class SelfPlayActor:
         self.tmp_packed = z(N, W, dtype=torch.int32)
         self.tmp_legal = z(N, A, dtype=torch.uint8)
         self.illegal_steps = z(1, dtype=torch.int64)
+        self.finished = z(N, dtype=torch.int32)
+        self.num_finished = z(1, dtype=torch.int32)
         self.counts = z(N, A, dtype=torch.int32)
         self.values = z(N, dtype=torch.float32)
         assert done_dtype_ok(self.env)
@@ -106,14 +109,14 @@ class SelfPlayActor:
                               out_visits=o["visits"].data_ptr(), out_legal=o["legal"].data_ptr(),
                               out_obs=o["obs"].data_ptr(), out_meta=self.out_meta.data_ptr(),
                               out_count=self.out_count.data_ptr(), slot=self.slot.data_ptr(),
+                              finished=self.finished.data_ptr(), num_finished=self.num_finished.data_ptr(),
                               illegal_steps=self.illegal_steps.data_ptr())
         self.total_moves = 0
         self._drained = 0
         self._graph = None
         self.use_graph = use_graph
-        self.gen = torch.Generator(device=d)
-        self.gen.manual_seed(int(seed) * 1000003 + self.env_id_base)
-        self._alpha = torch.full((N, self.A), float(config.root_dirichlet_alpha), dtype=torch.float64, device=d)
+        self.noise_seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.move_count = z(N, dtype=torch.int64)  # per-env draw counter of the noise stream
         self._start()
 
     # -- episode start for every env (selfplay_worker.py:118-138) ----------------------------------------
@@ -126,12 +129,11 @@ class SelfPlayActor:
         self.traj_len.zero_()
         torch.cuda.synchronize(self.device)
 
-    # -- host-side randomness for one lock-step (inputs of the captured step) -------------------------------
+    # -- randomness of one lock-step: root noise and sampling uniforms, drawn on the device (captured with the step) --
     def _draw(self):
-        # np.random.dirichlet([alpha]*A).astype(float32) per env (selfplay_worker.py:279): Gamma(alpha) normalised, fp64
-        g = torch._standard_gamma(self._alpha, generator=self.gen)
-        self.noise.copy_((g / g.sum(1, keepdim=True)).to(torch.float32))
-        self.uniform.copy_(torch.rand(self.N, dtype=torch.float64, device=self.device, generator=self.gen))
+        check(lib.hz_actor_draw(self.noise_seed, self.env_id_base, self.move_count.data_ptr(), self.N, self.A,
+                                float(self.cfg.root_dirichlet_alpha), self.noise.data_ptr(), self.uniform.data_ptr(),
+                                _stream()), "hz_actor_draw")
 
     # -- one lock-step, device only --------------------------------------------------------------------------
     def _step_body(self):
@@ -173,6 +175,7 @@ class SelfPlayActor:
         torch.cuda.synchronize(self.device)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
+            self._draw()
             self._step_body()
         self._graph = g
 
@@ -187,10 +190,10 @@ class SelfPlayActor:
     def _step(self):
         if self.use_graph and self._graph is None:
             self._capture()
-        self._draw()
         if self.use_graph:
             self._graph.replay()
         else:
+            self._draw()
             self._step_body()
         self.total_moves += self.N
 
@@ -248,6 +251,7 @@ class ActorGroup:
             for a, b in zip(self.actors, branches):
                 b.wait_stream(root)
                 with torch.cuda.stream(b):
+                    a._draw()
                     a._step_body()
             for b in branches:
                 root.wait_stream(b)
@@ -257,7 +261,6 @@ class ActorGroup:
         if self._graph is None:
             self._capture()
         for a in self.actors:
-            a._draw()
             a.total_moves += a.N
         self._graph.replay()
 

@@ -31,6 +31,17 @@ int hz_select_action(int num_envs, int num_actions, int32_t* counts, const uint8
  * rows are 16-byte aligned (4 B or 1 B per lane otherwise). */
 int hz_rows_scatter(const void* src, void* dst, int64_t row_bytes, const int32_t* slot, int num_rows, void* stream);
 
+/* Root exploration noise and the action-sampling uniform of one move for every env, on the device (the reference draws
+ * np.random.dirichlet([alpha] * A).astype(float32) per env on the host, selfplay_worker.py:279, and select_action's
+ * np.random.choice draws one uniform, core/utils.py:293):
+ *   noise   [N][A] f32  Dirichlet(alpha, ..., alpha): A independent Gamma(alpha, 1) draws (Marsaglia-Tsang on
+ *                       Gamma(alpha + 1) times U^(1/alpha), fp64) divided by their sum in action order
+ *   uniform [N] f64     U[0, 1) with 53 random bits
+ * The random stream is counter-based: draws of env i at its k-th move are a pure function of (seed, env_id_base + i,
+ * k), so results do not depend on how envs are sharded over GPUs; move_count [N] i64 holds k and is incremented. */
+int hz_actor_draw(uint64_t seed, int64_t env_id_base, int64_t* move_count, int num_envs, int num_actions, double alpha,
+                  float* noise, double* uniform, void* stream);
+
 /* ---- the actor's per-move bookkeeping (core/selfplay_worker.py:286-347 + GameHistory.append/store_search_stats,
  * core/game.py:170-200), one launch per phase instead of a Python loop over envs.  The caller owns every buffer. */
 typedef struct {
@@ -57,6 +68,8 @@ typedef struct {
   int32_t* out_meta;
   int64_t* out_count;     /* [1] games finished so far */
   int32_t* slot;          /* [N] scratch: outbox row of the env's finished game, -1 while it runs */
+  int32_t* finished;      /* [N] scratch: the envs whose game just ended, ascending */
+  int32_t* num_finished;  /* [1] scratch: how many */
   int64_t* illegal_steps; /* [1] env steps that reported an illegal move (stays 0) */
 } hz_actor_bufs_t;
 
@@ -69,11 +82,12 @@ int hz_actor_record_search(const hz_actor_bufs_t* bufs, int32_t* counts, const f
 /* After hz_env_step + hz_env_observe(packed, legal_next): reward[t] = reward, obs[t+1] / legal[t+1] = the observation
  * after the move (the terminal one included, selfplay_worker.py:308), meta row, illegal_steps += #(status != 0);
  * then the outbox slots of the games that just ended, in env order: slot = (out_count + rank among done) % capacity,
- * out_count += #done. */
+ * out_count += #done; the list of those envs goes to bufs->finished / num_finished. */
 int hz_actor_record_step(const hz_actor_bufs_t* bufs, const int32_t* reward, const uint8_t* done, const int32_t* score,
                          const int32_t* status, const int32_t* packed, const uint8_t* legal_next, void* stream);
 
-/* hz_rows_scatter of all six trajectory arrays and the meta rows by bufs->slot, one launch. */
+/* hz_rows_scatter of all six trajectory arrays and the meta rows by bufs->slot, one launch over bufs->finished
+ * (one workgroup per row and array). */
 int hz_actor_flush(const hz_actor_bufs_t* bufs, void* stream);
 
 /* After hz_env_reset(done) + hz_env_observe(newest, packed, legal): traj_len = done ? 0 : t+1, ent_sum = done ? 0 : ent_sum,

@@ -127,6 +127,42 @@ def test_graph_replay_equals_eager():
         assert (outs[0][2][k] == outs[1][2][k]).all(), k
 
 
+def test_root_noise_stream_is_dirichlet_and_sharding_independent():
+    """hz_actor_draw: Dirichlet(alpha) rows (marginals Beta(alpha, (A-1) alpha), KS test), U[0,1) uniforms, and the
+    draws of env i at move k depend only on (seed, global env id, k)."""
+    from scipy import stats
+    from hanabizero_amd._lib import check, lib
+    N, A, alpha = 8192, 20, 0.3
+    s = torch.cuda.current_stream().cuda_stream
+
+    def draw(base, n, moves):
+        mc = torch.zeros(n, dtype=torch.int64, device="cuda")
+        noise = torch.zeros(n, A, dtype=torch.float32, device="cuda")
+        uni = torch.zeros(n, dtype=torch.float64, device="cuda")
+        out = []
+        for _ in range(moves):
+            check(lib.hz_actor_draw(77, base, mc.data_ptr(), n, A, alpha, noise.data_ptr(), uni.data_ptr(), s), "draw")
+            out.append((noise.cpu().numpy().copy(), uni.cpu().numpy().copy()))
+        assert (mc == moves).all()
+        return out
+
+    full = draw(0, N, 3)
+    noise, uni = full[0]
+    assert np.isfinite(noise).all() and (noise >= 0).all() and np.abs(noise.sum(1) - 1).max() < 1e-5
+    assert (uni >= 0).all() and (uni < 1).all()
+    assert stats.kstest(uni, "uniform").pvalue > 1e-3
+    for a in (0, 7, A - 1):
+        assert stats.kstest(noise[:, a].astype(np.float64), stats.beta(alpha, (A - 1) * alpha).cdf).pvalue > 1e-3, a
+    assert abs(noise.mean() - 1.0 / A) < 1e-3
+    var = alpha * (A * alpha - alpha) / ((A * alpha) ** 2 * (A * alpha + 1))
+    assert abs(noise.var(0).mean() - var) / var < 0.05
+    assert abs(np.corrcoef(noise[:, 0], noise[:, 1])[0, 1] + 1.0 / (A - 1)) < 0.05  # Dirichlet: -alpha/(alpha0 - alpha)
+    assert not (full[0][0] == full[1][0]).all()                                      # next move, new draws
+    part = draw(4096, 100, 3)                                                         # another sharding of the same envs
+    for k in range(3):
+        assert (part[k][0] == full[k][0][4096:4196]).all() and (part[k][1] == full[k][1][4096:4196]).all()
+
+
 def test_select_action_kernel_edge_cases():
     from hanabizero_amd._lib import check, lib
     N, A = 5, 11
