@@ -127,12 +127,18 @@ __device__ uint32_t mt_next(uint32_t* mt, int N, int env) {
 __device__ void deal_random(const EnvCfg& g, St& s, int& cur, uint32_t* mt, int env) {
   const int ncards = g.C * g.R;
   const double total = (double)s.deck_total();
+  // a card type has 1..3 copies left (2-bit deck counters): its probability count/total takes three values, so the
+  // 2 x 25 fp64 divisions of the two passes below collapse to 2 x 3 with bit-identical quotients
+  const double q1 = 1.0 / total, q2 = 2.0 / total, q3 = 3.0 / total;
+  // the two deck words (16 + 9 counters) in registers
+  const uint32_t d0 = s.word(25), d1 = s.word(26);
+#define DECK(uid) (int)((((uid) < 16 ? d0 : d1) >> ((((uid) & 15)) * 2)) & 3u)
   int n = 0, only = 0;
   double sum = 0.0;  // std::accumulate(probabilities, 0.0) in chance-uid order
   for (int uid = 0; uid < ncards; ++uid) {
-    const int cnt = s.deck(uid);
+    const int cnt = DECK(uid);
     if (cnt == 0) continue;
-    sum += (double)cnt / total;  // ChanceOutcomeProb (:277-280)
+    sum += cnt == 1 ? q1 : (cnt == 2 ? q2 : q3);  // ChanceOutcomeProb (:277-280)
     only = uid;
     ++n;
   }
@@ -144,12 +150,13 @@ __device__ void deal_random(const EnvCfg& g, St& s, int& cur, uint32_t* mt, int 
     double u = (lo + hi * 4294967296.0) / 18446744073709551616.0;
     if (u >= 1.0) u = 0x1.fffffffffffffp-1;
     // normalise, partial_sum, last := 1.0, lower_bound (random.tcc:2666-2676, 2710-2712)
+    const double p1 = q1 / sum, p2 = q2 / sum, p3 = q3 / sum;
     double acc = 0.0;
     int seen = 0;
     for (int uid = 0; uid < ncards; ++uid) {
-      const int cnt = s.deck(uid);
+      const int cnt = DECK(uid);
       if (cnt == 0) continue;
-      const double p = ((double)cnt / total) / sum;
+      const double p = cnt == 1 ? p1 : (cnt == 2 ? p2 : p3);
       acc = (seen == 0) ? p : acc + p;
       ++seen;
       const double cp = (seen == n) ? 1.0 : acc;
@@ -159,6 +166,7 @@ __device__ void deal_random(const EnvCfg& g, St& s, int& cur, uint32_t* mt, int 
       }
     }
   }
+#undef DECK
   const int to = player_to_deal(g, s);
   const int slot = s.hand_n(to);
   const int color = pick / g.R, rank = pick % g.R;

@@ -82,7 +82,9 @@ extern "C" int hz_mlp_profile_read(unsigned long long* host) {
 #define PROF_ADD(var, t0) (void)(t0)
 #endif
 
-#define HZ_RING 8  // weight-fragment ring slots (k-steps); prefetch distance HZ_RING - 1
+#ifndef HZ_RING
+#define HZ_RING 8  // weight-fragment ring slots (k-steps); prefetch distance HZ_RING - 1 (8, or 4 for experiments)
+#endif
 
 template <int RT>
 __global__ __launch_bounds__(256, 1) void k_mlp_recurrent(
@@ -102,28 +104,51 @@ __global__ __launch_bounds__(256, 1) void k_mlp_recurrent(
   unsigned long long p_loop = 0, p_epi = 0, p_bar = 0, p_pre = 0;
   const unsigned long long p_t0 = PROF_NOW();
   (void)p_loop; (void)p_epi; (void)p_bar; (void)p_pre; (void)p_t0;
-  // this wave's weight stream: start the ring before anything else (it does not depend on the inputs)
+  // The parent hidden states (the gather of core/mcts.py:31-36) are one dependent pair of loads away: plane index,
+  // then the row.  Issue the index loads first, the weight ring next (it does not depend on the inputs and keeps the
+  // memory pipe busy meanwhile), then all row loads of this thread at once: two latencies in total, not two per trip.
+  const int chunks = H.hidden / 8;
+  const int n_stage = MT * chunks;
+  constexpr int SU = 4;  // rows-chunks per thread per trip (hidden = 512, 16 rows: exactly one trip)
+  long long plane0[SU];
+#pragma unroll
+  for (int u = 0; u < SU; ++u) {
+    const int i = tid + 256 * u;
+    const int row = row0 + i / chunks;
+    plane0[u] = (plane_index && i < n_stage && row < n_rows) ? (long long)plane_index[row] * plane_stride : 0;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // this wave's weight stream
   const bf16x8* wp = reinterpret_cast<const bf16x8*>(wstream + H.wave_stream_off[wave]) + lane;
   bf16x8 wf[HZ_RING][4];
 #pragma unroll
   for (int d = 0; d < HZ_RING - 1; ++d)
 #pragma unroll
     for (int t = 0; t < 4; ++t) wf[d][t] = wp[(d * 4 + t) * 64];
+  __builtin_amdgcn_sched_barrier(0);
 
-  // stage the parent hidden states (the gather of core/mcts.py:31-36) into the image; rows past N read as zero
-  {
-    const int chunks = H.hidden / 8;
-    for (int i = tid; i < MT * chunks; i += 256) {
+  // stage the states into the image; rows past N read as zero
+#ifndef HZ_MLP_X_NOSTAGE
+  for (int base = 0; base < n_stage; base += 256 * SU) {
+    uint4 v[SU];
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+      const int i = base + tid + 256 * u;
       const int r = i / chunks, c = i % chunks;
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
       const int row = row0 + r;
-      if (row < n_rows) {
-        const long long plane = plane_index ? (long long)plane_index[row] * plane_stride : 0;
-        v = *reinterpret_cast<const uint4*>(state_src + plane + (long long)row * state_row_stride + c * 8);
+      v[u] = make_uint4(0u, 0u, 0u, 0u);
+      if (i < n_stage && row < n_rows) {
+        const long long plane = base == 0 ? plane0[u] : (plane_index ? (long long)plane_index[row] * plane_stride : 0);
+        v[u] = *reinterpret_cast<const uint4*>(state_src + plane + (long long)row * state_row_stride + c * 8);
       }
-      *reinterpret_cast<uint4*>(lds + (size_t)r * rs + H.state_off + c * 8) = v;
+    }
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+      const int i = base + tid + 256 * u;
+      if (i < n_stage) *reinterpret_cast<uint4*>(lds + (size_t)(i / chunks) * rs + H.state_off + (i % chunks) * 8) = v[u];
     }
   }
+#endif
   int act[RT];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
@@ -190,7 +215,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_recurrent(
     }                                                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                               \
     _Pragma("unroll") for (int t = 0; t < 4; ++t) _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                  \
-        acc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[(U)][t], bq[(U) % 4][rt], acc[t][rt], 0, 0, 0);      \
+        acc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[(U) % HZ_RING][t], bq[(U) % 4][rt], acc[t][rt], 0, 0, 0); \
     __builtin_amdgcn_sched_barrier(0);                                                                               \
   }
 
@@ -223,8 +248,26 @@ __global__ __launch_bounds__(256, 1) void k_mlp_recurrent(
     PROF_ADD(p_loop, p_j2);
     const unsigned long long p_j3 = PROF_NOW();
 
+#ifdef HZ_MLP_X_NOEPI  // experiment (tools/mlp_variants.py): what the epilogues cost; results are garbage
+    if (acc[0][0][0] + acc[1][0][0] + acc[2][0][0] + acc[3][0][0] + bv[0].x + av[0][0].x == 12345.678f) lds[tid] = 1;
+    continue;
+#endif
     // epilogue: bias (+ action row) (+ residual) (+ ReLU) in fp32, round to bf16, 4 consecutive columns per lane
     const bool relu = J.flags & HZ_MLP_RELU;
+    // all residual fragments in one batch of LDS reads (one wait), not one round trip per column tile
+    uint2 rr[4][RT];
+    if (J.res_off >= 0) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+          rr[t][rt] = *reinterpret_cast<const uint2*>(lds + (size_t)(16 * rt + r0) * rs + J.res_off + 16 * t + c4);
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) rr[t][rt] = make_uint2(0u, 0u);  // bf16 +0: adds nothing
+    }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int col = 16 * t + c4;
@@ -233,11 +276,8 @@ __global__ __launch_bounds__(256, 1) void k_mlp_recurrent(
         const size_t rowbase = (size_t)(16 * rt + r0) * rs;
         float v[4] = {acc[t][rt][0] + bv[t].x + av[t][rt].x, acc[t][rt][1] + bv[t].y + av[t][rt].y,
                       acc[t][rt][2] + bv[t].z + av[t][rt].z, acc[t][rt][3] + bv[t].w + av[t][rt].w};
-        if (J.res_off >= 0) {
-          const uint2 rr = *reinterpret_cast<const uint2*>(lds + rowbase + J.res_off + col);
-          v[0] += bf2f((uint16_t)(rr.x & 0xffffu)); v[1] += bf2f((uint16_t)(rr.x >> 16));
-          v[2] += bf2f((uint16_t)(rr.y & 0xffffu)); v[3] += bf2f((uint16_t)(rr.y >> 16));
-        }
+        v[0] += bf2f((uint16_t)(rr[t][rt].x & 0xffffu)); v[1] += bf2f((uint16_t)(rr[t][rt].x >> 16));
+        v[2] += bf2f((uint16_t)(rr[t][rt].y & 0xffffu)); v[3] += bf2f((uint16_t)(rr[t][rt].y >> 16));
         if (relu) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = (v[r] > 0.0f || v[r] != v[r]) ? v[r] : 0.0f;
@@ -254,6 +294,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_recurrent(
   (void)p_jobs_done;
   __syncthreads();
   // heads -> scalars / policy logits: 16 lanes per (row, head) pair, 16 pairs in flight per workgroup pass
+#ifndef HZ_MLP_X_NOFINAL
   {
     const int l16 = tid & 15, slot = tid >> 4;
     for (int pair = slot; pair < 2 * MT; pair += 16) {
@@ -273,6 +314,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_recurrent(
       }
     }
   }
+#endif
 #ifdef HZ_MLP_PROFILE
   if (blockIdx.x == 100 && lane == 0) {
     unsigned long long* o = hz_mlp_prof + wave * 8;
