@@ -1,0 +1,326 @@
+// hz_mlp_dev.h -- device code of the fused recurrent-inference MLP (see hz_mlp.hip), shared by the stand-alone kernel
+// and the persistent search kernel (hz_search.hip).
+#pragma once
+#include "hz_common.h"
+#include "hz_mlp.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+__device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+// two fp32 -> packed bf16 pair: a plain cast compiles to v_cvt_pk_bf16_f32 on gfx950 (round-to-nearest-even, NaN kept)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+  const f32x2 f = {lo, hi};
+  const bf16x2 h = __builtin_convertvector(f, bf16x2);
+  return *reinterpret_cast<const uint32_t*>(&h);
+}
+
+// inverse_scalar_transform of LDS rows of bf16 logits, one (row, head) pair per 16-lane row of the wave: lane l16
+// owns logits [16*l16, 16*l16 + 16) (two ds_read_b128), DPP reductions across the 16 lanes; V <= 256.
+// Same maths as hz_tree.hip support_to_scalar.
+__device__ __forceinline__ float row16_support_to_scalar(const uint16_t* row, int V, int support_min, int l16) {
+  uint32_t w[8];
+  const int base = 16 * l16;
+  if (base < V) {
+    const uint4 a = *reinterpret_cast<const uint4*>(row + base);
+    const uint4 b = *reinterpret_cast<const uint4*>(row + base + 8);
+    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w[k] = 0;
+  }
+  float x[16];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    x[2 * k] = (base + 2 * k < V) ? __uint_as_float(w[k] << 16) : -INFINITY;
+    x[2 * k + 1] = (base + 2 * k + 1 < V) ? __uint_as_float(w[k] & 0xffff0000u) : -INFINITY;
+  }
+  float m = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) m = fmaxf(m, x[k]);
+  m = hz_row16_max(m);
+  float se = 0.0f, sw = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const float e = (base + k < V) ? __expf(x[k] - m) : 0.0f;
+    se += e;
+    sw += e * (float)(support_min + base + k);
+  }
+  se = hz_row16_sum(se);
+  sw = hz_row16_sum(sw);
+  const float v = sw / se;
+  const float eps = 0.001f;
+  const float t = (sqrtf(1.0f + 4.0f * eps * (fabsf(v) + 1.0f + eps)) - 1.0f) / (2.0f * eps);
+  float out = t * t - 1.0f;
+  if (v < 0.0f) out = -out;
+  if (out != out) out = 0.0f;
+  return out;
+}
+
+// Diagnostic build only (-DHZ_MLP_PROFILE, tools/mlp_profile.py): per-phase shader-cycle sums of workgroup 100.
+#ifdef HZ_MLP_PROFILE
+__device__ unsigned long long hz_mlp_prof[16 * 8];
+extern "C" int hz_mlp_profile_read(unsigned long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(hz_mlp_prof), sizeof(hz_mlp_prof));
+}
+#define PROF_NOW() __builtin_amdgcn_s_memtime()
+#define PROF_ADD(var, t0) var += __builtin_amdgcn_s_memtime() - (t0)
+#else
+#define PROF_NOW() 0ull
+#define PROF_ADD(var, t0) (void)(t0)
+#endif
+
+#ifdef HZ_MLP_X_NOBREAD  // experiment switch (tools/mlp_variants.py): no activation-fragment reads in the k-loop
+#define HZ_MLP_BREAD 0
+#else
+#define HZ_MLP_BREAD 1
+#endif
+#ifndef HZ_RING
+#define HZ_RING 4  // weight-fragment ring slots (k-steps); prefetch distance HZ_RING - 1.  Measured: 4 and 8 run at the
+#endif             // same rate (the memory pipe's own queue is the limit), 4 leaves registers for 16 waves per workgroup
+
+// The body, called by every wave of the workgroup: NW waves, each producing NT 16-column tiles per job (NW x NT = 4 x 4
+// for the stand-alone kernel, 16 x 2 inside the persistent search kernel, whose 16 waves also own one tree each).
+// `lds`: the row image, MT * row_stride bf16.
+template <int RT, int NW, int NT>
+__device__ __forceinline__ void mlp_body(
+    const hz_mlp_header_t& H, const hz_mlp_job_t* __restrict__ jobs, const uint16_t* __restrict__ wstream,
+    const float* __restrict__ bias, const float* __restrict__ act_tab, const uint16_t* __restrict__ state_src,
+    long long state_row_stride, const int32_t* __restrict__ plane_index, long long plane_stride,
+    const int32_t* __restrict__ actions, uint16_t* __restrict__ hidden_out, float* __restrict__ out_reward,
+    float* __restrict__ out_value, float* __restrict__ out_policy, int n_rows, uint16_t* lds, int row0) {
+  constexpr int NTHR = 64 * NW;
+  constexpr int MT = 16 * RT;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: job fields stay in SGPRs, branches are scalar
+  const int rs = H.row_stride;
+  const int r0 = lane & 15, kq = (lane >> 4) * 8, c4 = 4 * (lane >> 4);
+  (void)NTHR;
+
+  unsigned long long p_loop = 0, p_epi = 0, p_bar = 0, p_pre = 0;
+  const unsigned long long p_t0 = PROF_NOW();
+  (void)p_loop; (void)p_epi; (void)p_bar; (void)p_pre; (void)p_t0;
+  // The parent hidden states (the gather of core/mcts.py:31-36) are one dependent pair of loads away: plane index,
+  // then the row.  Issue the index loads first, the weight ring next (it does not depend on the inputs and keeps the
+  // memory pipe busy meanwhile), then all row loads of this thread at once: two latencies in total, not two per trip.
+  const int chunks = H.hidden / 8;
+  const int n_stage = MT * chunks;
+  constexpr int SU = 4;  // rows-chunks per thread per trip (hidden = 512, 16 rows: exactly one trip)
+  long long plane0[SU];
+#pragma unroll
+  for (int u = 0; u < SU; ++u) {
+    const int i = tid + NTHR * u;
+    const int row = row0 + i / chunks;
+    plane0[u] = (plane_index && i < n_stage && row < n_rows) ? (long long)plane_index[row] * plane_stride : 0;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // this wave's weight stream
+  const bf16x8* wp = reinterpret_cast<const bf16x8*>(wstream + H.wave_stream_off[wave]) + lane;
+  bf16x8 wf[HZ_RING][NT];
+#pragma unroll
+  for (int d = 0; d < HZ_RING - 1; ++d)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) wf[d][t] = wp[(d * NT + t) * 64];
+  __builtin_amdgcn_sched_barrier(0);
+
+  // stage the states into the image; rows past N read as zero
+#ifndef HZ_MLP_X_NOSTAGE
+  for (int base = 0; base < n_stage; base += NTHR * SU) {
+    uint4 v[SU];
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+      const int i = base + tid + NTHR * u;
+      const int r = i / chunks, c = i % chunks;
+      const int row = row0 + r;
+      v[u] = make_uint4(0u, 0u, 0u, 0u);
+      if (i < n_stage && row < n_rows) {
+        const long long plane = base == 0 ? plane0[u] : (plane_index ? (long long)plane_index[row] * plane_stride : 0);
+        v[u] = *reinterpret_cast<const uint4*>(state_src + plane + (long long)row * state_row_stride + c * 8);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+      const int i = base + tid + NTHR * u;
+      if (i < n_stage) *reinterpret_cast<uint4*>(lds + (size_t)(i / chunks) * rs + H.state_off + (i % chunks) * 8) = v[u];
+    }
+  }
+#endif
+  int act[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    const int row = row0 + 16 * rt + r0;
+    int a = row < n_rows ? actions[row] : 0;
+    act[rt] = (a < 0 || a >= H.num_actions) ? 0 : a;
+  }
+  __syncthreads();
+
+  const unsigned long long p_staged = PROF_NOW();
+  (void)p_staged;
+  long long gstep = 0;  // k-steps of this wave's stream consumed so far
+  for (int j = 0; j < H.n_jobs; ++j) {
+    const hz_mlp_job_t J = jobs[j * NW + wave];
+    const unsigned long long p_j0 = PROF_NOW();
+#ifndef HZ_MLP_X_NOBAR  // (experiment switch, tools/mlp_variants.py)
+    if (J.flags & HZ_MLP_BARRIER) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // LDS only: loads stay in flight
+#endif
+    if (J.flags & HZ_MLP_STORE_HIDDEN) {
+      const int chunks = H.hidden / 8;
+      for (int i = tid; i < MT * chunks; i += NTHR) {
+        const int r = i / chunks, c = i % chunks;
+        if (row0 + r < n_rows)
+          *reinterpret_cast<uint4*>(hidden_out + (size_t)(row0 + r) * H.hidden + c * 8) =
+              *reinterpret_cast<const uint4*>(lds + (size_t)r * rs + H.hidden_off + c * 8);
+      }
+    }
+    PROF_ADD(p_bar, p_j0);
+    if (J.ks == 0) continue;
+    const unsigned long long p_j1 = PROF_NOW();
+    // epilogue operands first: their latency hides under the k-loop
+    float4 bv[NT], av[NT][RT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      bv[t] = *reinterpret_cast<const float4*>(bias + J.bias_off + 16 * t + c4);
+      // unconditional loads (row num_actions of the table is all zeros): a load under a branch would make the
+      // compiler wait for EVERY outstanding load (vmcnt(0)) in the epilogue and drain the weight ring once per job
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const int arow = (J.flags & HZ_MLP_ACTION_ROW) ? act[rt] : H.num_actions;
+        av[t][rt] = *reinterpret_cast<const float4*>(act_tab + (size_t)arow * H.action_table_stride + J.bias_off + 16 * t + c4);
+      }
+    }
+    f32x4 acc[NT][RT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) acc[t][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const uint16_t* src = lds + (size_t)r0 * rs + J.src_off + kq;
+    bf16x8 bq[4][RT];  // activation fragments, 3 k-steps ahead of their use (LDS latency never exposed)
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+      if (d < J.ks) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) bq[d][rt] = *reinterpret_cast<const bf16x8*>(src + (size_t)(16 * rt) * rs + 32 * d);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+
+#define HZ_MLP_STEP(S, U)                                                                                            \
+  {                                                                                                                  \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                                   \
+        wf[((U) + HZ_RING - 1) % HZ_RING][t] = wp[((gstep + (S) + HZ_RING - 1) * NT + t) * 64];                      \
+    if (HZ_MLP_BREAD && (S) + 3 < J.ks) {                                                                            \
+      _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                                              \
+          bq[((U) + 3) % 4][rt] = *reinterpret_cast<const bf16x8*>(src + (size_t)(16 * rt) * rs + 32 * ((S) + 3));   \
+    }                                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t) _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                  \
+        acc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[(U) % HZ_RING][t], bq[(U) % 4][rt], acc[t][rt], 0, 0, 0); \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+  }
+
+    // all but the last 8 k-steps in a loop, the last 8 peeled: the 32 fragment loads they issue sit between the
+    // bias / action-row loads above and their first use, so the compiler can wait with vmcnt(>=28) instead of draining
+    // the whole ring (its wait-count analysis forgets how many loads a loop issued)
+    PROF_ADD(p_pre, p_j1);
+    const unsigned long long p_j2 = PROF_NOW();
+    int s = 0;
+    for (; s + 8 < J.ks; s += 8) {
+      HZ_MLP_STEP(s, 0)
+      HZ_MLP_STEP(s + 1, 1)
+      HZ_MLP_STEP(s + 2, 2)
+      HZ_MLP_STEP(s + 3, 3)
+      HZ_MLP_STEP(s + 4, 4)
+      HZ_MLP_STEP(s + 5, 5)
+      HZ_MLP_STEP(s + 6, 6)
+      HZ_MLP_STEP(s + 7, 7)
+    }
+    HZ_MLP_STEP(s, 0)
+    HZ_MLP_STEP(s + 1, 1)
+    HZ_MLP_STEP(s + 2, 2)
+    HZ_MLP_STEP(s + 3, 3)
+    HZ_MLP_STEP(s + 4, 4)
+    HZ_MLP_STEP(s + 5, 5)
+    HZ_MLP_STEP(s + 6, 6)
+    HZ_MLP_STEP(s + 7, 7)
+#undef HZ_MLP_STEP
+    gstep += J.ks;
+    PROF_ADD(p_loop, p_j2);
+    const unsigned long long p_j3 = PROF_NOW();
+
+#ifdef HZ_MLP_X_NOEPI  // experiment (tools/mlp_variants.py): what the epilogues cost; results are garbage
+    if (acc[0][0][0] + acc[NT - 1][0][0] + bv[0].x + av[0][0].x == 12345.678f) lds[tid] = 1;
+    continue;
+#endif
+    // epilogue: bias (+ action row) (+ residual) (+ ReLU) in fp32, round to bf16, 4 consecutive columns per lane
+    const bool relu = J.flags & HZ_MLP_RELU;
+    // all residual fragments in one batch of LDS reads (one wait), not one round trip per column tile
+    uint2 rr[NT][RT];
+    if (J.res_off >= 0) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+          rr[t][rt] = *reinterpret_cast<const uint2*>(lds + (size_t)(16 * rt + r0) * rs + J.res_off + 16 * t + c4);
+    } else {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) rr[t][rt] = make_uint2(0u, 0u);  // bf16 +0: adds nothing
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int col = 16 * t + c4;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const size_t rowbase = (size_t)(16 * rt + r0) * rs;
+        float v[4] = {acc[t][rt][0] + bv[t].x + av[t][rt].x, acc[t][rt][1] + bv[t].y + av[t][rt].y,
+                      acc[t][rt][2] + bv[t].z + av[t][rt].z, acc[t][rt][3] + bv[t].w + av[t][rt].w};
+        v[0] += bf2f((uint16_t)(rr[t][rt].x & 0xffffu)); v[1] += bf2f((uint16_t)(rr[t][rt].x >> 16));
+        v[2] += bf2f((uint16_t)(rr[t][rt].y & 0xffffu)); v[3] += bf2f((uint16_t)(rr[t][rt].y >> 16));
+        if (relu) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = (v[r] > 0.0f || v[r] != v[r]) ? v[r] : 0.0f;
+        }
+        uint2 o;
+        o.x = pack_bf16(v[0], v[1]);
+        o.y = pack_bf16(v[2], v[3]);
+        *reinterpret_cast<uint2*>(lds + rowbase + J.dst_off + col) = o;
+      }
+    }
+    PROF_ADD(p_epi, p_j3);
+  }
+  const unsigned long long p_jobs_done = PROF_NOW();
+  (void)p_jobs_done;
+  __syncthreads();
+  // heads -> scalars / policy logits: 16 lanes per (row, head) pair, 16 pairs in flight per workgroup pass
+#ifndef HZ_MLP_X_NOFINAL
+  {
+    const int l16 = tid & 15, slot = tid >> 4;
+    for (int pair = slot; pair < 2 * MT; pair += NTHR / 16) {
+      const int r = pair >> 1, head = pair & 1;
+      if (row0 + r < n_rows) {
+        const uint16_t* row = lds + (size_t)r * rs;
+        const float x = row16_support_to_scalar(row + (head ? H.off_value : H.off_reward), H.support_size, H.support_min, l16);
+        if (l16 == 0) (head ? out_value : out_reward)[row0 + r] = x;
+      }
+    }
+    for (int i = tid; i < MT * H.num_actions; i += NTHR) {
+      const int r = i / H.num_actions, a = i % H.num_actions;
+      if (row0 + r < n_rows) {
+        float x = bf2f(lds[(size_t)r * rs + H.off_policy + a]);
+        if (x != x) x = 0.0f;  // core/mcts.py:48-49
+        out_policy[(size_t)(row0 + r) * H.num_actions + a] = x;
+      }
+    }
+  }
+#endif
+#ifdef HZ_MLP_PROFILE
+  if (blockIdx.x == 100 && lane == 0) {
+    unsigned long long* o = hz_mlp_prof + wave * 8;
+    o[0] = p_staged - p_t0; o[1] = p_bar; o[2] = p_pre; o[3] = p_loop; o[4] = p_epi;
+    o[5] = PROF_NOW() - p_jobs_done; o[6] = PROF_NOW() - p_t0; o[7] = (unsigned long long)gstep;
+  }
+#endif
+}
+

@@ -1,0 +1,127 @@
+// hz_search.hip -- the whole search of one move (every simulation of core/mcts.py:26-58) as ONE persistent kernel.
+//
+// The S-1 simulations of a tree are a strict chain -- descent -> recurrent inference of the leaf -> expand + backup ->
+// next descent -- but chains of different trees never meet.  So a workgroup keeps 16 trees for the whole search: its
+// 16 wavefronts each own one tree (descent and backup: hz_tree_dev.h, one wave per tree as in hz_tree.hip), and
+// together they are the 16 x 2-tile workgroup of the fused MFMA recurrent inference (hz_mlp_dev.h) over exactly
+// those 16 rows.  Between the phases there is only a workgroup barrier: no launch, no grid-wide dependency, no wait for
+// the deepest of ALL trees before any inference can start, and the leaf outputs (reward, value, policy logits, next
+// hidden state) go from the MFMA phase to the backup phase of the same compute unit.
+// 256 workgroups x 16 trees = the 4096 envs of the benchmark on the 256 CUs of an MI355X; more envs simply queue.
+#include "hz_mlp_dev.h"
+#include "hz_search.h"
+#include "hz_tree_dev.h"
+
+struct SearchArgs {
+  const hz_mlp_job_t* jobs;
+  const uint16_t* wstream;
+  const float* bias;
+  const float* act_tab;
+  uint16_t* pool;          // [S][N][hidden] bf16; plane 0 = root hidden states
+  long long plane_stride;  // elements
+  long long row_stride;
+  int32_t* ix;             // [N] scratch: leaf parent entry of the current simulation (= pool plane)
+  int32_t* iy;             // [N]
+  int32_t* la;             // [N] last action
+  float* rew;              // [N] scratch: leaf reward / value / policy logits of the current simulation
+  float* val;
+  float* pol;              // [N][A]
+  int sims;                // simulations to run (S - 1, as the reference)
+};
+
+// The three phases are separate functions (not inlined): each gets its own register allocation inside the 128 VGPRs a
+// wave of a 1024-thread workgroup may use, instead of one allocation spanning both bodies (which spills).
+__device__ __noinline__ void search_first_descent(const TreeView& tv, const SearchArgs& a, int tree, int lane) {
+  TraverseOut to;
+  to.ix = a.ix; to.iy = a.iy; to.la = a.la;
+  to.pool = nullptr; to.net_in = nullptr; to.row_bytes = 0; to.net_in_stride_bytes = 0; to.onehot_cols = 0; to.dtype = 0;
+  traverse_body(tv, tree, lane, 0, tv.mm_min[tree], tv.mm_max[tree], tv.root_visit[tree], to, false,
+                make_float4(0.f, 0.f, 0.f, 0.f));
+}
+
+__device__ __noinline__ void search_backup_descent(const TreeView& tv, const SearchArgs& a, int tree, int lane, int wave,
+                                                   float* lds_q, int sim, bool more) {
+  TraverseOut to;
+  to.ix = a.ix; to.iy = a.iy; to.la = a.la;
+  to.pool = nullptr; to.net_in = nullptr; to.row_bytes = 0; to.net_in_stride_bytes = 0; to.onehot_cols = 0; to.dtype = 0;
+  NetOut no;
+  no.rewards = a.rew; no.values = a.val; no.logits = a.pol;
+  no.reward_logits = nullptr; no.value_logits = nullptr; no.policy_logits = nullptr;
+  no.reward_stride = 0; no.value_stride = 0; no.policy_stride = 0;
+  no.support_size = 0; no.support_min = 0; no.dtype = 0; no.out_rewards = nullptr; no.out_values = nullptr;
+  float4 root_row = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (more && lane < tv.A) root_row = tv.rec[(size_t)tree * tv.S * tv.A + lane];
+  float mn, mx;
+  int rv, a0;
+  float4 first;
+  backprop_body<false>(tv, tree, lane, wave, lds_q, sim + 1, no, mn, mx, rv, first, a0);
+  if (more) {
+    if (lane == a0) root_row = first;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    traverse_body(tv, tree, lane, sim + 1, mn, mx, rv, to, true, root_row);
+  }
+}
+
+__device__ __noinline__ void search_inference(const hz_mlp_header_t& H, const SearchArgs& a, int sim, int n_rows,
+                                              uint16_t* lds, int row0) {
+  mlp_body<1, 16, 2>(H, a.jobs, a.wstream, a.bias, a.act_tab, a.pool, a.row_stride, a.ix, a.plane_stride, a.la,
+                     a.pool + (size_t)(sim + 1) * a.plane_stride, a.rew, a.val, a.pol, n_rows, lds, row0);
+}
+
+__global__ __launch_bounds__(1024, 1) void k_search(TreeView tv, hz_mlp_header_t H, SearchArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int row0 = blockIdx.x * 16;
+  const int tree = row0 + wave;
+  const bool mine = tree < tv.N;
+  float* lds_q = reinterpret_cast<float*>(lds + (size_t)16 * H.row_stride);  // [16 waves][S] behind the row image
+  if (mine) search_first_descent(tv, a, tree, lane);
+  for (int sim = 0; sim < a.sims; ++sim) {
+    __syncthreads();  // the descents' (plane, action) of this workgroup's rows are visible to all its waves
+    search_inference(H, a, sim, tv.N, lds, row0);
+    __syncthreads();  // leaf outputs visible; the row image is free again
+    if (mine) search_backup_descent(tv, a, tree, lane, wave, lds_q, sim, sim + 1 < a.sims);
+  }
+}
+
+extern "C" int hz_search_run(hz_tree_t* t, int num_simulations, const hz_mlp_header_t* H, const hz_mlp_job_t* jobs,
+                             const void* wstream, const float* biases, const float* action_table, void* pool,
+                             int64_t plane_stride, int64_t row_stride, int32_t* ix, int32_t* iy, int32_t* la,
+                             float* rewards, float* values, float* policy, void* stream) {
+  HZ_REQUIRE(t && H && jobs && wstream && biases && action_table && pool && ix && iy && la && rewards && values && policy,
+             "hz_search_run: NULL argument");
+  HZ_REQUIRE(t->params_set, "hz_search_run: call hz_tree_set_params first");
+  HZ_REQUIRE(num_simulations >= 1 && num_simulations < t->S,
+             "hz_search_run: num_simulations=%d outside [1, tree capacity %d)", num_simulations, t->S);
+  HZ_REQUIRE(t->next_entry == 1, "hz_search_run: the tree must be freshly prepared (hz_tree_prepare)");
+  HZ_REQUIRE(H->num_waves == 16 && H->tiles_per_wave == 2, "hz_search_run: the MLP must be laid out for 16 waves x 2 tiles");
+  HZ_REQUIRE(H->num_actions == t->A, "hz_search_run: the MLP has %d actions, the tree %d", H->num_actions, t->A);
+  HZ_REQUIRE(H->n_jobs > 0 && H->n_jobs <= 256 && H->support_size > 0 && H->support_size <= 256 &&
+                 H->off_reward % 8 == 0 && H->off_value % 8 == 0 && H->row_stride % 8 == 0 && H->hidden % 8 == 0 &&
+                 H->state_off % 8 == 0 && H->hidden_off % 8 == 0 && H->action_table_stride % 4 == 0,
+             "hz_search_run: malformed MLP header");
+  HZ_REQUIRE(row_stride % 8 == 0 && plane_stride % 8 == 0 && row_stride >= H->hidden &&
+                 plane_stride >= (int64_t)t->N * row_stride,
+             "hz_search_run: pool strides must be multiples of 8 elements and cover [N][hidden]");
+  HZ_REQUIRE(((uintptr_t)pool % 16) == 0 && ((uintptr_t)wstream % 16) == 0 && ((uintptr_t)biases % 16) == 0 &&
+                 ((uintptr_t)action_table % 16) == 0,
+             "hz_search_run: pointers must be 16-B aligned");
+  for (int w = 0; w < 16; ++w)
+    HZ_REQUIRE(H->wave_stream_off[w] % 8 == 0, "hz_search_run: weight streams must start on 16-B boundaries");
+  const size_t lds_bytes = (size_t)16 * H->row_stride * sizeof(uint16_t) + (size_t)16 * t->S * sizeof(float);
+  HZ_REQUIRE(lds_bytes <= 160 * 1024, "hz_search_run: %zu B of LDS per workgroup exceed 160 KiB", lds_bytes);
+  static size_t configured = 0;
+  if (lds_bytes > configured) {
+    HZ_HIP(hipFuncSetAttribute((const void*)k_search, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    configured = lds_bytes;
+  }
+  SearchArgs a;
+  a.jobs = jobs; a.wstream = (const uint16_t*)wstream; a.bias = biases; a.act_tab = action_table;
+  a.pool = (uint16_t*)pool; a.plane_stride = plane_stride; a.row_stride = row_stride;
+  a.ix = ix; a.iy = iy; a.la = la; a.rew = rewards; a.val = values; a.pol = policy; a.sims = num_simulations;
+  hipLaunchKernelGGL(k_search, dim3((t->N + 15) / 16), dim3(1024), lds_bytes, (hipStream_t)stream, view(t), *H, a);
+  HZ_HIP(hipGetLastError());
+  t->next_entry = num_simulations + 1;
+  return 0;
+}

@@ -32,83 +32,7 @@ void hz_set_error(const char* fmt, ...) {
 extern "C" const char* hz_last_error(void) { return g_err; }
 extern "C" int hz_version(void) { return 1; }
 
-// ------------------------------------------------------------------------------------------ handle
-struct hz_tree {
-  int N, A, S, device;
-  int pb_c_base;
-  float pb_c_init, discount, delta;
-  uint64_t seed;
-  uint32_t id_base;
-  int params_set;
-  int next_entry;  // host-side guard: the entry the next backprop must create
-  float4* rec;
-  float* qsa;
-  int32_t* ref;
-  int32_t* path;
-  float4* prec;  // [N][S+1] the child record read at each depth of the last descent (what the backup will update)
-  int32_t* path_len;
-  int32_t* root_visit;
-  float* root_vsum;
-  float* mm_min;
-  float* mm_max;
-  int8_t* best_action;
-  float* pbc_tab;  // [S+1]: logf((n + base + 1) / base) + pb_c_init  for parent visit count n
-  int64_t bytes;
-};
-
-struct TreeView {
-  int N, A, S;
-  float discount, delta;
-  uint64_t seed;
-  uint32_t id_base;
-  float4* rec;
-  float* qsa;
-  int32_t* ref;
-  int32_t* path;
-  float4* prec;
-  int32_t* path_len;
-  int32_t* root_visit;
-  float* root_vsum;
-  float* mm_min;
-  float* mm_max;
-  int8_t* best_action;
-  const float* pbc_tab;
-};
-
-static TreeView view(const hz_tree* t) {
-  TreeView v;
-  v.N = t->N; v.A = t->A; v.S = t->S;
-  v.discount = t->discount; v.delta = t->delta; v.seed = t->seed; v.id_base = t->id_base;
-  v.rec = t->rec; v.qsa = t->qsa; v.ref = t->ref; v.path = t->path; v.prec = t->prec; v.path_len = t->path_len;
-  v.root_visit = t->root_visit; v.root_vsum = t->root_vsum; v.mm_min = t->mm_min; v.mm_max = t->mm_max;
-  v.best_action = t->best_action; v.pbc_tab = t->pbc_tab;
-  return v;
-}
-
-__device__ __forceinline__ uint32_t pack_vc(int visit, int child) { return ((uint32_t)visit << 16) | (uint32_t)(child + 1); }
-
-// masked softmax -> priors, the arithmetic of CNode::expand (cnode.cpp:49-114).
-// lane a holds logit a; `legal_mask` bit a set = legal.  Returns this lane's prior.
-__device__ __forceinline__ float expand_prior(float logit, uint64_t legal_mask, int lane, int A) {
-  const bool legal = (legal_mask >> lane) & 1ull;
-  // policy_max = max over legal, non-NaN logits, starting from FLOAT_MIN (cnode.cpp:59,68-78)
-  float m = (legal && logit == logit) ? logit : -INFINITY;
-  m = hz_wave_max(m);
-  const float policy_max = fmaxf(m, HZ_FLOAT_MIN);
-  const float tp = legal ? hz_expf(logit - policy_max) : 0.0f;  // cnode.cpp:87
-  // policy_sum: 1e-4 + terms in action order over the legal children (cnode.cpp:57,88)
-  float policy_sum = 0.0001f;
-  uint64_t mm = legal_mask;
-  while (mm) {
-    const int a = __ffsll((unsigned long long)mm) - 1;
-    mm &= mm - 1;
-    policy_sum += hz_readlane_f(tp, a);
-  }
-  float prior = legal ? tp / policy_sum : 0.0f;  // cnode.cpp:98-103
-  if (prior != prior) prior = 0.0f;              // cnode.cpp:107-109
-  (void)A;
-  return prior;
-}
+#include "hz_tree_dev.h"
 
 // ------------------------------------------------------------------------------------------ prepare
 // CRoots::prepare / prepare_no_noise (cnode.cpp:247-259): reset the tree, expand the root (hidden index (0, tree)),
@@ -159,351 +83,12 @@ __global__ __launch_bounds__(256) void k_prepare(TreeView tv, float frac, const 
   (void)rewards;  // the root's own reward is never read by the search (cnode.cpp:303,330 skip the root)
 }
 
-// ------------------------------------------------------------------------------------------ traverse
-// cmulti_traverse (cnode.cpp:407-441) with get_mean_q (:144-164), cselect_child (:346-374), cucb_score (:376-405)
-// and CMinMaxStats::normalize (cminimax.cpp:31-44).  Optionally fused with the hidden-state gather of
-// core/mcts.py:31-36.
-struct TraverseOut {
-  int32_t* ix;
-  int32_t* iy;
-  int32_t* la;
-  const uint8_t* pool;
-  uint8_t* net_in;
-  int row_bytes, net_in_stride_bytes, onehot_cols, dtype;
-};
-
-// one descent of one tree by one wave; mn / mx / root_visit are passed in registers so that the fused
-// backup+descent kernel does not have to re-read what it has just computed
-// Diagnostic build only (-DHZ_TREE_PROFILE, tools/tree_profile.py): s_memtime stamps of the wave that owns tree 400.
-#ifdef HZ_TREE_PROFILE
-__device__ unsigned long long hz_tree_prof[16];
-__device__ int hz_tree_prof_on;  // 1 while the wave of tree 400 runs the fused kernel (k_backprop shares the body)
-extern "C" int hz_tree_profile_read(unsigned long long* host) {
-  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(hz_tree_prof), sizeof(hz_tree_prof));
-}
-#define TP(i) do { if (tree == 400 && lane == 0 && hz_tree_prof_on) hz_tree_prof[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
-#define TP_ON(v) do { if (tree == 400 && lane == 0) hz_tree_prof_on = (v); } while (0)
-#else
-#define TP(i) do { } while (0)
-#define TP_ON(v) do { } while (0)
-#endif
-
-__device__ __forceinline__ void traverse_body(const TreeView& tv, int tree, int lane, int sim, float mn, float mx,
-                                              int root_visit, const TraverseOut& to, bool have_root, float4 root_row) {
-  const int A = tv.A, S = tv.S;
-  const bool on = lane < A;
-  const float discount = tv.discount;
-  const float delta = mx - mn;
-  const float4* rec = tv.rec + (size_t)tree * S * A;
-  int32_t* path = tv.path + (size_t)tree * (S + 1);
-  float4* prec = tv.prec + (size_t)tree * (S + 1);
-  // pb_c's first factor for every possible parent visit count, one per lane (S + 1 <= 64: no dependent table load
-  // on the critical path of a level); larger S falls back to the table in memory
-  const bool tab_in_regs = S < 64;
-  const float pbc_reg = (tab_in_regs && lane <= S) ? tv.pbc_tab[lane] : 0.0f;
-  const float sqrt_reg = sqrtf((float)lane + 1.0f);  // sqrt(parent visits + 1), same trick
-
-  int e = 0;
-  int pvc = root_visit;
-  bool is_root = true;
-  float parent_q = 0.0f;  // cnode.cpp:414 (0 whenever it is read, see oracle/ref_tree_harness.cpp)
-  int depth = 0;
-  int action = 0;
-  while (true) {
-    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (depth == 0 && have_root) r = root_row;  // already in registers (fused backup + descent)
-    else if (on) r = rec[(size_t)e * A + lane];
-    const uint32_t w = __float_as_uint(r.w);
-    const int visit = (int)(w >> 16);
-    const int child = (int)(w & 0xffffu) - 1;
-    float prior = r.x;
-    if (prior != prior) prior = 0.0f;  // cnode.cpp:379-381
-    const float val = (visit == 0) ? 0.0f : r.y / (float)visit;  // CNode::value cnode.cpp:180-189
-    const float qsa = r.z + discount * val;
-    // get_mean_q: sum over visited children in action order
-    uint64_t vm = __ballot(on && visit > 0);
-    const int nvis = __popcll((unsigned long long)vm);
-    float total = 0.0f;
-    while (vm) {
-      const int a = __ffsll((unsigned long long)vm) - 1;
-      vm &= vm - 1;
-      total += hz_readlane_f(qsa, a);
-    }
-    const bool root_mean = is_root && nvis > 0;  // cnode.cpp:228-236: the root leaves its own q out
-    const float mean_q = (root_mean ? total : parent_q + total) / (float)(root_mean ? nvis : nvis + 1);
-    is_root = false;
-    parent_q = mean_q;
-    // cucb_score
-    float pb_c = tab_in_regs ? hz_readlane_f(pbc_reg, pvc) : tv.pbc_tab[pvc];  // logf((n+base+1)/base) + pb_c_init
-    const float sq = tab_in_regs ? hz_readlane_f(sqrt_reg, pvc) : sqrtf((float)pvc + 1.0f);
-    pb_c = pb_c * (sq / (float)(visit + 1));  // cnode.cpp:386
-    const float prior_score = pb_c * prior;
-    float vs = (visit == 0) ? mean_q : qsa;
-    if (delta > 0.0f) vs = (vs - mn) / (delta < tv.delta ? tv.delta : delta);  // CMinMaxStats::normalize
-    if (vs < 0.0f) vs = 0.0f;
-    if (vs > 1.0f) vs = 1.0f;
-    const float score = prior_score + vs;
-    // cselect_child: final tie list = {first arg-max} U {later children within epsilon of the max}
-    const bool valid = on && (score == score) && (score > HZ_FLOAT_MIN);
-    const float M = hz_wave_max(valid ? score : -INFINITY);
-    const uint64_t eq = __ballot(valid && score == M);
-    action = 0;
-    if (eq != 0) {
-      const int first = __ffsll((unsigned long long)eq) - 1;
-      const float thr = M - 0.000001f;
-      uint64_t cand = __ballot(valid && score >= thr);
-      cand &= ~((1ull << first) - 1ull);
-      const uint32_t cnt = (uint32_t)__popcll((unsigned long long)cand);
-      if (cnt > 1) {  // (x % 1 == 0: the draw only matters when there is a tie)
-        const uint32_t rnd = hz_tiebreak_rand(tv.seed, tv.id_base + (uint32_t)tree, (uint32_t)sim, (uint32_t)depth);
-        uint32_t k = rnd % cnt;  // rand() % max_index_lst.size()  (cnode.cpp:369)
-        while (k--) cand &= cand - 1;
-      }
-      action = __ffsll((unsigned long long)cand) - 1;
-    }
-    action = hz_uniform(action);
-    if (lane == 0) {
-      tv.best_action[(size_t)tree * S + e] = (int8_t)action;  // node->best_action (cnode.cpp:426)
-      path[depth] = (e << 8) | action;
-    }
-    if (lane == action) prec[depth] = r;  // the record the coming backup updates: saves it a dependent load
-    const int child_e = hz_readlane_i(child, action);
-    const int child_visit = hz_readlane_i(visit, action);
-    ++depth;
-    TP(5 + (depth < 7 ? depth : 7));
-    if (child_e < 0 || depth >= S) break;  // leaf reached (second clause: defensive bound, never true)
-    e = child_e;
-    pvc = child_visit;
-  }
-  if (lane == 0) {
-    to.ix[tree] = e;     // parent->hidden_state_index_x (entry index == hidden_state_index_x)
-    to.iy[tree] = tree;  // parent->hidden_state_index_y
-    to.la[tree] = action;
-    tv.path_len[tree] = depth + 1;
-  }
-  if (to.pool != nullptr) {
-    // hidden_states[i] = hidden_state_pool[ix][iy]  (core/mcts.py:31-32), 16 B per lane per trip
-    const uint8_t* src = to.pool + ((size_t)e * tv.N + tree) * (size_t)to.row_bytes;
-    uint8_t* dst = to.net_in + (size_t)tree * (size_t)to.net_in_stride_bytes;
-    for (int off = lane * 16; off < to.row_bytes; off += 64 * 16)
-      *reinterpret_cast<uint4*>(dst + off) = *reinterpret_cast<const uint4*>(src + off);
-    // action_one_hot of MuZeroNet.dynamics (config/hanabi_control/model.py:215-219), appended after the state
-    for (int c = lane; c < to.onehot_cols; c += 64) {
-      const bool hot = (c == action);
-      if (to.dtype == HZ_F32) reinterpret_cast<float*>(dst + to.row_bytes)[c] = hot ? 1.0f : 0.0f;
-      else reinterpret_cast<uint16_t*>(dst + to.row_bytes)[c] = hot ? (to.dtype == HZ_BF16 ? 0x3f80u : 0x3c00u) : 0u;
-    }
-  }
-}
-
 __global__ __launch_bounds__(256) void k_traverse(TreeView tv, int sim, TraverseOut to) {
   const int lane = threadIdx.x & 63;
   const int tree = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: SALU addressing
   if (tree >= tv.N) return;
   traverse_body(tv, tree, lane, sim, tv.mm_min[tree], tv.mm_max[tree], tv.root_visit[tree], to, false,
                 make_float4(0.f, 0.f, 0.f, 0.f));
-}
-
-// ------------------------------------------------------------------------------------------ backprop
-// cmulti_back_propagate (cnode.cpp:337-344): expand (all legal) + cback_propagate (:317-335) + update_tree_q
-// (:296-315, here a wave min/max over the cached per-entry q values instead of a DFS of the whole tree).
-// Where the leaf's (reward, value, policy logits) come from.  Plain: three fp32 arrays (the cytree signature).
-// Fused: straight from the network heads -- categorical reward/value logits and policy logits in the net's dtype;
-// the kernel applies core/mcts.py:48-49 (NaN logits -> 0) and core/config.py:210-232 (softmax . support -> h^-1).
-struct NetOut {
-  const float* rewards;
-  const float* values;
-  const float* logits;
-  const void* reward_logits;
-  const void* value_logits;
-  const void* policy_logits;
-  long long reward_stride, value_stride, policy_stride;  // elements
-  int support_size, support_min, dtype;
-  float* out_rewards;
-  float* out_values;
-};
-
-__device__ __forceinline__ float load_as_f32(const void* p, long long i, int dtype) {
-  if (dtype == HZ_F32) return ((const float*)p)[i];
-  const uint16_t h = ((const uint16_t*)p)[i];
-  if (dtype == HZ_BF16) return __uint_as_float((uint32_t)h << 16);
-  return (float)(*reinterpret_cast<const _Float16*>(&h));
-}
-
-__device__ __forceinline__ float hz_wave_sum(float v) {
-  v = hz_row16_sum(v);
-  return (hz_readlane_f(v, 0) + hz_readlane_f(v, 16)) + (hz_readlane_f(v, 32) + hz_readlane_f(v, 48));
-}
-
-// inverse_scalar_transform (core/config.py:210-232, delta = 1, epsilon = 0.001) of one row of V categorical
-// logits over the integer support [support_min, support_min + V), by one wave.  Tolerance-level arithmetic (this is
-// a network output, north-star tolerance 1e-3); the tree arithmetic that consumes the scalar stays exact.
-__device__ __forceinline__ float support_to_scalar(const void* row, int V, int support_min, int dtype, int lane) {
-  float m = -INFINITY, se = 0.0f, sw = 0.0f;
-  if (V <= 256) {  // the Hanabi supports (51 / 201 bins): every logit is read once and kept in registers
-    float x[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int i = lane + 64 * k;
-      x[k] = (i < V) ? load_as_f32(row, i, dtype) : -INFINITY;
-      m = fmaxf(m, x[k]);
-    }
-    m = hz_wave_max(m);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int i = lane + 64 * k;
-      const float e = (i < V) ? __expf(x[k] - m) : 0.0f;
-      se += e;
-      sw += e * (float)(support_min + i);
-    }
-  } else {
-    for (int i = lane; i < V; i += 64) m = fmaxf(m, load_as_f32(row, i, dtype));
-    m = hz_wave_max(m);
-    for (int i = lane; i < V; i += 64) {
-      const float e = __expf(load_as_f32(row, i, dtype) - m);
-      se += e;
-      sw += e * (float)(support_min + i);
-    }
-  }
-  se = hz_wave_sum(se);
-  sw = hz_wave_sum(sw);
-  const float v = sw / se;
-  const float eps = 0.001f;
-  const float t = (sqrtf(1.0f + 4.0f * eps * (fabsf(v) + 1.0f + eps)) - 1.0f) / (2.0f * eps);
-  float out = t * t - 1.0f;
-  if (v < 0.0f) out = -out;
-  if (out != out) out = 0.0f;  // nan_part -> 0 (config.py:229-232)
-  return out;
-}
-
-// one tree's expand + backup + min-max by one wave; returns the new (min, max, root visit count) in registers
-template <bool FUSED>
-__device__ __forceinline__ void backprop_body(const TreeView& tv, int tree, int lane, int wave, float* lds_q, int e_new,
-                                              const NetOut& no, float& out_mn, float& out_mx, int& out_root_visit,
-                                              float4& out_first_rec, int& out_first_action) {
-  const int A = tv.A, S = tv.S;
-  const bool on = lane < A;
-  const float discount = tv.discount;
-  float4* rec = tv.rec + (size_t)tree * S * A;
-  const int32_t* path = tv.path + (size_t)tree * (S + 1);
-  float* lq = lds_q + wave * S;
-
-  // the path's first 64 edges and the records the descent read there, fetched before path_len is known (the buffers
-  // hold S+1 slots per tree, so this never leaves them): every load of this function is issued up front, independent
-  int pr0 = 0;
-  float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (lane <= S) {
-    pr0 = path[lane];
-    r0 = tv.prec[(size_t)tree * (S + 1) + lane];  // == rec[entry][action] as the descent read it
-  }
-  const float old_root_vsum = tv.root_vsum[tree];
-  const int old_root_visit = tv.root_visit[tree];
-  // stage the cached q of entries 1..e_new-1 in LDS (coalesced), entry e_new is produced below
-  for (int e = 1 + lane; e < e_new; e += 64) lq[e] = tv.qsa[(size_t)tree * S + e];
-
-  // expand the leaf: priors of the new entry's children
-  float logit = 0.0f;
-  if (on) {
-    if (FUSED) {
-      logit = load_as_f32(no.policy_logits, (long long)tree * no.policy_stride + lane, no.dtype);
-      if (logit != logit) logit = 0.0f;  // core/mcts.py:48-49
-    } else {
-      logit = no.logits[(size_t)tree * A + lane];
-    }
-  }
-  const uint64_t all = (A >= 64) ? ~0ull : ((1ull << A) - 1ull);
-  const float prior = expand_prior(logit, all, lane, A);
-  TP(1);
-  if (on) {
-    float4 r;
-    r.x = prior; r.y = 0.0f; r.z = 0.0f; r.w = __uint_as_float(pack_vc(0, -1));
-    rec[(size_t)e_new * A + lane] = r;
-  }
-
-  const int npairs = tv.path_len[tree] - 1;  // edges on the path; the node below edge k is at depth k+1
-  float G, leaf_reward;                      // bootstrap_value (cnode.cpp:318) and the leaf's reward
-  if (FUSED) {
-    const int es = (no.dtype == HZ_F32) ? 4 : 2;
-    const uint8_t* vrow = (const uint8_t*)no.value_logits + (size_t)tree * (size_t)no.value_stride * es;
-    const uint8_t* rrow = (const uint8_t*)no.reward_logits + (size_t)tree * (size_t)no.reward_stride * es;
-    G = support_to_scalar(vrow, no.support_size, no.support_min, no.dtype, lane);
-    leaf_reward = support_to_scalar(rrow, no.support_size, no.support_min, no.dtype, lane);
-    if (lane == 0) {
-      if (no.out_values) no.out_values[tree] = G;
-      if (no.out_rewards) no.out_rewards[tree] = leaf_reward;
-    }
-  } else {
-    G = no.values[tree];
-    leaf_reward = no.rewards[tree];
-  }
-  TP(2);
-  int pr = 0;
-  float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int base = ((npairs - 1) >> 6) << 6; base >= 0; base -= 64) {
-    const int k = base + lane;
-    const bool act = k < npairs;
-    if (base == 0) {
-      pr = pr0;
-      r = r0;
-    } else if (act) {
-      pr = path[k];
-      r = tv.prec[(size_t)tree * (S + 1) + k];
-    }
-    uint32_t w = __float_as_uint(r.w);
-    int visit = (int)(w >> 16);
-    int child = (int)(w & 0xffffu) - 1;
-    if (act && k == npairs - 1) {  // the leaf: CNode::expand sets reward and hidden index (cnode.cpp:50-53)
-      r.z = leaf_reward;
-      child = e_new;
-      tv.ref[(size_t)tree * S + e_new] = pr;
-    }
-    // the backup chain, deepest node first: value_sum += G; G = reward + discount * G   (cnode.cpp:320-331)
-    float myG = 0.0f;
-    const int hi = min(npairs - 1 - base, 63);
-    for (int j = hi; j >= 0; --j) {
-      const float rj = hz_readlane_f(r.z, j);
-      if (lane == j) myG = G;
-      G = rj + discount * G;
-    }
-    if (act) {
-      r.y += myG;
-      visit += 1;
-      r.w = __uint_as_float(pack_vc(visit, child));
-      rec[(size_t)(pr >> 8) * A + (pr & 255)] = r;
-      const float q = r.z + discount * (r.y / (float)visit);  // update_tree_q's qsa (cnode.cpp:304)
-      lq[child] = q;
-      tv.qsa[(size_t)tree * S + child] = q;
-    }
-  }
-  TP(3);
-  // the loop ends with the chunk that holds path edge 0 in lane 0: the root's child record as just stored
-  out_first_rec.x = hz_readlane_f(r.x, 0);
-  out_first_rec.y = hz_readlane_f(r.y, 0);
-  out_first_rec.z = hz_readlane_f(r.z, 0);
-  out_first_rec.w = hz_readlane_f(r.w, 0);
-  out_first_action = __builtin_amdgcn_readfirstlane(pr) & 255;
-  const float new_root_vsum = old_root_vsum + G;  // the root (search_path[0])
-  out_root_visit = old_root_visit + 1;
-  if (lane == 0) {
-    tv.root_vsum[tree] = new_root_vsum;
-    tv.root_visit[tree] = out_root_visit;
-  }
-  // min_max_stats.clear(); update_tree_q(root): every expanded non-root node contributes (cnode.cpp:332-334)
-  float vmax = -INFINITY, vmin = INFINITY;
-  for (int e = 1 + lane; e <= e_new; e += 64) {
-    const float q = lq[e];  // same-wave LDS traffic is processed in order: sees the stores above
-    if (q == q) {
-      vmax = fmaxf(vmax, q);
-      vmin = fminf(vmin, q);
-    }
-  }
-  out_mx = fmaxf(hz_wave_max(vmax), HZ_FLOAT_MIN);  // CMinMaxStats::update from the cleared state (cminimax.cpp:17-29)
-  out_mn = fminf(hz_wave_min(vmin), HZ_FLOAT_MAX);
-  if (lane == 0) {
-    tv.mm_max[tree] = out_mx;
-    tv.mm_min[tree] = out_mn;
-  }
-  TP(4);
 }
 
 template <bool FUSED>

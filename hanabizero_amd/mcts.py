@@ -15,8 +15,9 @@ from .model import InferenceEngine
 
 
 class MCTS(object):
-    def __init__(self, config):
+    def __init__(self, config, persistent=True):
         self.config = config
+        self.persistent = persistent  # fused engines: the whole simulation loop as one persistent kernel
 
     def run_multi(self, roots, model, hidden_state_roots, pool=None):
         """roots: hanabizero_amd.cytree.Roots (already prepared).  model: an InferenceEngine (fast path) or a
@@ -42,6 +43,11 @@ class MCTS(object):
                 rew = torch.empty(num, dtype=torch.float32, device=roots.device)
                 val = torch.empty(num, dtype=torch.float32, device=roots.device)
                 pol = torch.empty((num, roots.action_num), dtype=torch.float32, device=roots.device)
+                fused16 = model.fused_shape(16, 2) if self.persistent else None
+                if fused16 is not None and fused16.lds_bytes(16) + 64 * S <= 160 * 1024:
+                    # the whole loop below as ONE persistent kernel: a workgroup keeps 16 trees for all simulations
+                    roots.search_tensors(fused16, pool, S - 1, rew, val, pol)
+                    return
                 # 2 launches per simulation: [MFMA recurrent inference] [backup of sim k + descent of sim k+1]
                 ix, _, la = roots.traverse_tensors()  # the MFMA kernel gathers pool[ix, tree] itself
                 for index_simulation in range(S - 1):

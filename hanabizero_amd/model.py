@@ -276,6 +276,15 @@ class InferenceEngine:
             self.bw3 = self._stack([_fold(rw[3]), _fold(ac[3]), _fold(va[3])], self.out_pad, False)
         self.V = 2 * self.support + 1
         self.fused = FusedRecurrent(net, self) if self.use_fused else None
+        self._net, self._fused_shapes = net, {(4, 4): self.fused}
+
+    def fused_shape(self, waves, tiles):
+        """The fused recurrent inference laid out for another workgroup shape (16 x 2: the persistent search kernel)."""
+        if not self.use_fused:
+            return None
+        if (waves, tiles) not in self._fused_shapes:
+            self._fused_shapes[(waves, tiles)] = FusedRecurrent(self._net, self, waves, tiles)
+        return self._fused_shapes[(waves, tiles)]
 
     def _stack(self, folded, out_width, carry_one):
         """[(W [o, h], b [o])] * 3 -> Wt [3, hp, out_width] in the engine dtype for torch.bmm over the three head
@@ -400,17 +409,18 @@ class InferenceEngine:
 MLP_RELU, MLP_ACTION_ROW, MLP_BARRIER, MLP_STORE_HIDDEN = 1, 2, 4, 8  # include/hz_mlp.h flags
 
 
-def _pack_fragments(w64, ks):
-    """W [<=64, <=32*ks] fp32 -> [ks][4 tiles][64 lanes][8] (the A-operand fragments of v_mfma_f32_16x16x32_bf16:
-    lane l of tile t at k-step s holds W[16t + (l & 15)][32s + 8(l >> 4) + j], j = 0..7), flattened."""
-    Wp = torch.zeros(64, 32 * ks)
-    Wp[:w64.shape[0], :w64.shape[1]] = w64
+def _pack_fragments(wblk, ks, tiles=4):
+    """W [<=16*tiles, <=32*ks] fp32 -> [ks][tiles][64 lanes][8] (the A-operand fragments of
+    v_mfma_f32_16x16x32_bf16: lane l of tile t at k-step s holds W[16t + (l & 15)][32s + 8(l >> 4) + j], j = 0..7),
+    flattened."""
+    Wp = torch.zeros(16 * tiles, 32 * ks)
+    Wp[:wblk.shape[0], :wblk.shape[1]] = wblk
     s = torch.arange(ks).view(ks, 1, 1, 1)
-    t = torch.arange(4).view(1, 4, 1, 1)
+    t = torch.arange(tiles).view(1, tiles, 1, 1)
     lane = torch.arange(64).view(1, 1, 64, 1)
     j = torch.arange(8).view(1, 1, 1, 8)
-    n = (16 * t + (lane & 15)).expand(ks, 4, 64, 8)
-    k = (32 * s + 8 * (lane >> 4) + j).expand(ks, 4, 64, 8)
+    n = (16 * t + (lane & 15)).expand(ks, tiles, 64, 8)
+    k = (32 * s + 8 * (lane >> 4) + j).expand(ks, tiles, 64, 8)
     return Wp[n, k].reshape(-1)
 
 
@@ -422,25 +432,30 @@ class FusedRecurrent:
     __call__(pool [S, N, H] bf16, ix [N] i32, actions [N] i32, hidden_out [N, H] bf16, out_reward [N], out_value [N],
              out_policy [N, A])   (fp32 outputs; buffers supplied by the caller, nothing is allocated)"""
 
-    def __init__(self, net, engine):
+    def __init__(self, net, engine, waves=4, tiles=4):
+        """waves x tiles: the workgroup shape of the kernel -- `waves` wavefronts, each producing `tiles` 16-column
+        MFMA tiles per job (4 x 4 stand-alone, 16 x 2 inside the persistent search kernel).  Same arithmetic per
+        output column either way (k accumulates in the same order), so the two shapes give identical bits."""
         from ._lib import MlpHeader, MlpJob
         assert engine.dtype == torch.bfloat16, "the fused kernel computes in bf16 (fp32 accumulate)"
-        self.engine, self.device = engine, engine.device
+        assert (waves, tiles) in ((4, 4), (8, 4), (8, 2), (16, 2))
+        self.engine, self.device, self.waves, self.tiles = engine, engine.device, waves, tiles
+        cw = 16 * tiles        # output columns of one job
         H, A, h, full, V = engine.H, engine.A, engine.h, engine.full, 2 * engine.support + 1
         dyn, rw, ac, va = net._dynamics_state, net._dynamics_reward, net._prediction_actor, net._prediction_value
         jobs = []              # [pass][wave] -> dict or None
-        streams = [[], [], [], []]
-        bias_chunks = []       # 64-float chunks
+        streams = [[] for _ in range(waves)]
+        bias_chunks = []       # cw-float chunks
         act_rows = []          # (bias chunk index, [A, 64] block)
 
         def add_dense(w, b, K, src_off, dst_off, relu, res_off=None, barrier=True, store_hidden=False, act_w=None):
-            """out[:, dst_off:dst_off+nout] = act(in[:, src_off:src_off+K] @ w^T + b ...), nout split into 64-column
-            wave jobs, 4 per pass."""
+            """out[:, dst_off:dst_off+nout] = act(in[:, src_off:src_off+K] @ w^T + b ...), nout split into cw-column
+            wave jobs, `waves` per pass."""
             nout = w.shape[0]
-            chunks = [(c, min(64, nout - c)) for c in range(0, nout, 64)]
-            for p0 in range(0, len(chunks), 4):
+            chunks = [(c, min(cw, nout - c)) for c in range(0, nout, cw)]
+            for p0 in range(0, len(chunks), waves):
                 row = []
-                for wave in range(4):
+                for wave in range(waves):
                     if p0 + wave >= len(chunks):
                         row.append(None)
                         continue
@@ -451,12 +466,15 @@ class FusedRecurrent:
                 jobs.append(dict(entries=row, barrier=barrier and p0 == 0, store_hidden=store_hidden and p0 == 0))
 
         def add_group(items, K, barrier=True):
-            """one pass: wave g runs its own (w [<=64.., K], b, src, dst, res, relu) job; items may hold > 4 jobs."""
-            for p0 in range(0, len(items), 4):
-                row = [None] * 4
-                for wave, it in enumerate(items[p0:p0 + 4]):
-                    w, b, src, dst, res, relu = it
-                    row[wave] = dict(w=w, b=b, ks=K // 32, src=src, dst=dst, res=res, relu=relu, act=None)
+            """independent small layers (w, b, src, dst, res, relu) side by side: cut into cw-column jobs, `waves`
+            per pass."""
+            cut = []
+            for w, b, src, dst, res, relu in items:
+                for c in range(0, w.shape[0], cw):
+                    cut.append(dict(w=w[c:c + cw], b=b[c:c + cw], ks=K // 32, src=src, dst=dst + c,
+                                    res=None if res is None else res + c, relu=relu, act=None))
+            for p0 in range(0, len(cut), waves):
+                row = cut[p0:p0 + waves] + [None] * (waves - len(cut[p0:p0 + waves]))
                 jobs.append(dict(entries=row, barrier=barrier and p0 == 0, store_hidden=False))
 
         X, Y0, Y1 = 0, H, 2 * H
@@ -500,18 +518,27 @@ class FusedRecurrent:
             add_group([(w, b, src, dst, None, False) for (w, b), src, dst in outs], kpad)
             off_r, off_p, off_v, width = X, X + 64, X + 128, 3 * H
         rs = width + ((8 - width) % 128)
-        # flatten: job table, per-wave weight streams, biases, action table
+        # flatten: job table, per-wave weight streams, biases, action table.  A pass with fewer jobs than waves goes to
+        # the waves that have streamed the least so far (the kernel is bound by the CU's weight stream: every wave
+        # should carry the same share of it and none should idle through whole layers)
         table = []
+        load = [0] * waves
         for job in jobs:
-            for wave, e in enumerate(job["entries"]):
+            ents = [e for e in job["entries"] if e is not None]
+            order = sorted(range(waves), key=lambda w: (load[w], w))[:len(ents)]
+            row = [None] * waves
+            for w, e in zip(sorted(order), ents):
+                row[w] = e
+                load[w] += e["ks"]
+            for wave, e in enumerate(row):
                 flags = (MLP_BARRIER if job["barrier"] else 0) | (MLP_STORE_HIDDEN if job["store_hidden"] else 0)
                 if e is None:
                     table.append(MlpJob(ks=0, src_off=0, dst_off=0, res_off=-1, bias_off=0, flags=flags))
                     continue
                 assert e["ks"] % 8 == 0, "K must be a multiple of 256 (8 k-steps)"
-                streams[wave].append(_pack_fragments(e["w"], e["ks"]))
-                bias_off = 64 * len(bias_chunks)
-                bc = torch.zeros(64)
+                streams[wave].append(_pack_fragments(e["w"], e["ks"], tiles))
+                bias_off = cw * len(bias_chunks)
+                bc = torch.zeros(cw)
                 bc[:e["b"].shape[0]] = e["b"]
                 bias_chunks.append(bc)
                 if e["act"] is not None:
@@ -523,19 +550,19 @@ class FusedRecurrent:
                                     res_off=-1 if e["res"] is None else e["res"], bias_off=bias_off, flags=flags))
         biases = torch.cat(bias_chunks)
         act_table = torch.zeros(A + 1, biases.numel())      # row A stays zero: what jobs without an action row add
-        for off, blk in act_rows:                           # blk [n <= 64, A] = columns of the action block
+        for off, blk in act_rows:                           # blk [n <= cw, A] = columns of the action block
             act_table[:A, off:off + blk.shape[0]] = blk.t()
-        pad = torch.zeros(8 * 4 * 64 * 8)                   # 8 k-steps of zeros behind each stream (ring overrun)
+        pad = torch.zeros(8 * tiles * 64 * 8)               # 8 k-steps of zeros behind each stream (ring overrun)
         offs, parts, cur = [], [], 0
-        for wave in range(4):
+        for wave in range(waves):
             offs.append(cur)
             st = torch.cat(streams[wave] + [pad])
             parts.append(st)
             cur += st.numel()
         hdr = MlpHeader(n_jobs=len(jobs), row_stride=rs, hidden=H, state_off=X, hidden_off=Y0, off_reward=off_r,
                         off_value=off_v, off_policy=off_p, support_size=V, support_min=-engine.support, num_actions=A,
-                        action_table_stride=biases.numel())
-        for wave in range(4):
+                        action_table_stride=biases.numel(), num_waves=waves, tiles_per_wave=tiles)
+        for wave in range(waves):
             hdr.wave_stream_off[wave] = offs[wave]
         import ctypes as C
         self.header = hdr

@@ -34,7 +34,8 @@ enum {
   HZ_MLP_STORE_HIDDEN = 8   /* after that barrier copy LDS columns [hidden_off, hidden_off+hidden) to hidden_out */
 };
 
-/* One (job, wave) entry; all offsets are bf16-element columns of the LDS row image.  ks == 0: this wave idles. */
+/* One (job, wave) entry; all offsets are bf16-element columns of the LDS row image.  ks == 0: this wave idles.
+ * "64" below is 16 * tiles_per_wave: 64 columns per job with 4 waves x 4 tiles, 32 with 16 waves x 2 tiles. */
 typedef struct {
   int32_t ks;        /* k-steps of 32 inputs; multiple of 8 (pad K with zero weights) */
   int32_t src_off;   /* first input column */
@@ -54,10 +55,12 @@ typedef struct {
   int32_t off_reward, off_value, off_policy; /* LDS columns of the final reward / value / policy logits */
   int32_t support_size, support_min, num_actions;
   int32_t action_table_stride;   /* fp32 elements per action row */
-  int64_t wave_stream_off[4];    /* element offset of each wave's weight stream inside `wstream` */
+  int32_t num_waves;             /* 4 (stand-alone kernel) or 16 (inside hz_search_run) */
+  int32_t tiles_per_wave;        /* 16-column MFMA tiles per job: 4 with 4 waves, 2 with 16 waves */
+  int64_t wave_stream_off[16];   /* element offset of each wave's weight stream inside `wstream` */
 } hz_mlp_header_t;
 
-/* jobs        [n_jobs][4] hz_mlp_job_t (DEVICE)
+/* jobs        [n_jobs][num_waves] hz_mlp_job_t (DEVICE)
  * wstream     packed bf16 weight streams (DEVICE; each stream followed by >= 8 k-steps of zero padding)
  * biases      fp32 (DEVICE), action_table [num_actions + 1][action_table_stride] fp32 (DEVICE; last row all zero)
  * state rows  row i is read from state_src + plane_index[i]*plane_stride + i*row_stride (bf16 elements);

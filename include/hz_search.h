@@ -1,0 +1,39 @@
+/* hz_search.h -- C ABI of the persistent search kernel (libhanabizero_hip.so).
+ *
+ * What it replaces: the whole simulation loop of MCTS.run_multi (/root/reference/core/mcts.py:26-58) -- for every
+ * simulation multi_traverse (cytree.pyx:97-101), the hidden-state gather (mcts.py:31-36), recurrent_inference
+ * (core/model.py:74-84) and multi_back_propagate (cytree.pyx:87-94) -- for all trees, as ONE kernel launch per move.
+ * A workgroup owns 16 trees for the whole search: one wavefront per tree for descent / expand / backup (the code of
+ * hz_tree_traverse / hz_tree_backprop), all 16 wavefronts together for the fused MFMA inference of those 16 rows (the
+ * code of hz_mlp_recurrent, 16 waves x 2 tiles).  Results are bit-identical to the launch-per-phase path
+ * (hz_tree_traverse -> hz_mlp_recurrent -> hz_tree_backprop_traverse ...): same arithmetic, same order.
+ * Conventions as include/hz_tree.h.
+ */
+#ifndef HZ_SEARCH_H
+#define HZ_SEARCH_H
+
+#include <stdint.h>
+
+#include "hz_mlp.h"
+#include "hz_tree.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* t                freshly prepared tree (hz_tree_prepare), parameters set (hz_tree_set_params)
+ * num_simulations  simulations to run: the reference runs config.num_simulations - 1 (core/mcts.py:27-29)
+ * H, jobs, wstream, biases, action_table   the MLP as for hz_mlp_recurrent, laid out for num_waves = 16, tiles = 2
+ * pool             [>= num_simulations + 1][N][hidden] bf16 (DEVICE), plane 0 = the roots' hidden states; plane k+1
+ *                  receives the hidden states simulation k produces; plane_stride / row_stride in elements
+ * ix, iy, la       [N] i32 scratch (DEVICE): on return the values of the last simulation
+ * rewards, values  [N] f32 scratch; policy [N][num_actions] f32 scratch: leaf outputs of the last simulation */
+int hz_search_run(hz_tree_t* t, int num_simulations, const hz_mlp_header_t* H, const hz_mlp_job_t* jobs,
+                  const void* wstream, const float* biases, const float* action_table, void* pool,
+                  int64_t plane_stride, int64_t row_stride, int32_t* ix, int32_t* iy, int32_t* la, float* rewards,
+                  float* values, float* policy, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HZ_SEARCH_H */

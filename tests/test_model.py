@@ -176,3 +176,29 @@ def test_fused_mfma_recurrent_kernel(game, N):
     assert err(h[:B], torch.from_numpy(fx["rec_hidden"]).cuda()) < 6e-2
     assert err(v[:B], torch.from_numpy(fx["rec_value"]).reshape(-1).cuda()) < 8e-2
     assert err(p[:B], torch.from_numpy(fx["rec_logits"]).cuda()) < 6e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("game", ["Hanabi-Small", "Hanabi-Full"])
+@pytest.mark.parametrize("shape", [(8, 4), (16, 2)])
+def test_fused_mfma_kernel_workgroup_shapes_give_identical_bits(game, shape):
+    """The same layer chain cut for another workgroup shape (16 waves x 2 tiles: the persistent search kernel) sums
+    every output column over k in the same order, so nothing may differ from the 4 x 4 kernel."""
+    from hanabizero_amd.model import InferenceEngine
+    net, fx, sup = build(game)
+    eng = InferenceEngine(net, sup, dtype=torch.bfloat16, device="cuda")
+    N, S = 1000, 4
+    g = torch.Generator(device="cuda").manual_seed(5)
+    pool = (torch.rand(S, N, eng.H, device="cuda", generator=g) * 2).to(torch.bfloat16)
+    ix = torch.randint(0, S, (N,), device="cuda", generator=g).to(torch.int32)
+    act = torch.randint(0, eng.A, (N,), device="cuda", generator=g).to(torch.int32)
+    outs = []
+    for sh in ((4, 4), shape):
+        f = eng.fused_shape(*sh)
+        h = torch.zeros(N, eng.H, dtype=torch.bfloat16, device="cuda")
+        r, v, p = torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda"), torch.zeros(N, eng.A, device="cuda")
+        f(pool, ix, act, h, r, v, p)
+        outs.append((h, r, v, p))
+    torch.cuda.synchronize()
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)

@@ -179,3 +179,32 @@ def test_select_action_kernel_edge_cases():
     assert abs(float(ent[1]) - np.log2(11)) < 1e-12 and float(ent[0]) == 0.0
     check(lib.hz_select_action(N, A, counts.data_ptr(), legal.data_ptr(), u.data_ptr(), 1.0, 1, act.data_ptr(), None, s), "x")
     assert act.tolist() == [10, 0, -1, 1, 0]
+
+
+@pytest.mark.parametrize("game,N,sims", [("Hanabi-Small", 100, 12), ("Hanabi-Full", 50, 50), ("Hanabi-Full", 1000, 20)])
+def test_persistent_search_kernel_equals_launch_per_phase(game, N, sims):
+    """hz_search_run (all simulations in one persistent kernel, a workgroup per 16 trees) against the launch-per-phase
+    search (hz_tree_traverse -> hz_mlp_recurrent -> hz_tree_backprop_traverse ...): bit-identical trees, hidden-state
+    pools and leaf outputs; the launch-per-phase path itself is pinned to the oracle by the tests above."""
+    from hanabizero_amd import cytree
+    from hanabizero_amd.mcts import MCTS
+    cfg, eng, actor = make(game, N, sims, 2, torch.bfloat16, use_graph=False)
+    A = cfg.action_space_size
+    g = torch.Generator(device="cuda").manual_seed(N)
+    value0, logits0, hidden0 = eng.initial(actor.stack_buf.view(N, -1))
+    noise = torch.rand(N, A, device="cuda", generator=g)
+    noise = noise / noise.sum(1, keepdim=True)
+    res = []
+    for persistent in (False, True):
+        roots = cytree.Roots(N, A, sims, tie_seed=5, tree_id_base=17)
+        roots.prepare(cfg.root_exploration_fraction, noise, torch.zeros(N, device="cuda"), logits0, actor.legal)
+        pool = torch.zeros(sims, N, eng.H, dtype=eng.dtype, device="cuda")
+        MCTS(cfg, persistent=persistent).run_multi(roots, eng, hidden0, pool=pool)
+        torch.cuda.synchronize()
+        res.append((roots.distributions_tensor(), roots.values_tensor(), roots.trajectories_tensor(),
+                    roots.minmax_tensors(), roots.path_len_tensor(), pool))
+    a, b = res
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[4], b[4])
+    assert torch.equal(a[3][0], b[3][0]) and torch.equal(a[3][1], b[3][1])
+    assert torch.equal(a[5], b[5])
+    assert int(a[0].sum()) == N * (sims - 1)

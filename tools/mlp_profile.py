@@ -26,9 +26,10 @@ def main():
     from hanabizero_amd.config import make_config
     game = sys.argv[1] if len(sys.argv) > 1 else "Hanabi-Full"
     N = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+    waves, tiles = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (4, 4)
     cfg = make_config(game, simulations=50, stack=4)
     eng = bench.build_engine(cfg, torch.bfloat16, "cuda")
-    f = eng.fused
+    f = eng.fused_shape(waves, tiles)
     hid = torch.rand(N, eng.H, device="cuda").to(torch.bfloat16)
     act = torch.randint(0, eng.A, (N,), device="cuda", dtype=torch.int32)
     h = torch.empty(N, eng.H, dtype=torch.bfloat16, device="cuda")
@@ -44,13 +45,13 @@ def main():
                                   r.data_ptr(), v.data_ptr(), p.data_ptr(), N, mt, C.c_void_p(torch.cuda.current_stream().cuda_stream))
         assert rc == 0
     torch.cuda.synchronize()
-    prof = np.zeros(32, np.uint64)
+    prof = np.zeros(128, np.uint64)
     lib.hz_mlp_profile_read(prof.ctypes.data_as(V))
     print("%s N=%d rows/WG=%d  (shader cycles of workgroup 100)" % (game, N, mt))
-    for w in range(4):
+    for w in range(waves):
         o = prof[w * 8:w * 8 + 8]
-        print("  wave %d: staging %6d | barriers %6d | job prologues %6d | k-loops %6d | epilogues %6d | final %6d | total %6d" % (
-            w, o[0], o[1], o[2], o[3], o[4], o[5], o[6]))
+        print("  wave %d: staging %6d | barriers %6d | job prologues %6d | k-loops %6d | epilogues %6d | final %6d | total %6d | k-steps %4d" % (
+            w, o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7]))
 
 
 if __name__ == "__main__":

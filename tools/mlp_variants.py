@@ -11,9 +11,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-VARIANTS = [("baseline", []), ("no epilogues", ["-DHZ_MLP_X_NOEPI"]), ("no final stage", ["-DHZ_MLP_X_NOFINAL"]),
-            ("no staging", ["-DHZ_MLP_X_NOSTAGE"]), ("ring 4", ["-DHZ_RING=4"]),
-            ("no epi/final/staging", ["-DHZ_MLP_X_NOEPI", "-DHZ_MLP_X_NOFINAL", "-DHZ_MLP_X_NOSTAGE"])]
+STRIP = ["-DHZ_MLP_X_NOEPI", "-DHZ_MLP_X_NOFINAL", "-DHZ_MLP_X_NOSTAGE"]
+VARIANTS = [("baseline", []), ("ring 8", ["-DHZ_RING=8"]), ("ring 8 no epi/final/staging", STRIP + ["-DHZ_RING=8"])]
+SHAPES = [(8, 2), (16, 2)]
 
 
 def main():
@@ -23,7 +23,6 @@ def main():
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     cfg = make_config("Hanabi-Full", simulations=50, stack=4)
     eng = bench.build_engine(cfg, torch.bfloat16, "cuda")
-    f = eng.fused
     S = 8
     pool = torch.rand(S, N, eng.H, device="cuda").to(torch.bfloat16)
     ix = torch.randint(0, S, (N,), device="cuda", dtype=torch.int32)
@@ -32,8 +31,8 @@ def main():
     r, v, p = torch.empty(N, device="cuda"), torch.empty(N, device="cuda"), torch.empty(N, eng.A, device="cuda")
     V, I, I64 = C.c_void_p, C.c_int, C.c_int64
     src = os.path.join(ROOT, "hanabizero_amd", "csrc")
-    mt = f.rows_per_wg(N)
-    for name, flags in VARIANTS:
+    for name, flags, f in [(n + " %dx%d" % sh, fl, eng.fused_shape(*sh)) for sh in SHAPES for n, fl in VARIANTS]:
+        mt = f.rows_per_wg(N)
         out = os.path.join(ROOT, "gpurun_out", "libmlp_var_%s.so" % "".join(c for c in name if c.isalnum()))
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                                "-ffp-contract=off", "-w", "-I" + src, "-I" + os.path.join(ROOT, "include"), "-o", out,
@@ -63,7 +62,7 @@ def main():
                 g.replay()
             e1.record()
             torch.cuda.synchronize()
-        print("%-24s %7.2f us/launch" % (name, e0.elapsed_time(e1) * 1e3 / 100), flush=True)
+        print("%-40s %7.2f us/launch" % (name, e0.elapsed_time(e1) * 1e3 / 100), flush=True)
 
 
 if __name__ == "__main__":
