@@ -29,9 +29,10 @@ struct SearchArgs {
   int sims;                // simulations to run (S - 1, as the reference)
 };
 
-// The three phases are separate functions (not inlined): each gets its own register allocation inside the 128 VGPRs a
-// wave of a 1024-thread workgroup may use, instead of one allocation spanning both bodies (which spills).
-__device__ __noinline__ void search_first_descent(const TreeView& tv, const SearchArgs& a, int tree, int lane) {
+// (The phases must be inlined into the kernel: through a real call the compiler loses the address space of every
+// pointer -- flat loads, which count against both wait counters and break the MFMA loop's pipelining -- and the
+// uniformity of every scalar.  The price is a few loop-invariant registers spilled across the phase boundaries.)
+__device__ __forceinline__ void search_first_descent(const TreeView& tv, const SearchArgs& a, int tree, int lane) {
   TraverseOut to;
   to.ix = a.ix; to.iy = a.iy; to.la = a.la;
   to.pool = nullptr; to.net_in = nullptr; to.row_bytes = 0; to.net_in_stride_bytes = 0; to.onehot_cols = 0; to.dtype = 0;
@@ -39,7 +40,7 @@ __device__ __noinline__ void search_first_descent(const TreeView& tv, const Sear
                 make_float4(0.f, 0.f, 0.f, 0.f));
 }
 
-__device__ __noinline__ void search_backup_descent(const TreeView& tv, const SearchArgs& a, int tree, int lane, int wave,
+__device__ __forceinline__ void search_backup_descent(const TreeView& tv, const SearchArgs& a, int tree, int lane, int wave,
                                                    float* lds_q, int sim, bool more) {
   TraverseOut to;
   to.ix = a.ix; to.iy = a.iy; to.la = a.la;
@@ -62,7 +63,7 @@ __device__ __noinline__ void search_backup_descent(const TreeView& tv, const Sea
   }
 }
 
-__device__ __noinline__ void search_inference(const hz_mlp_header_t& H, const SearchArgs& a, int sim, int n_rows,
+__device__ __forceinline__ void search_inference(const hz_mlp_header_t& H, const SearchArgs& a, int sim, int n_rows,
                                               uint16_t* lds, int row0) {
   mlp_body<1, 16, 2>(H, a.jobs, a.wstream, a.bias, a.act_tab, a.pool, a.row_stride, a.ix, a.plane_stride, a.la,
                      a.pool + (size_t)(sim + 1) * a.plane_stride, a.rew, a.val, a.pol, n_rows, lds, row0);
