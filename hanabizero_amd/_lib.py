@@ -23,7 +23,7 @@ class MlpHeader(C.Structure):  # include/hz_mlp.h hz_mlp_header_t
                 ("hidden_off", C.c_int32), ("off_reward", C.c_int32), ("off_value", C.c_int32), ("off_policy", C.c_int32),
                 ("support_size", C.c_int32), ("support_min", C.c_int32), ("num_actions", C.c_int32),
                 ("action_table_stride", C.c_int32), ("num_waves", C.c_int32), ("tiles_per_wave", C.c_int32),
-                ("wave_stream_off", C.c_int64 * 16)]
+                ("kstep_stride", C.c_int64), ("wave_stream_off", C.c_int64 * 16)]
 
 
 class ActorBufs(C.Structure):  # include/hz_selfplay.h hz_actor_bufs_t

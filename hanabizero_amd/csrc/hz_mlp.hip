@@ -50,6 +50,8 @@ extern "C" int hz_mlp_recurrent(const hz_mlp_header_t* H, const hz_mlp_job_t* jo
              H->tiles_per_wave);
   for (int w = 0; w < H->num_waves; ++w)
     HZ_REQUIRE(H->wave_stream_off[w] % 8 == 0, "hz_mlp_recurrent: weight streams must start on 16-B boundaries");
+  HZ_REQUIRE(H->kstep_stride >= 512 * H->tiles_per_wave && H->kstep_stride % 8 == 0,
+             "hz_mlp_recurrent: kstep_stride must be a multiple of 8 and at least one k-step (512 * tiles_per_wave)");
   const size_t lds_bytes = (size_t)rows_per_wg * H->row_stride * sizeof(uint16_t);
   HZ_REQUIRE(lds_bytes <= 160 * 1024, "hz_mlp_recurrent: %zu B of LDS per workgroup exceed 160 KiB", lds_bytes);
   const int grid = (num_rows + rows_per_wg - 1) / rows_per_wg;

@@ -77,6 +77,9 @@ extern "C" int hz_mlp_profile_read(unsigned long long* host) {
 #else
 #define HZ_MLP_BREAD 1
 #endif
+#ifndef HZ_BURST
+#define HZ_BURST 1  // k-steps whose weight fragments are requested together (1 or 2)
+#endif
 #ifndef HZ_RING
 #define HZ_RING 4  // weight-fragment ring slots (k-steps); prefetch distance HZ_RING - 1.  Measured: 4 and 8 run at the
 #endif             // same rate (the memory pipe's own queue is the limit), 4 leaves registers for 16 waves per workgroup
@@ -117,12 +120,15 @@ __device__ __forceinline__ void mlp_body(
   }
   __builtin_amdgcn_sched_barrier(0);
   // this wave's weight stream
-  const bf16x8* wp = reinterpret_cast<const bf16x8*>(wstream + H.wave_stream_off[wave]) + lane;
+  // uniform base + per-lane 16-B offset: the k-loop advances the base on the scalar unit, not with 64-bit VALU adds
+  const bf16x8* wbase = reinterpret_cast<const bf16x8*>(wstream + H.wave_stream_off[wave]);
+  const long long kss = H.kstep_stride / 8;  // in 16-B fragments-per-lane units
+#define wp(k, t) wbase[(long long)(k) * kss + (t) * 64 + lane]
   bf16x8 wf[HZ_RING][NT];
 #pragma unroll
-  for (int d = 0; d < HZ_RING - 1; ++d)
+  for (int d = 0; d < HZ_RING - HZ_BURST; ++d)
 #pragma unroll
-    for (int t = 0; t < NT; ++t) wf[d][t] = wp[(d * NT + t) * 64];
+    for (int t = 0; t < NT; ++t) wf[d][t] = wp(d, t);
   __builtin_amdgcn_sched_barrier(0);
 
   // stage the states into the image; rows past N read as zero
@@ -207,9 +213,14 @@ __device__ __forceinline__ void mlp_body(
 
 #define HZ_MLP_STEP(S, U)                                                                                            \
   {                                                                                                                  \
-    _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                                   \
-        wf[((U) + HZ_RING - 1) % HZ_RING][t] = wp[((gstep + (S) + HZ_RING - 1) * NT + t) * 64];                      \
-    if (HZ_MLP_BREAD && (S) + 3 < J.ks) {                                                                            \
+    if (HZ_BURST == 1) {                                                                                             \
+      _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                                 \
+          wf[((U) + HZ_RING - 1) % HZ_RING][t] = wp(gstep + (S) + HZ_RING - 1, t);                                  \
+    } else if ((U) % 2 == 0) { /* two k-steps' fragments back to back: longer bursts per wave on the memory pipe */ \
+      _Pragma("unroll") for (int t = 0; t < 2 * NT; ++t)                                                             \
+          wf[((U) + HZ_RING - 2 + t / NT) % HZ_RING][t % NT] = wp(gstep + (S) + HZ_RING - 2 + t / NT, t % NT);          \
+    }                                                                                                                \
+    if (HZ_MLP_BREAD) { /* unconditional: the last three trips read past the K range, into fragments nobody uses */ \
       _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                                              \
           bq[((U) + 3) % 4][rt] = *reinterpret_cast<const bf16x8*>(src + (size_t)(16 * rt) * rs + 32 * ((S) + 3));   \
     }                                                                                                                \

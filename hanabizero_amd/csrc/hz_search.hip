@@ -69,6 +69,17 @@ __device__ __forceinline__ void search_inference(const hz_mlp_header_t& H, const
                      a.pool + (size_t)(sim + 1) * a.plane_stride, a.rew, a.val, a.pol, n_rows, lds, row0);
 }
 
+// Diagnostic build only (-DHZ_SEARCH_PROFILE, tools/search_profile.py): per-phase s_memtime sums of workgroup 100.
+#ifdef HZ_SEARCH_PROFILE
+__device__ unsigned long long hz_search_prof[16 * 4];
+extern "C" int hz_search_profile_read(unsigned long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(hz_search_prof), sizeof(hz_search_prof));
+}
+#define SP_NOW() __builtin_amdgcn_s_memtime()
+#else
+#define SP_NOW() 0ull
+#endif
+
 __global__ __launch_bounds__(1024, 1) void k_search(TreeView tv, hz_mlp_header_t H, SearchArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
   const int lane = threadIdx.x & 63;
@@ -77,13 +88,28 @@ __global__ __launch_bounds__(1024, 1) void k_search(TreeView tv, hz_mlp_header_t
   const int tree = row0 + wave;
   const bool mine = tree < tv.N;
   float* lds_q = reinterpret_cast<float*>(lds + (size_t)16 * H.row_stride);  // [16 waves][S] behind the row image
+  unsigned long long p_tree = 0, p_wait1 = 0, p_mlp = 0, p_wait2 = 0;
+  (void)p_tree; (void)p_wait1; (void)p_mlp; (void)p_wait2;
+  unsigned long long t0 = SP_NOW();
   if (mine) search_first_descent(tv, a, tree, lane);
   for (int sim = 0; sim < a.sims; ++sim) {
+    unsigned long long t1 = SP_NOW();
     __syncthreads();  // the descents' (plane, action) of this workgroup's rows are visible to all its waves
+    unsigned long long t2 = SP_NOW();
     search_inference(H, a, sim, tv.N, lds, row0);
+    unsigned long long t3 = SP_NOW();
     __syncthreads();  // leaf outputs visible; the row image is free again
+    unsigned long long t4 = SP_NOW();
     if (mine) search_backup_descent(tv, a, tree, lane, wave, lds_q, sim, sim + 1 < a.sims);
+    p_tree += t1 - t0; p_wait1 += t2 - t1; p_mlp += t3 - t2; p_wait2 += t4 - t3;
+    t0 = t4;
   }
+#ifdef HZ_SEARCH_PROFILE
+  if (blockIdx.x == 100 && lane == 0) {
+    unsigned long long* o = hz_search_prof + wave * 4;
+    o[0] = p_tree + (SP_NOW() - t0); o[1] = p_wait1; o[2] = p_mlp; o[3] = p_wait2;
+  }
+#endif
 }
 
 extern "C" int hz_search_run(hz_tree_t* t, int num_simulations, const hz_mlp_header_t* H, const hz_mlp_job_t* jobs,
@@ -110,6 +136,8 @@ extern "C" int hz_search_run(hz_tree_t* t, int num_simulations, const hz_mlp_hea
              "hz_search_run: pointers must be 16-B aligned");
   for (int w = 0; w < 16; ++w)
     HZ_REQUIRE(H->wave_stream_off[w] % 8 == 0, "hz_search_run: weight streams must start on 16-B boundaries");
+  HZ_REQUIRE(H->kstep_stride >= 512 * H->tiles_per_wave && H->kstep_stride % 8 == 0,
+             "hz_search_run: kstep_stride must be a multiple of 8 and at least one k-step (512 * tiles_per_wave)");
   const size_t lds_bytes = (size_t)16 * H->row_stride * sizeof(uint16_t) + (size_t)16 * t->S * sizeof(float);
   HZ_REQUIRE(lds_bytes <= 160 * 1024, "hz_search_run: %zu B of LDS per workgroup exceed 160 KiB", lds_bytes);
   static size_t configured = 0;

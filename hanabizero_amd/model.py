@@ -552,16 +552,19 @@ class FusedRecurrent:
         act_table = torch.zeros(A + 1, biases.numel())      # row A stays zero: what jobs without an action row add
         for off, blk in act_rows:                           # blk [n <= cw, A] = columns of the action block
             act_table[:A, off:off + blk.shape[0]] = blk.t()
-        pad = torch.zeros(8 * tiles * 64 * 8)               # 8 k-steps of zeros behind each stream (ring overrun)
-        offs, parts, cur = [], [], 0
+        # weight streams, interleaved k-step by k-step: [k-step][wave][tiles * 512]; at any moment the waves of a
+        # workgroup (all near the same k-step) read one contiguous region, so every L2 channel carries an equal share
+        frag = tiles * 512
+        steps = [sum(x.numel() for x in st) // frag for st in streams]
+        P = max(steps) + 8                                  # 8 k-steps of zeros behind each stream (ring overrun)
+        W = torch.zeros(P, waves, frag)
         for wave in range(waves):
-            offs.append(cur)
-            st = torch.cat(streams[wave] + [pad])
-            parts.append(st)
-            cur += st.numel()
+            if streams[wave]:
+                W[:steps[wave], wave] = torch.cat(streams[wave]).view(-1, frag)
+        offs, parts = [wave * frag for wave in range(waves)], [W.reshape(-1)]
         hdr = MlpHeader(n_jobs=len(jobs), row_stride=rs, hidden=H, state_off=X, hidden_off=Y0, off_reward=off_r,
                         off_value=off_v, off_policy=off_p, support_size=V, support_min=-engine.support, num_actions=A,
-                        action_table_stride=biases.numel(), num_waves=waves, tiles_per_wave=tiles)
+                        action_table_stride=biases.numel(), num_waves=waves, tiles_per_wave=tiles, kstep_stride=waves * tiles * 512)
         for wave in range(waves):
             hdr.wave_stream_off[wave] = offs[wave]
         import ctypes as C

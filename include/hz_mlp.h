@@ -57,6 +57,10 @@ typedef struct {
   int32_t action_table_stride;   /* fp32 elements per action row */
   int32_t num_waves;             /* 4 (stand-alone kernel) or 16 (inside hz_search_run) */
   int32_t tiles_per_wave;        /* 16-column MFMA tiles per job: 4 with 4 waves, 2 with 16 waves */
+  int64_t kstep_stride;          /* elements between consecutive k-steps of one wave's stream: 512 * tiles_per_wave when
+                                    each stream is contiguous, 512 * tiles_per_wave * num_waves when the streams are
+                                    interleaved k-step by k-step (all waves of a workgroup then read one contiguous
+                                    region at a time: every L2 channel serves an equal share) */
   int64_t wave_stream_off[16];   /* element offset of each wave's weight stream inside `wstream` */
 } hz_mlp_header_t;
 

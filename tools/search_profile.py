@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""tools/search_profile.py -- diagnostic build of the persistent search kernel (-DHZ_SEARCH_PROFILE): where the waves of
+workgroup 100 spend their cycles over one move's search (tree phases, MFMA inference phases, barrier waits).
+Builds a scratch copy of the library (HANABIZERO_HIP_LIB points the loader at it).  Never quote run times of it."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+out = os.path.join(ROOT, "gpurun_out", "libsearch_prof.so")
+os.makedirs(os.path.dirname(out), exist_ok=True)
+src = os.path.join(ROOT, "hanabizero_amd", "csrc")
+files = [os.path.join(src, f) for f in ("hz_tree.hip", "hz_env.hip", "hz_selfplay.hip", "hz_netglue.hip", "hz_mlp.hip",
+                                        "hz_search.hip")]
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+                       "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt", "-w",
+                       "-DHZ_SEARCH_PROFILE", "-I" + src, "-I" + os.path.join(ROOT, "include"), "-o", out] + files)
+os.environ["HANABIZERO_HIP_LIB"] = out
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from hanabizero_amd import _lib  # noqa: E402
+from hanabizero_amd.config import make_config  # noqa: E402
+from hanabizero_amd.selfplay import SelfPlayActor  # noqa: E402
+
+
+def main():
+    N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+    cfg = make_config("Hanabi-Full", simulations=50, stack=4)
+    eng = bench.build_engine(cfg, torch.bfloat16, "cuda")
+    actor = SelfPlayActor(cfg, eng, num_envs=N, rank=0, seed=1, use_graph=False)
+    for _ in range(3):
+        actor.step()
+    torch.cuda.synchronize()
+    lib = _lib.lib
+    lib.hz_search_profile_read.argtypes = [C.c_void_p]
+    prof = np.zeros(64, np.uint64)
+    lib.hz_search_profile_read(prof.ctypes.data_as(C.c_void_p))
+    p = prof.astype(np.int64).reshape(16, 4)
+    print("k_search, workgroup 100, one move (%d simulations): s_memtime ticks per wave" % (cfg.num_simulations - 1))
+    for w in range(16):
+        print("  wave %2d: tree phases %8d | wait for the other trees %8d | inference %8d | wait after inference %7d | total %8d"
+              % (w, p[w, 0], p[w, 1], p[w, 2], p[w, 3], p[w].sum()))
+    print("  per simulation (mean over waves): tree %.0f, wait %.0f, inference %.0f, wait %.0f"
+          % tuple(p.mean(0) / (cfg.num_simulations - 1)))
+
+
+if __name__ == "__main__":
+    main()
