@@ -87,7 +87,8 @@ extern "C" int hz_mlp_profile_read(unsigned long long* host) {
 // The body, called by every wave of the workgroup: NW waves, each producing NT 16-column tiles per job (NW x NT = 4 x 4
 // for the stand-alone kernel, 16 x 2 inside the persistent search kernel, whose 16 waves also own one tree each).
 // `lds`: the row image, MT * row_stride bf16.
-template <int RT, int NW, int NT>
+// PRESTAGED: the caller has already put the input rows into the image (state_src / plane_index unused).
+template <int RT, int NW, int NT, bool PRESTAGED = false>
 __device__ __forceinline__ void mlp_body(
     const hz_mlp_header_t& H, const hz_mlp_job_t* __restrict__ jobs, const uint16_t* __restrict__ wstream,
     const float* __restrict__ bias, const float* __restrict__ act_tab, const uint16_t* __restrict__ state_src,
@@ -116,7 +117,7 @@ __device__ __forceinline__ void mlp_body(
   for (int u = 0; u < SU; ++u) {
     const int i = tid + NTHR * u;
     const int row = row0 + i / chunks;
-    plane0[u] = (plane_index && i < n_stage && row < n_rows) ? (long long)plane_index[row] * plane_stride : 0;
+    plane0[u] = (!PRESTAGED && plane_index && i < n_stage && row < n_rows) ? (long long)plane_index[row] * plane_stride : 0;
   }
   __builtin_amdgcn_sched_barrier(0);
   // this wave's weight stream
@@ -133,7 +134,7 @@ __device__ __forceinline__ void mlp_body(
 
   // stage the states into the image; rows past N read as zero
 #ifndef HZ_MLP_X_NOSTAGE
-  for (int base = 0; base < n_stage; base += NTHR * SU) {
+  for (int base = 0; !PRESTAGED && base < n_stage; base += NTHR * SU) {
     uint4 v[SU];
 #pragma unroll
     for (int u = 0; u < SU; ++u) {

@@ -32,21 +32,43 @@ struct SearchArgs {
 // (The phases must be inlined into the kernel: through a real call the compiler loses the address space of every
 // pointer -- flat loads, which count against both wait counters and break the MFMA loop's pipelining -- and the
 // uniformity of every scalar.  The price is a few loop-invariant registers spilled across the phase boundaries.)
-__device__ __forceinline__ void search_first_descent(const TreeView& tv, const SearchArgs& a, int tree, int lane) {
+// What the phases hand to each other inside a workgroup lives in LDS behind the row image: the descent puts the leaf's
+// parent hidden state (pool[entry][tree], one 16-B load per lane) straight into its row of the image and the action into
+// act_s; the inference leaves reward / value / policy logits in rew_s / val_s / pol_s for the backup.  The pointers
+// handed to the shared bodies are biased by -row0 so that their indexing by the global tree number lands in these arrays.
+struct SearchLds {
+  uint16_t* image;  // [16][row_stride]
+  float* lds_q;     // [16][S]
+  int32_t* act_s;   // [16]
+  float* rew_s;     // [16]
+  float* val_s;     // [16]
+  float* pol_s;     // [16][A]
+};
+
+__device__ __forceinline__ TraverseOut search_traverse_out(const hz_mlp_header_t& H, const SearchArgs& a, const SearchLds& L,
+                                                           int row0) {
   TraverseOut to;
-  to.ix = a.ix; to.iy = a.iy; to.la = a.la;
-  to.pool = nullptr; to.net_in = nullptr; to.row_bytes = 0; to.net_in_stride_bytes = 0; to.onehot_cols = 0; to.dtype = 0;
+  to.ix = a.ix; to.iy = a.iy; to.la = L.act_s - row0;
+  to.pool = reinterpret_cast<const uint8_t*>(a.pool);
+  to.net_in = reinterpret_cast<uint8_t*>(L.image + H.state_off);
+  to.row_bytes = H.hidden * 2; to.net_in_stride_bytes = H.row_stride * 2; to.onehot_cols = 0; to.dtype = HZ_BF16;
+  to.tree0 = row0;
+  return to;
+}
+
+__device__ __forceinline__ void search_first_descent(const TreeView& tv, const hz_mlp_header_t& H, const SearchArgs& a,
+                                                     const SearchLds& L, int row0, int tree, int lane) {
+  const TraverseOut to = search_traverse_out(H, a, L, row0);
   traverse_body(tv, tree, lane, 0, tv.mm_min[tree], tv.mm_max[tree], tv.root_visit[tree], to, false,
                 make_float4(0.f, 0.f, 0.f, 0.f));
 }
 
-__device__ __forceinline__ void search_backup_descent(const TreeView& tv, const SearchArgs& a, int tree, int lane, int wave,
-                                                   float* lds_q, int sim, bool more) {
-  TraverseOut to;
-  to.ix = a.ix; to.iy = a.iy; to.la = a.la;
-  to.pool = nullptr; to.net_in = nullptr; to.row_bytes = 0; to.net_in_stride_bytes = 0; to.onehot_cols = 0; to.dtype = 0;
+__device__ __forceinline__ void search_backup_descent(const TreeView& tv, const hz_mlp_header_t& H, const SearchArgs& a,
+                                                      const SearchLds& L, int row0, int tree, int lane, int wave, int sim,
+                                                      bool more) {
+  const TraverseOut to = search_traverse_out(H, a, L, row0);
   NetOut no;
-  no.rewards = a.rew; no.values = a.val; no.logits = a.pol;
+  no.rewards = L.rew_s - row0; no.values = L.val_s - row0; no.logits = L.pol_s - (size_t)row0 * tv.A;
   no.reward_logits = nullptr; no.value_logits = nullptr; no.policy_logits = nullptr;
   no.reward_stride = 0; no.value_stride = 0; no.policy_stride = 0;
   no.support_size = 0; no.support_min = 0; no.dtype = 0; no.out_rewards = nullptr; no.out_values = nullptr;
@@ -55,7 +77,7 @@ __device__ __forceinline__ void search_backup_descent(const TreeView& tv, const 
   float mn, mx;
   int rv, a0;
   float4 first;
-  backprop_body<false>(tv, tree, lane, wave, lds_q, sim + 1, no, mn, mx, rv, first, a0);
+  backprop_body<false>(tv, tree, lane, wave, L.lds_q, sim + 1, no, mn, mx, rv, first, a0);
   if (more) {
     if (lane == a0) root_row = first;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -63,10 +85,11 @@ __device__ __forceinline__ void search_backup_descent(const TreeView& tv, const 
   }
 }
 
-__device__ __forceinline__ void search_inference(const hz_mlp_header_t& H, const SearchArgs& a, int sim, int n_rows,
-                                              uint16_t* lds, int row0) {
-  mlp_body<1, 16, 2>(H, a.jobs, a.wstream, a.bias, a.act_tab, a.pool, a.row_stride, a.ix, a.plane_stride, a.la,
-                     a.pool + (size_t)(sim + 1) * a.plane_stride, a.rew, a.val, a.pol, n_rows, lds, row0);
+__device__ __forceinline__ void search_inference(const hz_mlp_header_t& H, const SearchArgs& a, const SearchLds& L, int sim,
+                                                 int n_rows, int row0) {
+  mlp_body<1, 16, 2, true>(H, a.jobs, a.wstream, a.bias, a.act_tab, a.pool, a.row_stride, nullptr, a.plane_stride,
+                           L.act_s - row0, a.pool + (size_t)(sim + 1) * a.plane_stride, L.rew_s - row0, L.val_s - row0,
+                           L.pol_s - (size_t)row0 * H.num_actions, n_rows, L.image, row0);
 }
 
 // Diagnostic build only (-DHZ_SEARCH_PROFILE, tools/search_profile.py): per-phase s_memtime sums of workgroup 100.
@@ -87,20 +110,26 @@ __global__ __launch_bounds__(1024, 1) void k_search(TreeView tv, hz_mlp_header_t
   const int row0 = blockIdx.x * 16;
   const int tree = row0 + wave;
   const bool mine = tree < tv.N;
-  float* lds_q = reinterpret_cast<float*>(lds + (size_t)16 * H.row_stride);  // [16 waves][S] behind the row image
+  SearchLds L;
+  L.image = lds;
+  L.lds_q = reinterpret_cast<float*>(lds + (size_t)16 * H.row_stride);
+  L.act_s = reinterpret_cast<int32_t*>(L.lds_q + 16 * tv.S);
+  L.rew_s = reinterpret_cast<float*>(L.act_s + 16);
+  L.val_s = L.rew_s + 16;
+  L.pol_s = L.val_s + 16;
   unsigned long long p_tree = 0, p_wait1 = 0, p_mlp = 0, p_wait2 = 0;
   (void)p_tree; (void)p_wait1; (void)p_mlp; (void)p_wait2;
   unsigned long long t0 = SP_NOW();
-  if (mine) search_first_descent(tv, a, tree, lane);
+  if (mine) search_first_descent(tv, H, a, L, row0, tree, lane);
   for (int sim = 0; sim < a.sims; ++sim) {
     unsigned long long t1 = SP_NOW();
     __syncthreads();  // the descents' (plane, action) of this workgroup's rows are visible to all its waves
     unsigned long long t2 = SP_NOW();
-    search_inference(H, a, sim, tv.N, lds, row0);
+    search_inference(H, a, L, sim, tv.N, row0);
     unsigned long long t3 = SP_NOW();
     __syncthreads();  // leaf outputs visible; the row image is free again
     unsigned long long t4 = SP_NOW();
-    if (mine) search_backup_descent(tv, a, tree, lane, wave, lds_q, sim, sim + 1 < a.sims);
+    if (mine) search_backup_descent(tv, H, a, L, row0, tree, lane, wave, sim, sim + 1 < a.sims);
     p_tree += t1 - t0; p_wait1 += t2 - t1; p_mlp += t3 - t2; p_wait2 += t4 - t3;
     t0 = t4;
   }
@@ -128,9 +157,9 @@ extern "C" int hz_search_run(hz_tree_t* t, int num_simulations, const hz_mlp_hea
                  H->off_reward % 8 == 0 && H->off_value % 8 == 0 && H->row_stride % 8 == 0 && H->hidden % 8 == 0 &&
                  H->state_off % 8 == 0 && H->hidden_off % 8 == 0 && H->action_table_stride % 4 == 0,
              "hz_search_run: malformed MLP header");
-  HZ_REQUIRE(row_stride % 8 == 0 && plane_stride % 8 == 0 && row_stride >= H->hidden &&
-                 plane_stride >= (int64_t)t->N * row_stride,
-             "hz_search_run: pool strides must be multiples of 8 elements and cover [N][hidden]");
+  HZ_REQUIRE(row_stride == H->hidden && plane_stride == (int64_t)t->N * row_stride,
+             "hz_search_run: the pool must be contiguous [planes][N][hidden] (row_stride %lld, plane_stride %lld)",
+             (long long)row_stride, (long long)plane_stride);
   HZ_REQUIRE(((uintptr_t)pool % 16) == 0 && ((uintptr_t)wstream % 16) == 0 && ((uintptr_t)biases % 16) == 0 &&
                  ((uintptr_t)action_table % 16) == 0,
              "hz_search_run: pointers must be 16-B aligned");
@@ -138,7 +167,8 @@ extern "C" int hz_search_run(hz_tree_t* t, int num_simulations, const hz_mlp_hea
     HZ_REQUIRE(H->wave_stream_off[w] % 8 == 0, "hz_search_run: weight streams must start on 16-B boundaries");
   HZ_REQUIRE(H->kstep_stride >= 512 * H->tiles_per_wave && H->kstep_stride % 8 == 0,
              "hz_search_run: kstep_stride must be a multiple of 8 and at least one k-step (512 * tiles_per_wave)");
-  const size_t lds_bytes = (size_t)16 * H->row_stride * sizeof(uint16_t) + (size_t)16 * t->S * sizeof(float);
+  const size_t lds_bytes = (size_t)16 * H->row_stride * sizeof(uint16_t) + (size_t)16 * t->S * sizeof(float) +
+                           (size_t)(16 * 3 + 16 * t->A) * sizeof(float);
   HZ_REQUIRE(lds_bytes <= 160 * 1024, "hz_search_run: %zu B of LDS per workgroup exceed 160 KiB", lds_bytes);
   static size_t configured = 0;
   if (lds_bytes > configured) {

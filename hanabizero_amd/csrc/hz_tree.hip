@@ -286,6 +286,7 @@ static int launch_traverse(hz_tree_t* t, int sim, int32_t* ix, int32_t* iy, int3
   TraverseOut to;
   to.ix = ix; to.iy = iy; to.la = la; to.pool = (const uint8_t*)pool; to.net_in = (uint8_t*)net_in;
   to.row_bytes = row_bytes; to.net_in_stride_bytes = stride_bytes; to.onehot_cols = onehot_cols; to.dtype = dtype;
+  to.tree0 = 0;
   hipLaunchKernelGGL(k_traverse, tree_grid(t), dim3(256), 0, (hipStream_t)stream, view(t), sim, to);
   HZ_HIP(hipGetLastError());
   return 0;

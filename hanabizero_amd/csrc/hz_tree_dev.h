@@ -95,6 +95,7 @@ struct TraverseOut {
   const uint8_t* pool;
   uint8_t* net_in;
   int row_bytes, net_in_stride_bytes, onehot_cols, dtype;
+  int tree0;  // row of net_in that tree `tree0` owns is row 0 (0 for the whole-batch buffer)
 };
 
 // one descent of one tree by one wave; mn / mx / root_visit are passed in registers so that the fused
@@ -209,7 +210,7 @@ __device__ __forceinline__ void traverse_body(const TreeView& tv, int tree, int 
   if (to.pool != nullptr) {
     // hidden_states[i] = hidden_state_pool[ix][iy]  (core/mcts.py:31-32), 16 B per lane per trip
     const uint8_t* src = to.pool + ((size_t)e * tv.N + tree) * (size_t)to.row_bytes;
-    uint8_t* dst = to.net_in + (size_t)tree * (size_t)to.net_in_stride_bytes;
+    uint8_t* dst = to.net_in + (size_t)(tree - to.tree0) * (size_t)to.net_in_stride_bytes;
     for (int off = lane * 16; off < to.row_bytes; off += 64 * 16)
       *reinterpret_cast<uint4*>(dst + off) = *reinterpret_cast<const uint4*>(src + off);
     // action_one_hot of MuZeroNet.dynamics (config/hanabi_control/model.py:215-219), appended after the state
