@@ -74,6 +74,7 @@ def kernel_timing(actor, sample_sims=(4, 16, 28, 40), clones=8, replays=5):
     pol = torch.empty((N, actor.A), dtype=torch.float32, device=actor.device)
     launches, depth, entries = 0, 0.0, 0.0
     ev = lambda: torch.cuda.Event(enable_timing=True)
+    t_search = None
 
     def timed_graph(body):
         side = torch.cuda.Stream(device=actor.device)
@@ -83,6 +84,21 @@ def kernel_timing(actor, sample_sims=(4, 16, 28, 40), clones=8, replays=5):
             body()
         return g
 
+    fused16 = eng.fused_shape(16, 2) if (fused is not None and getattr(actor.mcts, "persistent", False)) else None
+    if fused16 is not None:
+        # the kernel the product path launches: ONE persistent search kernel per move.  4 launches per graph, each on
+        # its own snapshot of the freshly prepared trees (a finished tree cannot be searched again), best of 3 replays
+        best = 1e9
+        for _ in range(3):
+            snaps = [roots.clone() for _ in range(4)]
+            torch.cuda.synchronize()
+            g0 = timed_graph(lambda: [c.search_tensors(fused16, actor.pool, S - 1, rew, val, pol) for c in snaps])
+            a, b = ev(), ev()
+            a.record(); g0.replay(); b.record()
+            torch.cuda.synchronize()
+            best = min(best, a.elapsed_time(b) * 1e-3 / 4)
+            del g0, snaps
+        t_search = best
     for sim in range(S - 1):
         sampled = sim in sample_sims
         if sampled:
@@ -157,7 +173,10 @@ def kernel_timing(actor, sample_sims=(4, 16, 28, 40), clones=8, replays=5):
             del g, snaps, ins
         back(roots)
     torch.cuda.synchronize()
-    return {k: v / launches for k, v in tot.items()}, launches * clones * replays, depth / launches, entries / launches
+    times = {k: v / launches for k, v in tot.items()}
+    if t_search is not None:
+        times["k_search"] = t_search
+    return times, launches * clones * replays, depth / launches, entries / launches
 
 
 def cpu_baseline(game, A, S, sample_trees, moves):
@@ -348,6 +367,16 @@ def main():
             other["k_mlp_recurrent"] = {"bound": "mfma", "avg_launch_us": t * 1e6, "flop_per_launch": flops,
                                         "TFLOPps": flops / t / 1e12, "frac": flops / t / 1e12 / MFMA_BF16_PEAK_TFLOPS,
                                         "weight_bytes_per_wg": engine.fused.weight_bytes_per_wg}
+        if fused_on and "k_search" in times:
+            # the persistent search kernel: all S-1 simulations of a move; MFMA work = (S-1) recurrent inferences, its
+            # tree phases add the algorithmic HBM bytes of (S-1) backups and descents
+            t = times["k_search"]
+            fl = flops * (S - 1)
+            other["k_search"] = {"bound": "mfma", "avg_launch_us": t * 1e6, "flop_per_launch": fl,
+                                 "TFLOPps": fl / t / 1e12, "frac": fl / t / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                                 "simulations_per_launch": S - 1,
+                                 "weight_bytes_streamed_per_cu_per_simulation": engine.fused.weight_bytes_per_wg,
+                                 "tree_bytes_per_launch": (b_trav + b_back) * (S - 1)}
         traffic_all = {}
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
@@ -365,7 +394,7 @@ def main():
                                "unit": "TFLOP/s", "frac": d["frac"], "traffic": traffic_all.get(dom)}
         out["roofline"].update({"avg_launch_us": d["avg_launch_us"], "launches_timed": launches,
                                 "mean_path_edges": dbar, "mean_expanded_entries": sbar,
-                                "method": "HIP events around hipGraph replays of 8 launches on independent snapshots of live search states",
+                                "method": "HIP events around hipGraph replays of back-to-back launches on independent snapshots of live search states (4 for k_search, 8 for the per-phase kernels)",
                                 "other": other})
 
     if rank == 0 and not args.no_cpu_baseline:

@@ -202,6 +202,16 @@ __device__ __forceinline__ void mlp_body(
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) acc[t][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#ifdef HZ_MLP_X_SPLITACC  // experiment: odd k-steps accumulate into a second set (twice the independent MFMA chains)
+    f32x4 acc2[NT][RT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) acc2[t][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#define HZ_ACC(U) (((U) & 1) ? acc2 : acc)
+#else
+#define HZ_ACC(U) acc
+#endif
     const uint16_t* src = lds + (size_t)r0 * rs + J.src_off + kq;
     bf16x8 bq[4][RT];  // activation fragments, 3 k-steps ahead of their use (LDS latency never exposed)
 #pragma unroll
@@ -227,7 +237,7 @@ __device__ __forceinline__ void mlp_body(
     }                                                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                               \
     _Pragma("unroll") for (int t = 0; t < NT; ++t) _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                  \
-        acc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[(U) % HZ_RING][t], bq[(U) % 4][rt], acc[t][rt], 0, 0, 0); \
+        HZ_ACC(U)[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[(U) % HZ_RING][t], bq[(U) % 4][rt], HZ_ACC(U)[t][rt], 0, 0, 0); \
     __builtin_amdgcn_sched_barrier(0);                                                                               \
   }
 
@@ -256,6 +266,13 @@ __device__ __forceinline__ void mlp_body(
     HZ_MLP_STEP(s + 6, 6)
     HZ_MLP_STEP(s + 7, 7)
 #undef HZ_MLP_STEP
+#ifdef HZ_MLP_X_SPLITACC
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) acc[t][rt] += acc2[t][rt];
+#endif
+#undef HZ_ACC
     gstep += J.ks;
     PROF_ADD(p_loop, p_j2);
     const unsigned long long p_j3 = PROF_NOW();
