@@ -22,7 +22,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_recurrent(
     float* __restrict__ out_value, float* __restrict__ out_policy, int n_rows) {
   extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
   mlp_body<RT, NW, NT>(H, jobs, wstream, bias, act_tab, state_src, state_row_stride, plane_index, plane_stride, actions,
-                       hidden_out, out_reward, out_value, out_policy, n_rows, lds, (int)blockIdx.x * 16 * RT);
+                       hidden_out, out_reward, out_value, out_policy, n_rows, lds, (int)blockIdx.x * 16 * RT, RowFrag());
 }
 
 extern "C" int hz_mlp_recurrent(const hz_mlp_header_t* H, const hz_mlp_job_t* jobs, const void* wstream,
@@ -35,7 +35,7 @@ extern "C" int hz_mlp_recurrent(const hz_mlp_header_t* H, const hz_mlp_job_t* jo
              "hz_mlp_recurrent: NULL argument");
   HZ_REQUIRE(num_rows > 0, "hz_mlp_recurrent: num_rows must be > 0");
   HZ_REQUIRE(rows_per_wg == 16 || rows_per_wg == 32, "hz_mlp_recurrent: rows_per_wg must be 16 or 32");
-  HZ_REQUIRE(H->n_jobs > 0 && H->n_jobs <= 256, "hz_mlp_recurrent: bad job count %d", H->n_jobs);
+  HZ_REQUIRE(H->n_jobs > 0 && H->n_jobs <= 32, "hz_mlp_recurrent: bad job count %d", H->n_jobs);
   HZ_REQUIRE(H->support_size > 0 && H->support_size <= 256 && H->off_reward % 8 == 0 && H->off_value % 8 == 0,
              "hz_mlp_recurrent: support_size must be <= 256 and the logit columns 16-B aligned");
   HZ_REQUIRE(H->row_stride % 8 == 0 && H->hidden % 8 == 0 && row_stride % 8 == 0 && plane_stride % 8 == 0 &&

@@ -87,15 +87,23 @@ extern "C" int hz_mlp_profile_read(unsigned long long* host) {
 // The body, called by every wave of the workgroup: NW waves, each producing NT 16-column tiles per job (NW x NT = 4 x 4
 // for the stand-alone kernel, 16 x 2 inside the persistent search kernel, whose 16 waves also own one tree each).
 // `lds`: the row image, MT * row_stride bf16.
-// PRESTAGED: the caller has already put the input rows into the image (state_src / plane_index unused).
-template <int RT, int NW, int NT, bool PRESTAGED = false>
+// The input rows of a workgroup: gathered here from state_src (STAGE_GATHER), or handed over by the caller's waves in
+// registers (STAGE_REGS: wave w holds row w, lane l its l-th 16-B chunk in row_frag.v[l / 64]; needs NW == 16 * RT) and
+// written into the image here, after the weight ring has been started -- the rows' load latency hides under it.
+enum { STAGE_GATHER = 0, STAGE_REGS = 1 };
+struct RowFrag {
+  uint4 v[2];
+};
+template <int RT, int NW, int NT, int STAGE = STAGE_GATHER>
 __device__ __forceinline__ void mlp_body(
     const hz_mlp_header_t& H, const hz_mlp_job_t* __restrict__ jobs, const uint16_t* __restrict__ wstream,
     const float* __restrict__ bias, const float* __restrict__ act_tab, const uint16_t* __restrict__ state_src,
     long long state_row_stride, const int32_t* __restrict__ plane_index, long long plane_stride,
     const int32_t* __restrict__ actions, uint16_t* __restrict__ hidden_out, float* __restrict__ out_reward,
-    float* __restrict__ out_value, float* __restrict__ out_policy, int n_rows, uint16_t* lds, int row0) {
+    float* __restrict__ out_value, float* __restrict__ out_policy, int n_rows, uint16_t* lds, int row0,
+    const RowFrag& row_frag) {
   constexpr int NTHR = 64 * NW;
+  constexpr bool PRESTAGED = STAGE == STAGE_REGS;
   constexpr int MT = 16 * RT;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: job fields stay in SGPRs, branches are scalar
@@ -109,6 +117,14 @@ __device__ __forceinline__ void mlp_body(
   // The parent hidden states (the gather of core/mcts.py:31-36) are one dependent pair of loads away: plane index,
   // then the row.  Issue the index loads first, the weight ring next (it does not depend on the inputs and keeps the
   // memory pipe busy meanwhile), then all row loads of this thread at once: two latencies in total, not two per trip.
+  // this wave's job entries: 8 dwords per job, lane 8*(j % 8) + f of register j / 8 holds field f of job j.  One vector
+  // load now instead of one scalar load (a dependent L2 round trip in front of every job) inside the job loop.
+  int jv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int jl = 8 * i + (lane >> 3);
+    jv[i] = jl < H.n_jobs ? reinterpret_cast<const int*>(jobs)[((size_t)jl * NW + wave) * 8 + (lane & 7)] : 0;
+  }
   const int chunks = H.hidden / 8;
   const int n_stage = MT * chunks;
   constexpr int SU = 4;  // rows-chunks per thread per trip (hidden = 512, 16 rows: exactly one trip)
@@ -154,20 +170,35 @@ __device__ __forceinline__ void mlp_body(
     }
   }
 #endif
-  int act[RT];
+  if (STAGE == STAGE_REGS) {
+    static_assert(STAGE != STAGE_REGS || NW == 16 * RT, "one wave per row");
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      if (lane + 64 * u < chunks)
+        *reinterpret_cast<uint4*>(lds + (size_t)wave * rs + H.state_off + (lane + 64 * u) * 8) = row_frag.v[u];
+  }
+  __syncthreads();
+  int act[RT];  // (read after the barrier: in STAGE_REGS mode the caller's waves have only just written them)
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
     const int row = row0 + 16 * rt + r0;
     int a = row < n_rows ? actions[row] : 0;
     act[rt] = (a < 0 || a >= H.num_actions) ? 0 : a;
   }
-  __syncthreads();
 
   const unsigned long long p_staged = PROF_NOW();
   (void)p_staged;
   long long gstep = 0;  // k-steps of this wave's stream consumed so far
   for (int j = 0; j < H.n_jobs; ++j) {
-    const hz_mlp_job_t J = jobs[j * NW + wave];
+    const int jsel = j >> 3, jb = (j & 7) * 8;
+    const int jr = jsel == 0 ? jv[0] : (jsel == 1 ? jv[1] : (jsel == 2 ? jv[2] : jv[3]));
+    hz_mlp_job_t J;
+    J.ks = __builtin_amdgcn_readlane(jr, jb + 0);
+    J.src_off = __builtin_amdgcn_readlane(jr, jb + 1);
+    J.dst_off = __builtin_amdgcn_readlane(jr, jb + 2);
+    J.res_off = __builtin_amdgcn_readlane(jr, jb + 3);
+    J.bias_off = __builtin_amdgcn_readlane(jr, jb + 4);
+    J.flags = __builtin_amdgcn_readlane(jr, jb + 5);
     const unsigned long long p_j0 = PROF_NOW();
 #ifndef HZ_MLP_X_NOBAR  // (experiment switch, tools/mlp_variants.py)
     if (J.flags & HZ_MLP_BARRIER) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // LDS only: loads stay in flight

@@ -32,9 +32,10 @@ struct SearchArgs {
 // (The phases must be inlined into the kernel: through a real call the compiler loses the address space of every
 // pointer -- flat loads, which count against both wait counters and break the MFMA loop's pipelining -- and the
 // uniformity of every scalar.  The price is a few loop-invariant registers spilled across the phase boundaries.)
-// What the phases hand to each other inside a workgroup lives in LDS behind the row image: the descent puts the leaf's
-// parent hidden state (pool[entry][tree], one 16-B load per lane) straight into its row of the image and the action into
-// act_s; the inference leaves reward / value / policy logits in rew_s / val_s / pol_s for the backup.  The pointers
+// What the phases hand to each other inside a workgroup: the descent ends by requesting its leaf's parent hidden state
+// (pool[entry][tree], one 16-B load per lane) into registers and leaves the action in act_s; the inference writes those
+// registers into its row of the image only after it has started its weight stream (the load's latency hides under it),
+// and leaves reward / value / policy logits in rew_s / val_s / pol_s for the backup.  The pointers
 // handed to the shared bodies are biased by -row0 so that their indexing by the global tree number lands in these arrays.
 struct SearchLds {
   uint16_t* image;  // [16][row_stride]
@@ -49,23 +50,32 @@ __device__ __forceinline__ TraverseOut search_traverse_out(const hz_mlp_header_t
                                                            int row0) {
   TraverseOut to;
   to.ix = a.ix; to.iy = a.iy; to.la = L.act_s - row0;
-  to.pool = reinterpret_cast<const uint8_t*>(a.pool);
-  to.net_in = reinterpret_cast<uint8_t*>(L.image + H.state_off);
-  to.row_bytes = H.hidden * 2; to.net_in_stride_bytes = H.row_stride * 2; to.onehot_cols = 0; to.dtype = HZ_BF16;
-  to.tree0 = row0;
+  to.pool = nullptr; to.net_in = nullptr; to.row_bytes = 0; to.net_in_stride_bytes = 0; to.onehot_cols = 0; to.dtype = 0;
+  to.tree0 = 0;
   return to;
 }
 
-__device__ __forceinline__ void search_first_descent(const TreeView& tv, const hz_mlp_header_t& H, const SearchArgs& a,
-                                                     const SearchLds& L, int row0, int tree, int lane) {
-  const TraverseOut to = search_traverse_out(H, a, L, row0);
-  traverse_body(tv, tree, lane, 0, tv.mm_min[tree], tv.mm_max[tree], tv.root_visit[tree], to, false,
-                make_float4(0.f, 0.f, 0.f, 0.f));
+__device__ __forceinline__ RowFrag search_request_row(const TreeView& tv, const hz_mlp_header_t& H, const SearchArgs& a,
+                                                      int entry, int tree, int lane) {
+  RowFrag f;
+  const uint4* src = reinterpret_cast<const uint4*>(a.pool + ((size_t)entry * tv.N + tree) * (size_t)H.hidden);
+#pragma unroll
+  for (int u = 0; u < 2; ++u) f.v[u] = (lane + 64 * u) * 8 < H.hidden ? src[lane + 64 * u] : make_uint4(0u, 0u, 0u, 0u);
+  return f;
 }
 
-__device__ __forceinline__ void search_backup_descent(const TreeView& tv, const hz_mlp_header_t& H, const SearchArgs& a,
-                                                      const SearchLds& L, int row0, int tree, int lane, int wave, int sim,
-                                                      bool more) {
+__device__ __forceinline__ RowFrag search_first_descent(const TreeView& tv, const hz_mlp_header_t& H, const SearchArgs& a,
+                                                        const SearchLds& L, int row0, int tree, int lane) {
+  const TraverseOut to = search_traverse_out(H, a, L, row0);
+  int entry;
+  traverse_body(tv, tree, lane, 0, tv.mm_min[tree], tv.mm_max[tree], tv.root_visit[tree], to, false,
+                make_float4(0.f, 0.f, 0.f, 0.f), &entry);
+  return search_request_row(tv, H, a, entry, tree, lane);
+}
+
+__device__ __forceinline__ RowFrag search_backup_descent(const TreeView& tv, const hz_mlp_header_t& H, const SearchArgs& a,
+                                                         const SearchLds& L, int row0, int tree, int lane, int wave, int sim,
+                                                         bool more) {
   const TraverseOut to = search_traverse_out(H, a, L, row0);
   NetOut no;
   no.rewards = L.rew_s - row0; no.values = L.val_s - row0; no.logits = L.pol_s - (size_t)row0 * tv.A;
@@ -78,18 +88,23 @@ __device__ __forceinline__ void search_backup_descent(const TreeView& tv, const 
   int rv, a0;
   float4 first;
   backprop_body<false>(tv, tree, lane, wave, L.lds_q, sim + 1, no, mn, mx, rv, first, a0);
+  RowFrag f;
+  f.v[0] = f.v[1] = make_uint4(0u, 0u, 0u, 0u);
   if (more) {
     if (lane == a0) root_row = first;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    traverse_body(tv, tree, lane, sim + 1, mn, mx, rv, to, true, root_row);
+    int entry;
+    traverse_body(tv, tree, lane, sim + 1, mn, mx, rv, to, true, root_row, &entry);
+    f = search_request_row(tv, H, a, entry, tree, lane);
   }
+  return f;
 }
 
 __device__ __forceinline__ void search_inference(const hz_mlp_header_t& H, const SearchArgs& a, const SearchLds& L, int sim,
-                                                 int n_rows, int row0) {
-  mlp_body<1, 16, 2, true>(H, a.jobs, a.wstream, a.bias, a.act_tab, a.pool, a.row_stride, nullptr, a.plane_stride,
-                           L.act_s - row0, a.pool + (size_t)(sim + 1) * a.plane_stride, L.rew_s - row0, L.val_s - row0,
-                           L.pol_s - (size_t)row0 * H.num_actions, n_rows, L.image, row0);
+                                                 int n_rows, int row0, const RowFrag& rows) {
+  mlp_body<1, 16, 2, STAGE_REGS>(H, a.jobs, a.wstream, a.bias, a.act_tab, a.pool, a.row_stride, nullptr, a.plane_stride,
+                                 L.act_s - row0, a.pool + (size_t)(sim + 1) * a.plane_stride, L.rew_s - row0,
+                                 L.val_s - row0, L.pol_s - (size_t)row0 * H.num_actions, n_rows, L.image, row0, rows);
 }
 
 // Diagnostic build only (-DHZ_SEARCH_PROFILE, tools/search_profile.py): per-phase s_memtime sums of workgroup 100.
@@ -120,16 +135,18 @@ __global__ __launch_bounds__(1024, 1) void k_search(TreeView tv, hz_mlp_header_t
   unsigned long long p_tree = 0, p_wait1 = 0, p_mlp = 0, p_wait2 = 0;
   (void)p_tree; (void)p_wait1; (void)p_mlp; (void)p_wait2;
   unsigned long long t0 = SP_NOW();
-  if (mine) search_first_descent(tv, H, a, L, row0, tree, lane);
+  RowFrag rows;
+  rows.v[0] = rows.v[1] = make_uint4(0u, 0u, 0u, 0u);
+  if (mine) rows = search_first_descent(tv, H, a, L, row0, tree, lane);
   for (int sim = 0; sim < a.sims; ++sim) {
     unsigned long long t1 = SP_NOW();
-    __syncthreads();  // the descents' (plane, action) of this workgroup's rows are visible to all its waves
+    // (no barrier here: the inference's own barrier after staging orders the waves' rows and actions)
     unsigned long long t2 = SP_NOW();
-    search_inference(H, a, L, sim, tv.N, row0);
+    search_inference(H, a, L, sim, tv.N, row0, rows);
     unsigned long long t3 = SP_NOW();
     __syncthreads();  // leaf outputs visible; the row image is free again
     unsigned long long t4 = SP_NOW();
-    if (mine) search_backup_descent(tv, H, a, L, row0, tree, lane, wave, sim, sim + 1 < a.sims);
+    if (mine) rows = search_backup_descent(tv, H, a, L, row0, tree, lane, wave, sim, sim + 1 < a.sims);
     p_tree += t1 - t0; p_wait1 += t2 - t1; p_mlp += t3 - t2; p_wait2 += t4 - t3;
     t0 = t4;
   }
@@ -153,7 +170,7 @@ extern "C" int hz_search_run(hz_tree_t* t, int num_simulations, const hz_mlp_hea
   HZ_REQUIRE(t->next_entry == 1, "hz_search_run: the tree must be freshly prepared (hz_tree_prepare)");
   HZ_REQUIRE(H->num_waves == 16 && H->tiles_per_wave == 2, "hz_search_run: the MLP must be laid out for 16 waves x 2 tiles");
   HZ_REQUIRE(H->num_actions == t->A, "hz_search_run: the MLP has %d actions, the tree %d", H->num_actions, t->A);
-  HZ_REQUIRE(H->n_jobs > 0 && H->n_jobs <= 256 && H->support_size > 0 && H->support_size <= 256 &&
+  HZ_REQUIRE(H->n_jobs > 0 && H->n_jobs <= 32 && H->support_size > 0 && H->support_size <= 256 &&
                  H->off_reward % 8 == 0 && H->off_value % 8 == 0 && H->row_stride % 8 == 0 && H->hidden % 8 == 0 &&
                  H->state_off % 8 == 0 && H->hidden_off % 8 == 0 && H->action_table_stride % 4 == 0,
              "hz_search_run: malformed MLP header");

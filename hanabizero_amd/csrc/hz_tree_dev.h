@@ -115,7 +115,8 @@ extern "C" int hz_tree_profile_read(unsigned long long* host) {
 #endif
 
 __device__ __forceinline__ void traverse_body(const TreeView& tv, int tree, int lane, int sim, float mn, float mx,
-                                              int root_visit, const TraverseOut& to, bool have_root, float4 root_row) {
+                                              int root_visit, const TraverseOut& to, bool have_root, float4 root_row,
+                                              int* out_entry = nullptr) {
   const int A = tv.A, S = tv.S;
   const bool on = lane < A;
   const float discount = tv.discount;
@@ -207,6 +208,7 @@ __device__ __forceinline__ void traverse_body(const TreeView& tv, int tree, int 
     to.la[tree] = action;
     tv.path_len[tree] = depth + 1;
   }
+  if (out_entry) *out_entry = e;
   if (to.pool != nullptr) {
     // hidden_states[i] = hidden_state_pool[ix][iy]  (core/mcts.py:31-32), 16 B per lane per trip
     const uint8_t* src = to.pool + ((size_t)e * tv.N + tree) * (size_t)to.row_bytes;

@@ -530,10 +530,12 @@ class FusedRecurrent:
             for w, e in zip(sorted(order), ents):
                 row[w] = e
                 load[w] += e["ks"]
+            pass_ks = max(e["ks"] for e in ents)
+            assert all(e["ks"] == pass_ks for e in ents), "jobs of one pass share their K"
             for wave, e in enumerate(row):
                 flags = (MLP_BARRIER if job["barrier"] else 0) | (MLP_STORE_HIDDEN if job["store_hidden"] else 0)
                 if e is None:
-                    table.append(MlpJob(ks=0, src_off=0, dst_off=0, res_off=-1, bias_off=0, flags=flags))
+                    table.append(MlpJob(ks=0, src_off=0, dst_off=0, res_off=-1, bias_off=0, flags=flags, reserved0=pass_ks))
                     continue
                 assert e["ks"] % 8 == 0, "K must be a multiple of 256 (8 k-steps)"
                 streams[wave].append(_pack_fragments(e["w"], e["ks"], tiles))
@@ -547,7 +549,8 @@ class FusedRecurrent:
                 if e["relu"]:
                     flags |= MLP_RELU
                 table.append(MlpJob(ks=e["ks"], src_off=e["src"], dst_off=e["dst"],
-                                    res_off=-1 if e["res"] is None else e["res"], bias_off=bias_off, flags=flags))
+                                    res_off=-1 if e["res"] is None else e["res"], bias_off=bias_off, flags=flags,
+                                    reserved0=pass_ks))
         biases = torch.cat(bias_chunks)
         act_table = torch.zeros(A + 1, biases.numel())      # row A stays zero: what jobs without an action row add
         for off, blk in act_rows:                           # blk [n <= cw, A] = columns of the action block

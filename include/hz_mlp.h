@@ -47,7 +47,7 @@ typedef struct {
 } hz_mlp_job_t;
 
 typedef struct {
-  int32_t n_jobs;
+  int32_t n_jobs;      /* <= 32 */
   int32_t row_stride;  /* LDS elements per row, multiple of 8, = 8 (mod 128) for conflict-free ds_read_b128 */
   int32_t hidden;      /* width of the hidden state (multiple of 8) */
   int32_t state_off;   /* LDS column where the input hidden state is staged */
