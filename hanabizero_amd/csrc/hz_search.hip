@@ -39,7 +39,9 @@ struct SearchArgs {
 // handed to the shared bodies are biased by -row0 so that their indexing by the global tree number lands in these arrays.
 struct SearchLds {
   uint16_t* image;  // [16][row_stride]
-  float* lds_q;     // [16][S]
+  float4* prec_s;   // [16][S+1]  the last descent's records, per tree
+  int32_t* path_s;  // [16][S+1]  the last descent's path, per tree
+  float* lds_q;     // [16][S]    q cache, per tree, for the whole search
   int32_t* act_s;   // [16]
   float* rew_s;     // [16]
   float* val_s;     // [16]
@@ -65,36 +67,38 @@ __device__ __forceinline__ RowFrag search_request_row(const TreeView& tv, const 
 }
 
 __device__ __forceinline__ RowFrag search_first_descent(const TreeView& tv, const hz_mlp_header_t& H, const SearchArgs& a,
-                                                        const SearchLds& L, int row0, int tree, int lane) {
+                                                        const SearchLds& L, int row0, int tree, int lane, TreeLocal& tl,
+                                                        float4& root_row) {
   const TraverseOut to = search_traverse_out(H, a, L, row0);
   int entry;
-  traverse_body(tv, tree, lane, 0, tv.mm_min[tree], tv.mm_max[tree], tv.root_visit[tree], to, false,
-                make_float4(0.f, 0.f, 0.f, 0.f), &entry);
+  tl.root_visit = tv.root_visit[tree];
+  tl.root_vsum = tv.root_vsum[tree];
+  root_row = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (lane < tv.A) root_row = tv.rec[(size_t)tree * tv.S * tv.A + lane];  // from now on kept in registers, patched per backup
+  traverse_body<true>(tv, tree, lane, 0, tv.mm_min[tree], tv.mm_max[tree], tl.root_visit, to, true, root_row, &entry, &tl);
   return search_request_row(tv, H, a, entry, tree, lane);
 }
 
 __device__ __forceinline__ RowFrag search_backup_descent(const TreeView& tv, const hz_mlp_header_t& H, const SearchArgs& a,
                                                          const SearchLds& L, int row0, int tree, int lane, int wave, int sim,
-                                                         bool more) {
+                                                         bool more, TreeLocal& tl, float4& root_row) {
   const TraverseOut to = search_traverse_out(H, a, L, row0);
   NetOut no;
   no.rewards = L.rew_s - row0; no.values = L.val_s - row0; no.logits = L.pol_s - (size_t)row0 * tv.A;
   no.reward_logits = nullptr; no.value_logits = nullptr; no.policy_logits = nullptr;
   no.reward_stride = 0; no.value_stride = 0; no.policy_stride = 0;
   no.support_size = 0; no.support_min = 0; no.dtype = 0; no.out_rewards = nullptr; no.out_values = nullptr;
-  float4 root_row = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (more && lane < tv.A) root_row = tv.rec[(size_t)tree * tv.S * tv.A + lane];
   float mn, mx;
   int rv, a0;
   float4 first;
-  backprop_body<false>(tv, tree, lane, wave, L.lds_q, sim + 1, no, mn, mx, rv, first, a0);
+  backprop_body<false, true>(tv, tree, lane, wave, L.lds_q, sim + 1, no, mn, mx, rv, first, a0, &tl);
   RowFrag f;
   f.v[0] = f.v[1] = make_uint4(0u, 0u, 0u, 0u);
+  if (lane == a0) root_row = first;  // the one record of the root's row this backup changed
   if (more) {
-    if (lane == a0) root_row = first;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     int entry;
-    traverse_body(tv, tree, lane, sim + 1, mn, mx, rv, to, true, root_row, &entry);
+    traverse_body<true>(tv, tree, lane, sim + 1, mn, mx, rv, to, true, root_row, &entry, &tl);
     f = search_request_row(tv, H, a, entry, tree, lane);
   }
   return f;
@@ -127,8 +131,14 @@ __global__ __launch_bounds__(1024, 1) void k_search(TreeView tv, hz_mlp_header_t
   const bool mine = tree < tv.N;
   SearchLds L;
   L.image = lds;
-  L.lds_q = reinterpret_cast<float*>(lds + (size_t)16 * H.row_stride);
+  L.prec_s = reinterpret_cast<float4*>(lds + (size_t)16 * H.row_stride);  // (row_stride % 8 == 0: 16-B aligned)
+  L.path_s = reinterpret_cast<int32_t*>(L.prec_s + 16 * (tv.S + 1));
+  L.lds_q = reinterpret_cast<float*>(L.path_s + 16 * (tv.S + 1));
   L.act_s = reinterpret_cast<int32_t*>(L.lds_q + 16 * tv.S);
+  TreeLocal tl;
+  tl.path = L.path_s + wave * (tv.S + 1);
+  tl.prec = L.prec_s + wave * (tv.S + 1);
+  tl.root_vsum = 0.0f; tl.root_visit = 0; tl.path_len = 0;
   L.rew_s = reinterpret_cast<float*>(L.act_s + 16);
   L.val_s = L.rew_s + 16;
   L.pol_s = L.val_s + 16;
@@ -137,7 +147,8 @@ __global__ __launch_bounds__(1024, 1) void k_search(TreeView tv, hz_mlp_header_t
   unsigned long long t0 = SP_NOW();
   RowFrag rows;
   rows.v[0] = rows.v[1] = make_uint4(0u, 0u, 0u, 0u);
-  if (mine) rows = search_first_descent(tv, H, a, L, row0, tree, lane);
+  float4 root_row = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (mine) rows = search_first_descent(tv, H, a, L, row0, tree, lane, tl, root_row);
   for (int sim = 0; sim < a.sims; ++sim) {
     unsigned long long t1 = SP_NOW();
     // (no barrier here: the inference's own barrier after staging orders the waves' rows and actions)
@@ -146,7 +157,7 @@ __global__ __launch_bounds__(1024, 1) void k_search(TreeView tv, hz_mlp_header_t
     unsigned long long t3 = SP_NOW();
     __syncthreads();  // leaf outputs visible; the row image is free again
     unsigned long long t4 = SP_NOW();
-    if (mine) rows = search_backup_descent(tv, H, a, L, row0, tree, lane, wave, sim, sim + 1 < a.sims);
+    if (mine) rows = search_backup_descent(tv, H, a, L, row0, tree, lane, wave, sim, sim + 1 < a.sims, tl, root_row);
     p_tree += t1 - t0; p_wait1 += t2 - t1; p_mlp += t3 - t2; p_wait2 += t4 - t3;
     t0 = t4;
   }
@@ -184,8 +195,8 @@ extern "C" int hz_search_run(hz_tree_t* t, int num_simulations, const hz_mlp_hea
     HZ_REQUIRE(H->wave_stream_off[w] % 8 == 0, "hz_search_run: weight streams must start on 16-B boundaries");
   HZ_REQUIRE(H->kstep_stride >= 512 * H->tiles_per_wave && H->kstep_stride % 8 == 0,
              "hz_search_run: kstep_stride must be a multiple of 8 and at least one k-step (512 * tiles_per_wave)");
-  const size_t lds_bytes = (size_t)16 * H->row_stride * sizeof(uint16_t) + (size_t)16 * t->S * sizeof(float) +
-                           (size_t)(16 * 3 + 16 * t->A) * sizeof(float);
+  const size_t lds_bytes = (size_t)16 * H->row_stride * sizeof(uint16_t) + (size_t)16 * (t->S + 1) * (16 + 4) +
+                           (size_t)16 * t->S * sizeof(float) + (size_t)(16 * 3 + 16 * t->A) * sizeof(float);
   HZ_REQUIRE(lds_bytes <= 160 * 1024, "hz_search_run: %zu B of LDS per workgroup exceed 160 KiB", lds_bytes);
   static size_t configured = 0;
   if (lds_bytes > configured) {

@@ -114,16 +114,28 @@ extern "C" int hz_tree_profile_read(unsigned long long* host) {
 #define TP_ON(v) do { } while (0)
 #endif
 
+// Per-tree search state a persistent kernel keeps on chip from simulation to simulation (hz_search.hip): the last
+// descent's path and records and the q cache in LDS, the root's running sums in registers.  With LOCAL = false the
+// bodies read all of it from the tree's arrays in HBM (one launch per phase) and this struct is ignored.
+struct TreeLocal {
+  int32_t* path;    // [S+1]  (LDS)
+  float4* prec;     // [S+1]  (LDS)
+  float root_vsum;  // the root's value_sum / visit_count (also stored to HBM for the read-outs)
+  int root_visit;
+  int path_len;     // nodes on the last descent's path
+};
+
+template <bool LOCAL = false>
 __device__ __forceinline__ void traverse_body(const TreeView& tv, int tree, int lane, int sim, float mn, float mx,
                                               int root_visit, const TraverseOut& to, bool have_root, float4 root_row,
-                                              int* out_entry = nullptr) {
+                                              int* out_entry = nullptr, TreeLocal* tl = nullptr) {
   const int A = tv.A, S = tv.S;
   const bool on = lane < A;
   const float discount = tv.discount;
   const float delta = mx - mn;
   const float4* rec = tv.rec + (size_t)tree * S * A;
-  int32_t* path = tv.path + (size_t)tree * (S + 1);
-  float4* prec = tv.prec + (size_t)tree * (S + 1);
+  int32_t* path = LOCAL ? tl->path : tv.path + (size_t)tree * (S + 1);
+  float4* prec = LOCAL ? tl->prec : tv.prec + (size_t)tree * (S + 1);
   // pb_c's first factor for every possible parent visit count, one per lane (S + 1 <= 64: no dependent table load
   // on the critical path of a level); larger S falls back to the table in memory
   const bool tab_in_regs = S < 64;
@@ -208,6 +220,7 @@ __device__ __forceinline__ void traverse_body(const TreeView& tv, int tree, int 
     to.la[tree] = action;
     tv.path_len[tree] = depth + 1;
   }
+  if (LOCAL) tl->path_len = depth + 1;
   if (out_entry) *out_entry = e;
   if (to.pool != nullptr) {
     // hidden_states[i] = hidden_state_pool[ix][iy]  (core/mcts.py:31-32), 16 B per lane per trip
@@ -297,16 +310,17 @@ __device__ __forceinline__ float support_to_scalar(const void* row, int V, int s
 }
 
 // one tree's expand + backup + min-max by one wave; returns the new (min, max, root visit count) in registers
-template <bool FUSED>
+template <bool FUSED, bool LOCAL = false>
 __device__ __forceinline__ void backprop_body(const TreeView& tv, int tree, int lane, int wave, float* lds_q, int e_new,
                                               const NetOut& no, float& out_mn, float& out_mx, int& out_root_visit,
-                                              float4& out_first_rec, int& out_first_action) {
+                                              float4& out_first_rec, int& out_first_action, TreeLocal* tl = nullptr) {
   const int A = tv.A, S = tv.S;
   const bool on = lane < A;
   const float discount = tv.discount;
   float4* rec = tv.rec + (size_t)tree * S * A;
-  const int32_t* path = tv.path + (size_t)tree * (S + 1);
-  float* lq = lds_q + wave * S;
+  const int32_t* path = LOCAL ? tl->path : tv.path + (size_t)tree * (S + 1);
+  const float4* prec = LOCAL ? tl->prec : tv.prec + (size_t)tree * (S + 1);
+  float* lq = lds_q + wave * S;  // LOCAL: persists across the simulations (never re-staged from tv.qsa)
 
   // the path's first 64 edges and the records the descent read there, fetched before path_len is known (the buffers
   // hold S+1 slots per tree, so this never leaves them): every load of this function is issued up front, independent
@@ -314,12 +328,13 @@ __device__ __forceinline__ void backprop_body(const TreeView& tv, int tree, int 
   float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (lane <= S) {
     pr0 = path[lane];
-    r0 = tv.prec[(size_t)tree * (S + 1) + lane];  // == rec[entry][action] as the descent read it
+    r0 = prec[lane];  // == rec[entry][action] as the descent read it
   }
-  const float old_root_vsum = tv.root_vsum[tree];
-  const int old_root_visit = tv.root_visit[tree];
+  const float old_root_vsum = LOCAL ? tl->root_vsum : tv.root_vsum[tree];
+  const int old_root_visit = LOCAL ? tl->root_visit : tv.root_visit[tree];
   // stage the cached q of entries 1..e_new-1 in LDS (coalesced), entry e_new is produced below
-  for (int e = 1 + lane; e < e_new; e += 64) lq[e] = tv.qsa[(size_t)tree * S + e];
+  if (!LOCAL)
+    for (int e = 1 + lane; e < e_new; e += 64) lq[e] = tv.qsa[(size_t)tree * S + e];
 
   // expand the leaf: priors of the new entry's children
   float logit = 0.0f;
@@ -340,7 +355,7 @@ __device__ __forceinline__ void backprop_body(const TreeView& tv, int tree, int 
     rec[(size_t)e_new * A + lane] = r;
   }
 
-  const int npairs = tv.path_len[tree] - 1;  // edges on the path; the node below edge k is at depth k+1
+  const int npairs = (LOCAL ? tl->path_len : tv.path_len[tree]) - 1;  // edges on the path; the node below edge k is at depth k+1
   float G, leaf_reward;                      // bootstrap_value (cnode.cpp:318) and the leaf's reward
   if (FUSED) {
     const int es = (no.dtype == HZ_F32) ? 4 : 2;
@@ -367,7 +382,7 @@ __device__ __forceinline__ void backprop_body(const TreeView& tv, int tree, int 
       r = r0;
     } else if (act) {
       pr = path[k];
-      r = tv.prec[(size_t)tree * (S + 1) + k];
+      r = prec[k];
     }
     uint32_t w = __float_as_uint(r.w);
     int visit = (int)(w >> 16);
@@ -392,7 +407,7 @@ __device__ __forceinline__ void backprop_body(const TreeView& tv, int tree, int 
       rec[(size_t)(pr >> 8) * A + (pr & 255)] = r;
       const float q = r.z + discount * (r.y / (float)visit);  // update_tree_q's qsa (cnode.cpp:304)
       lq[child] = q;
-      tv.qsa[(size_t)tree * S + child] = q;
+      if (!LOCAL) tv.qsa[(size_t)tree * S + child] = q;
     }
   }
   TP(3);
@@ -407,6 +422,10 @@ __device__ __forceinline__ void backprop_body(const TreeView& tv, int tree, int 
   if (lane == 0) {
     tv.root_vsum[tree] = new_root_vsum;
     tv.root_visit[tree] = out_root_visit;
+  }
+  if (LOCAL) {
+    tl->root_vsum = new_root_vsum;
+    tl->root_visit = out_root_visit;
   }
   // min_max_stats.clear(); update_tree_q(root): every expanded non-root node contributes (cnode.cpp:332-334)
   float vmax = -INFINITY, vmin = INFINITY;
