@@ -80,7 +80,7 @@ def kernel_timing(actor, sample_sims=(4, 16, 28, 40), clones=8, replays=5):
         side = torch.cuda.Stream(device=actor.device)
         side.wait_stream(torch.cuda.current_stream())
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=side):
+        with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
             body()
         return g
 
@@ -397,7 +397,7 @@ def main():
                                 "method": "HIP events around hipGraph replays of back-to-back launches on independent snapshots of live search states (4 for k_search, 8 for the per-phase kernels)",
                                 "other": other})
 
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:  # (rank 0 at N = 1 only)
         v, dt = cpu_baseline(game, cfg.action_space_size, S, args.cpu_sample_trees, args.cpu_sample_moves)
         out["cpu_baseline"] = {"value": v, "unit": "moves/s", "cores": 1, "kind": "port",
                                "sample": "oracle tree+env (no nets), %d envs x %d moves x %d sims, %.1f s on 1 core" % (
@@ -405,6 +405,7 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
+        barrier()  # rank 0 spent extra seconds on the roofline pass: leave together
         dist.destroy_process_group()
 
 

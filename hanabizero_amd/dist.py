@@ -38,17 +38,19 @@ def gather_records(rec, dst=0, group=None, device=None):
     mx = max(all_counts)
     if mx == 0:
         return None
-    # tail shapes/dtypes travel with the first rank that has data; every rank knows them from its own buffers
-    spec = None if rec is None else {k: (rec[k].shape[1:], rec[k].dtype.str) for k in _FIELDS}
+    # every rank trims its records to its own longest finished game (SelfPlayActor.drain): agree on the element-wise
+    # maximum of the tail shapes (dtypes are the same everywhere) and pad to it
+    spec = None if rec is None else {k: (tuple(rec[k].shape[1:]), rec[k].dtype.str) for k in _FIELDS}
     specs = [None] * world
     dist.all_gather_object(specs, spec, group=group)
-    spec = next(s for s in specs if s is not None)
+    have = [s for s in specs if s is not None]
+    spec = {k: (tuple(max(s[k][0][d] for s in have) for d in range(len(have[0][k][0]))), have[0][k][1]) for k in _FIELDS}
     out = {} if rank == dst else None
     for k in _FIELDS:
         shape, dt = spec[k]
         pad = np.zeros((mx,) + tuple(shape), dtype=np.dtype(dt))
         if n:
-            pad[:n] = rec[k]
+            pad[(slice(0, n),) + tuple(slice(0, d) for d in rec[k].shape[1:])] = rec[k]
         t = _to_dev(pad.view(np.uint8).reshape(mx, -1), device)
         bufs = [torch.empty_like(t) for _ in range(world)] if rank == dst else None
         dist.gather(t, bufs, dst=dst, group=group)

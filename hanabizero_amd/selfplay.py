@@ -174,7 +174,7 @@ class SelfPlayActor:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize(self.device)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):  # other threads (e.g. the RCCL watchdog) may call HIP meanwhile
             self._draw()
             self._step_body()
         self._graph = g
@@ -246,7 +246,7 @@ class ActorGroup:
         torch.cuda.synchronize(self.device)
         branches = [torch.cuda.Stream(device=self.device) for _ in self.actors]
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):  # other threads (e.g. the RCCL watchdog) may call HIP meanwhile
             root = torch.cuda.current_stream()
             for a, b in zip(self.actors, branches):
                 b.wait_stream(root)

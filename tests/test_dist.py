@@ -33,6 +33,18 @@ def _worker(rank, world, port, counts, q):
                     ok &= bool((got[k] == np.concatenate([w[k] for w in want], 0)).all()) and got[k].dtype == want[0][k].dtype
         else:
             ok &= got is None
+    # ranks trim their records to their own longest finished game (SelfPlayActor.drain): different time extents
+    Ts = (4, 9)
+    rec = _fake_rec(3, 7 + rank, T=Ts[rank])
+    got = gather_records(rec, dst=0)
+    if rank == 0:
+        ok &= got["action"].shape == (6, 9) and got["obs"].shape[:2] == (6, 10) and got["meta"].shape == (6, 4)
+        for r in range(2):
+            w = _fake_rec(3, 7 + r, T=Ts[r])
+            for k in w:
+                sl = (slice(3 * r, 3 * r + 3),) + tuple(slice(0, d) for d in w[k].shape[1:])
+                ok &= bool((got[k][sl] == w[k]).all())
+        ok &= bool((got["action"][:3, 4:] == 0).all())  # rank 0's rows are zero-padded up to rank 1's extent
     sd = {"b": torch.full((3,), float(rank)), "a": torch.arange(4.0) * (rank + 1)}
     out = broadcast_weights(sd, src=0)
     ok &= bool((out["b"] == 0).all()) and bool((out["a"] == torch.arange(4.0)).all())
