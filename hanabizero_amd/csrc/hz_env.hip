@@ -104,17 +104,50 @@ __device__ __forceinline__ int player_to_deal(const EnvCfg& g, const St& s) {  /
 // block needs the OLD words i and i+1 and word i+397 -- old for i < 227, already regenerated (i - 227) afterwards;
 // word 623 uses the new word 0 -- which is exactly what is in the array when draw i arrives.  Same output stream,
 // no 624-step stall of one lane while 63 wait (position 624 after seeding == position 0 of the first block).
-__device__ uint32_t mt_next(uint32_t* mt, int N, int env) {
-#define MT(k) mt[(size_t)(k) * N + env]
-  uint32_t idx = MT(624);
-  if (idx >= 624u) idx = 0;
-  const uint32_t i1 = idx + 1 == 624u ? 0u : idx + 1;
-  const uint32_t im = idx < 227u ? idx + 397u : idx - 227u;
-  const uint32_t y = (MT(idx) & 0x80000000u) | (MT(i1) & 0x7fffffffu);
-  uint32_t z = MT(im) ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-  MT(idx) = z;
-  MT(624) = idx + 1;
-#undef MT
+// All draws of one kernel call are prepared together: the raw words they need are requested at the start of the kernel
+// (independent loads, one round trip: a reset needs 2 * players * hand_size draws, which was 40 dependent round trips
+// word by word), the recurrence then runs out of LDS, and the words of the draws actually consumed are written back.
+#define MT_MAX_DRAWS 50  // 2 * (players * hand_size <= 25)
+struct MtBatch {
+  uint32_t* mt;
+  int N, env;
+  uint32_t* w;    // LDS column [MT_MAX_DRAWS + 1]: words at positions idx0 .. idx0 + n (old; regenerated in place)
+  uint32_t* far;  // LDS column [MT_MAX_DRAWS]: words at positions idx0 + 397 + k (mod 624)
+  int stride, idx0, n, pos;
+};
+
+__device__ __forceinline__ int mt_wrap(int i) { return i >= 624 ? i - 624 : i; }
+
+__device__ void mt_batch_begin(MtBatch& b, int n) {
+#define MT(k) b.mt[(size_t)(k) * b.N + b.env]
+  int idx = (int)MT(624);
+  if (idx >= 624) idx = 0;
+  b.idx0 = idx;
+  b.n = n;
+  b.pos = 0;
+  // (the far words are never among those this batch regenerates: that would need n > 227)
+  for (int k0 = 0; k0 <= n; k0 += 8) {
+    uint32_t a[8], f[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = k0 + u;
+      a[u] = k <= n ? MT(mt_wrap(idx + k)) : 0u;
+      f[u] = k < n ? MT(mt_wrap(mt_wrap(idx + k) + 397)) : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = k0 + u;
+      if (k <= n) b.w[k * b.stride] = a[u];
+      if (k < n) b.far[k * b.stride] = f[u];
+    }
+  }
+}
+
+__device__ uint32_t mt_batch_next(MtBatch& b) {
+  const int k = b.pos++;
+  const uint32_t y = (b.w[k * b.stride] & 0x80000000u) | (b.w[(k + 1) * b.stride] & 0x7fffffffu);
+  uint32_t z = b.far[k * b.stride] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+  b.w[k * b.stride] = z;
   z ^= (z >> 11);
   z ^= (z << 7) & 0x9d2c5680u;
   z ^= (z << 15) & 0xefc60000u;
@@ -122,9 +155,17 @@ __device__ uint32_t mt_next(uint32_t* mt, int N, int env) {
   return z;
 }
 
+__device__ void mt_batch_commit(MtBatch& b) {
+  if (b.pos == 0) return;
+  for (int k = 0; k < b.pos; ++k) MT(mt_wrap(b.idx0 + k)) = b.w[k * b.stride];
+  const int idx = b.idx0 + b.pos;
+  MT(624) = (uint32_t)(idx > 624 ? idx - 624 : idx);
+#undef MT
+}
+
 // ApplyRandomChance (hanabi_state.cc:282-286): ChanceOutcomes (:313-325) -> PickRandomChance
 // (hanabi_game.cc:106-112: std::discrete_distribution over doubles count/deck_size) -> ApplyMove(kDeal) (:229-241)
-__device__ void deal_random(const EnvCfg& g, St& s, int& cur, uint32_t* mt, int env) {
+__device__ void deal_random(const EnvCfg& g, St& s, int& cur, MtBatch& rng) {
   const int ncards = g.C * g.R;
   const double total = (double)s.deck_total();
   // a card type has 1..3 copies left (2-bit deck counters): its probability count/total takes three values, so the
@@ -145,8 +186,8 @@ __device__ void deal_random(const EnvCfg& g, St& s, int& cur, uint32_t* mt, int 
   int pick = only;
   if (n >= 2) {  // with < 2 outcomes libstdc++ returns index 0 WITHOUT drawing (random.tcc:2660-2664, 2704-2705)
     // generate_canonical<double,53>: two 32-bit draws, low word first (random.tcc:3348-3380)
-    const double lo = (double)mt_next(mt, g.N, env);
-    const double hi = (double)mt_next(mt, g.N, env);
+    const double lo = (double)mt_batch_next(rng);
+    const double hi = (double)mt_batch_next(rng);
     double u = (lo + hi * 4294967296.0) / 18446744073709551616.0;
     if (u >= 1.0) u = 0x1.fffffffffffffp-1;
     // normalise, partial_sum, last := 1.0, lower_bound (random.tcc:2666-2676, 2710-2712)
@@ -233,9 +274,15 @@ __global__ __launch_bounds__(RULES_THREADS) void k_env_rules(EnvCfg g, uint32_t*
                                                              int32_t* __restrict__ score_out,
                                                              int32_t* __restrict__ status) {
   __shared__ uint32_t lds[32 * RULES_THREADS];
+  __shared__ uint32_t lds_rng[(2 * MT_MAX_DRAWS + 1) * RULES_THREADS];
   const int env = blockIdx.x * RULES_THREADS + threadIdx.x;
   if (env >= g.N) return;
   if (mask != nullptr && mask[env] == 0) return;
+  MtBatch rng;
+  rng.mt = mt; rng.N = g.N; rng.env = env; rng.stride = RULES_THREADS;
+  rng.w = lds_rng + threadIdx.x;
+  rng.far = lds_rng + (MT_MAX_DRAWS + 1) * RULES_THREADS + threadIdx.x;
+  mt_batch_begin(rng, mode == 0 ? 2 * g.P * g.H : 2);  // a reset deals every hand, a move at most one card
   St s;
   s.p = lds + threadIdx.x;
   s.stride = RULES_THREADS;
@@ -256,7 +303,7 @@ __global__ __launch_bounds__(RULES_THREADS) void k_env_rules(EnvCfg g, uint32_t*
     s.set_next(0);  // GetSampledStartPlayer, random_start_player = false (hanabi_game.cc:138-145)
     s.set_turns(g.P);
     cur = -1;
-    while (cur == -1) deal_random(g, s, cur, mt, env);
+    while (cur == -1) deal_random(g, s, cur, rng);
     s.set_cur(cur);
   } else {
 #pragma unroll
@@ -343,13 +390,14 @@ __global__ __launch_bounds__(RULES_THREADS) void k_env_rules(EnvCfg g, uint32_t*
       cur = s.next();
       s.set_next((cur + 1) % g.P);
     }
-    while (cur == -1) deal_random(g, s, cur, mt, env);
+    while (cur == -1) deal_random(g, s, cur, rng);
     s.set_cur(cur);
     const int sc = env_score(g, s);
     reward[env] = sc - last_score;
     done[env] = (uint8_t)(env_end_status(g, s) != 0);
     score_out[env] = sc;
   }
+  mt_batch_commit(rng);
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     uint4 v;
