@@ -125,7 +125,7 @@ __device__ __forceinline__ void mlp_body(
     const int jl = 8 * i + (lane >> 3);
     jv[i] = jl < H.n_jobs ? reinterpret_cast<const int*>(jobs)[((size_t)jl * NW + wave) * 8 + (lane & 7)] : 0;
   }
-  const int chunks = H.hidden / 8;
+  const int chunks = H.in_width / 8;
   const int n_stage = MT * chunks;
   constexpr int SU = 4;  // rows-chunks per thread per trip (hidden = 512, 16 rows: exactly one trip)
   long long plane0[SU];

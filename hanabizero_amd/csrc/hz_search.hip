@@ -195,6 +195,8 @@ extern "C" int hz_search_run(hz_tree_t* t, int num_simulations, const hz_mlp_hea
     HZ_REQUIRE(H->wave_stream_off[w] % 8 == 0, "hz_search_run: weight streams must start on 16-B boundaries");
   HZ_REQUIRE(H->kstep_stride >= 512 * H->tiles_per_wave && H->kstep_stride % 8 == 0,
              "hz_search_run: kstep_stride must be a multiple of 8 and at least one k-step (512 * tiles_per_wave)");
+  HZ_REQUIRE(H->in_width > 0 && H->in_width % 8 == 0, "hz_search_run: in_width must be a positive multiple of 8");
+  HZ_REQUIRE(H->in_width == H->hidden && H->hidden <= 1024, "hz_search_run: the recurrent inference maps a hidden state (<= 1024 wide) to a hidden state");
   const size_t lds_bytes = (size_t)16 * H->row_stride * sizeof(uint16_t) + (size_t)16 * (t->S + 1) * (16 + 4) +
                            (size_t)16 * t->S * sizeof(float) + (size_t)(16 * 3 + 16 * t->A) * sizeof(float);
   HZ_REQUIRE(lds_bytes <= 160 * 1024, "hz_search_run: %zu B of LDS per workgroup exceed 160 KiB", lds_bytes);

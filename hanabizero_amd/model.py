@@ -276,6 +276,7 @@ class InferenceEngine:
             self.bw3 = self._stack([_fold(rw[3]), _fold(ac[3]), _fold(va[3])], self.out_pad, False)
         self.V = 2 * self.support + 1
         self.fused = FusedRecurrent(net, self) if self.use_fused else None
+        self.fused_tail = FusedInitialTail(net, self) if (self.use_fused and self.full) else None
         self._net, self._fused_shapes = net, {(4, 4): self.fused}
 
     def fused_shape(self, waves, tiles):
@@ -343,6 +344,17 @@ class InferenceEngine:
     # -- entry points -----------------------------------------------------------------------------------
     @torch.no_grad()
     def initial(self, obs):
+        if self.fused_tail is not None and obs.is_cuda:
+            # the two large representation layers as GEMMs, everything after them in one launch of the MFMA kernel
+            r, x = self.rep, obs.to(self.dtype)
+            x = r[0](x, relu=True)
+            x = self._add_relu(r[2](r[1](x, relu=True)), x)
+            N = x.shape[0]
+            state = torch.empty((N, self.H), dtype=self.dtype, device=x.device)
+            value = torch.empty(N, dtype=torch.float32, device=x.device)
+            logits = torch.empty((N, self.A), dtype=torch.float32, device=x.device)
+            self.fused_tail(x, state, value, logits)
+            return value, logits, state
         state = self._representation(obs.to(self.dtype))
         logits, value, _ = self._tails(self.pred1(state, relu=True), with_reward=False)
         return self._scalar(value), logits, state
@@ -424,7 +436,142 @@ def _pack_fragments(wblk, ks, tiles=4):
     return Wp[n, k].reshape(-1)
 
 
-class FusedRecurrent:
+class _FusedChain:
+    """A chain of Linear(+folded BN)(+residual)(+ReLU) layers as the job table + per-wave weight streams of the fused
+    MFMA kernel (include/hz_mlp.h).  Subclasses describe the layers with add_dense / add_group and call _finish."""
+
+    def __init__(self, engine, waves, tiles):
+        """waves x tiles: the workgroup shape of the kernel -- `waves` wavefronts, each producing `tiles` 16-column
+        MFMA tiles per job (4 x 4 stand-alone, 16 x 2 inside the persistent search kernel).  Same arithmetic per
+        output column either way (k accumulates in the same order), so the shapes give identical bits."""
+        assert engine.dtype == torch.bfloat16, "the fused kernel computes in bf16 (fp32 accumulate)"
+        assert (waves, tiles) in ((4, 4), (8, 4), (8, 2), (16, 2))
+        self.engine, self.device, self.waves, self.tiles = engine, engine.device, waves, tiles
+        self.cw = 16 * tiles   # output columns of one job
+        self._jobs = []        # [pass] -> dict(entries [wave] -> dict or None, barrier, store_hidden)
+
+    def add_dense(self, w, b, K, src_off, dst_off, relu, res_off=None, barrier=True, store_hidden=False, act_w=None):
+        """out[:, dst_off:dst_off+nout] = act(in[:, src_off:src_off+K] @ w^T + b ...), nout split into cw-column
+        wave jobs, `waves` per pass."""
+        cw, waves = self.cw, self.waves
+        nout = w.shape[0]
+        chunks = [(c, min(cw, nout - c)) for c in range(0, nout, cw)]
+        for p0 in range(0, len(chunks), waves):
+            row = []
+            for wave in range(waves):
+                if p0 + wave >= len(chunks):
+                    row.append(None)
+                    continue
+                c, n = chunks[p0 + wave]
+                row.append(dict(w=w[c:c + n], b=b[c:c + n], ks=K // 32, src=src_off, dst=dst_off + c,
+                                res=None if res_off is None else res_off + c, relu=relu,
+                                act=None if act_w is None else act_w[c:c + n]))
+            self._jobs.append(dict(entries=row, barrier=barrier and p0 == 0, store_hidden=store_hidden and p0 == 0))
+
+    def add_group(self, items, K, barrier=True):
+        """independent small layers (w, b, src, dst, res, relu) side by side: cut into cw-column jobs, `waves`
+        per pass."""
+        cw, waves = self.cw, self.waves
+        cut = []
+        for w, b, src, dst, res, relu in items:
+            for c in range(0, w.shape[0], cw):
+                cut.append(dict(w=w[c:c + cw], b=b[c:c + cw], ks=K // 32, src=src, dst=dst + c,
+                                res=None if res is None else res + c, relu=relu, act=None))
+        for p0 in range(0, len(cut), waves):
+            row = cut[p0:p0 + waves] + [None] * (waves - len(cut[p0:p0 + waves]))
+            self._jobs.append(dict(entries=row, barrier=barrier and p0 == 0, store_hidden=False))
+
+    def _finish(self, width, in_width, hidden, state_off, hidden_off, off_r, off_v, off_p):
+        from ._lib import MlpHeader, MlpJob
+        engine, waves, tiles, cw, jobs = self.engine, self.waves, self.tiles, self.cw, self._jobs
+        A, V = engine.A, 2 * engine.support + 1
+        streams = [[] for _ in range(waves)]
+        bias_chunks = []       # cw-float chunks
+        act_rows = []          # (bias chunk index, [A, cw] block)
+        rs = width + ((8 - width) % 128)
+        # flatten: job table, per-wave weight streams, biases, action table.  A pass with fewer jobs than waves goes to
+        # the waves that have streamed the least so far (the kernel is bound by the CU's weight stream: every wave
+        # should carry the same share of it and none should idle through whole layers)
+        table = []
+        load = [0] * waves
+        for job in jobs:
+            ents = [e for e in job["entries"] if e is not None]
+            order = sorted(range(waves), key=lambda w: (load[w], w))[:len(ents)]
+            row = [None] * waves
+            for w, e in zip(sorted(order), ents):
+                row[w] = e
+                load[w] += e["ks"]
+            pass_ks = max(e["ks"] for e in ents)
+            assert all(e["ks"] == pass_ks for e in ents), "jobs of one pass share their K"
+            for wave, e in enumerate(row):
+                flags = (MLP_BARRIER if job["barrier"] else 0) | (MLP_STORE_HIDDEN if job["store_hidden"] else 0)
+                if e is None:
+                    table.append(MlpJob(ks=0, src_off=0, dst_off=0, res_off=-1, bias_off=0, flags=flags, reserved0=pass_ks))
+                    continue
+                assert e["ks"] % 8 == 0, "K must be a multiple of 256 (8 k-steps)"
+                streams[wave].append(_pack_fragments(e["w"], e["ks"], tiles))
+                bias_off = cw * len(bias_chunks)
+                bc = torch.zeros(cw)
+                bc[:e["b"].shape[0]] = e["b"]
+                bias_chunks.append(bc)
+                if e["act"] is not None:
+                    act_rows.append((bias_off, e["act"]))
+                    flags |= MLP_ACTION_ROW
+                if e["relu"]:
+                    flags |= MLP_RELU
+                table.append(MlpJob(ks=e["ks"], src_off=e["src"], dst_off=e["dst"],
+                                    res_off=-1 if e["res"] is None else e["res"], bias_off=bias_off, flags=flags,
+                                    reserved0=pass_ks))
+        biases = torch.cat(bias_chunks)
+        act_table = torch.zeros(A + 1, biases.numel())      # row A stays zero: what jobs without an action row add
+        for off, blk in act_rows:                           # blk [n <= cw, A] = columns of the action block
+            act_table[:A, off:off + blk.shape[0]] = blk.t()
+        # weight streams, interleaved k-step by k-step: [k-step][wave][tiles * 512]; at any moment the waves of a
+        # workgroup (all near the same k-step) read one contiguous region
+        frag = tiles * 512
+        steps = [sum(x.numel() for x in st) // frag for st in streams]
+        P = max(steps) + 8                                  # 8 k-steps of zeros behind each stream (ring overrun)
+        W = torch.zeros(P, waves, frag)
+        for wave in range(waves):
+            if streams[wave]:
+                W[:steps[wave], wave] = torch.cat(streams[wave]).view(-1, frag)
+        hdr = MlpHeader(n_jobs=len(jobs), row_stride=rs, hidden=hidden, state_off=state_off, hidden_off=hidden_off,
+                        off_reward=off_r, off_value=off_v, off_policy=off_p, support_size=V, support_min=-engine.support,
+                        num_actions=A, action_table_stride=biases.numel(), in_width=in_width, num_waves=waves,
+                        tiles_per_wave=tiles, kstep_stride=waves * tiles * 512)
+        for wave in range(waves):
+            hdr.wave_stream_off[wave] = wave * frag
+        self.header = hdr
+        self.n_jobs = len(jobs)
+        buf = (MlpJob * len(table))(*table)
+        self.jobs = torch.frombuffer(bytearray(bytes(buf)), dtype=torch.uint8).to(self.device)
+        self.weights = W.reshape(-1).to(device=self.device, dtype=torch.bfloat16).contiguous()
+        self.biases = biases.to(device=self.device, dtype=torch.float32).contiguous()
+        self.act_table = act_table.to(device=self.device, dtype=torch.float32).contiguous()
+        self.row_stride = rs
+        self.weight_bytes_per_wg = int(sum(sum(x.numel() for x in s) for s in streams) * 2)
+        self._jobs = None
+
+    def lds_bytes(self, rows_per_wg):
+        return rows_per_wg * self.row_stride * 2
+
+    def rows_per_wg(self, N):
+        return 16 if N <= 16 * 256 or self.lds_bytes(32) > 160 * 1024 else 32
+
+    def _launch(self, state_src, row_stride, ix, plane_stride, actions, hidden_out, out_reward, out_value, out_policy, N,
+                rows_per_wg=None):
+        import ctypes as C
+        from ._lib import check, lib
+        mt = rows_per_wg or self.rows_per_wg(N)
+        check(lib.hz_mlp_recurrent(C.byref(self.header), self.jobs.data_ptr(), self.weights.data_ptr(),
+                                   self.biases.data_ptr(), self.act_table.data_ptr(), state_src.data_ptr(), row_stride,
+                                   None if ix is None else ix.data_ptr(), plane_stride, actions.data_ptr(),
+                                   hidden_out.data_ptr(), out_reward.data_ptr(), out_value.data_ptr(),
+                                   out_policy.data_ptr(), N, mt, C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+              "hz_mlp_recurrent")
+
+
+class FusedRecurrent(_FusedChain):
     """The search loop's recurrent_inference as ONE hand-written MFMA kernel (include/hz_mlp.h): gathers the parent
     hidden states from the pool, runs dynamics + reward/value/policy heads with every activation in LDS, applies the
     scalar transforms, writes the next hidden state into its pool slot.
@@ -433,50 +580,10 @@ class FusedRecurrent:
              out_policy [N, A])   (fp32 outputs; buffers supplied by the caller, nothing is allocated)"""
 
     def __init__(self, net, engine, waves=4, tiles=4):
-        """waves x tiles: the workgroup shape of the kernel -- `waves` wavefronts, each producing `tiles` 16-column
-        MFMA tiles per job (4 x 4 stand-alone, 16 x 2 inside the persistent search kernel).  Same arithmetic per
-        output column either way (k accumulates in the same order), so the two shapes give identical bits."""
-        from ._lib import MlpHeader, MlpJob
-        assert engine.dtype == torch.bfloat16, "the fused kernel computes in bf16 (fp32 accumulate)"
-        assert (waves, tiles) in ((4, 4), (8, 4), (8, 2), (16, 2))
-        self.engine, self.device, self.waves, self.tiles = engine, engine.device, waves, tiles
-        cw = 16 * tiles        # output columns of one job
+        super().__init__(engine, waves, tiles)
+        add_dense, add_group = self.add_dense, self.add_group
         H, A, h, full, V = engine.H, engine.A, engine.h, engine.full, 2 * engine.support + 1
         dyn, rw, ac, va = net._dynamics_state, net._dynamics_reward, net._prediction_actor, net._prediction_value
-        jobs = []              # [pass][wave] -> dict or None
-        streams = [[] for _ in range(waves)]
-        bias_chunks = []       # cw-float chunks
-        act_rows = []          # (bias chunk index, [A, 64] block)
-
-        def add_dense(w, b, K, src_off, dst_off, relu, res_off=None, barrier=True, store_hidden=False, act_w=None):
-            """out[:, dst_off:dst_off+nout] = act(in[:, src_off:src_off+K] @ w^T + b ...), nout split into cw-column
-            wave jobs, `waves` per pass."""
-            nout = w.shape[0]
-            chunks = [(c, min(cw, nout - c)) for c in range(0, nout, cw)]
-            for p0 in range(0, len(chunks), waves):
-                row = []
-                for wave in range(waves):
-                    if p0 + wave >= len(chunks):
-                        row.append(None)
-                        continue
-                    c, n = chunks[p0 + wave]
-                    row.append(dict(w=w[c:c + n], b=b[c:c + n], ks=K // 32, src=src_off, dst=dst_off + c,
-                                    res=None if res_off is None else res_off + c, relu=relu,
-                                    act=None if act_w is None else act_w[c:c + n]))
-                jobs.append(dict(entries=row, barrier=barrier and p0 == 0, store_hidden=store_hidden and p0 == 0))
-
-        def add_group(items, K, barrier=True):
-            """independent small layers (w, b, src, dst, res, relu) side by side: cut into cw-column jobs, `waves`
-            per pass."""
-            cut = []
-            for w, b, src, dst, res, relu in items:
-                for c in range(0, w.shape[0], cw):
-                    cut.append(dict(w=w[c:c + cw], b=b[c:c + cw], ks=K // 32, src=src, dst=dst + c,
-                                    res=None if res is None else res + c, relu=relu, act=None))
-            for p0 in range(0, len(cut), waves):
-                row = cut[p0:p0 + waves] + [None] * (waves - len(cut[p0:p0 + waves]))
-                jobs.append(dict(entries=row, barrier=barrier and p0 == 0, store_hidden=False))
-
         X, Y0, Y1 = 0, H, 2 * H
         w1, b1 = _fold(dyn.fc1, dyn.bn1)          # [H, H + A]: state block | action block
         w1s, w1a = w1[:, :H], w1[:, H:]           # the one-hot product = a row of w1a^T added in the epilogue
@@ -517,89 +624,62 @@ class FusedRecurrent:
             outs = [(_fold(rw[3]), Z, X), (_fold(ac[3]), Z + h, X + 64), (_fold(va[3]), Z + 2 * h, X + 128)]
             add_group([(w, b, src, dst, None, False) for (w, b), src, dst in outs], kpad)
             off_r, off_p, off_v, width = X, X + 64, X + 128, 3 * H
-        rs = width + ((8 - width) % 128)
-        # flatten: job table, per-wave weight streams, biases, action table.  A pass with fewer jobs than waves goes to
-        # the waves that have streamed the least so far (the kernel is bound by the CU's weight stream: every wave
-        # should carry the same share of it and none should idle through whole layers)
-        table = []
-        load = [0] * waves
-        for job in jobs:
-            ents = [e for e in job["entries"] if e is not None]
-            order = sorted(range(waves), key=lambda w: (load[w], w))[:len(ents)]
-            row = [None] * waves
-            for w, e in zip(sorted(order), ents):
-                row[w] = e
-                load[w] += e["ks"]
-            pass_ks = max(e["ks"] for e in ents)
-            assert all(e["ks"] == pass_ks for e in ents), "jobs of one pass share their K"
-            for wave, e in enumerate(row):
-                flags = (MLP_BARRIER if job["barrier"] else 0) | (MLP_STORE_HIDDEN if job["store_hidden"] else 0)
-                if e is None:
-                    table.append(MlpJob(ks=0, src_off=0, dst_off=0, res_off=-1, bias_off=0, flags=flags, reserved0=pass_ks))
-                    continue
-                assert e["ks"] % 8 == 0, "K must be a multiple of 256 (8 k-steps)"
-                streams[wave].append(_pack_fragments(e["w"], e["ks"], tiles))
-                bias_off = cw * len(bias_chunks)
-                bc = torch.zeros(cw)
-                bc[:e["b"].shape[0]] = e["b"]
-                bias_chunks.append(bc)
-                if e["act"] is not None:
-                    act_rows.append((bias_off, e["act"]))
-                    flags |= MLP_ACTION_ROW
-                if e["relu"]:
-                    flags |= MLP_RELU
-                table.append(MlpJob(ks=e["ks"], src_off=e["src"], dst_off=e["dst"],
-                                    res_off=-1 if e["res"] is None else e["res"], bias_off=bias_off, flags=flags,
-                                    reserved0=pass_ks))
-        biases = torch.cat(bias_chunks)
-        act_table = torch.zeros(A + 1, biases.numel())      # row A stays zero: what jobs without an action row add
-        for off, blk in act_rows:                           # blk [n <= cw, A] = columns of the action block
-            act_table[:A, off:off + blk.shape[0]] = blk.t()
-        # weight streams, interleaved k-step by k-step: [k-step][wave][tiles * 512]; at any moment the waves of a
-        # workgroup (all near the same k-step) read one contiguous region, so every L2 channel carries an equal share
-        frag = tiles * 512
-        steps = [sum(x.numel() for x in st) // frag for st in streams]
-        P = max(steps) + 8                                  # 8 k-steps of zeros behind each stream (ring overrun)
-        W = torch.zeros(P, waves, frag)
-        for wave in range(waves):
-            if streams[wave]:
-                W[:steps[wave], wave] = torch.cat(streams[wave]).view(-1, frag)
-        offs, parts = [wave * frag for wave in range(waves)], [W.reshape(-1)]
-        hdr = MlpHeader(n_jobs=len(jobs), row_stride=rs, hidden=H, state_off=X, hidden_off=Y0, off_reward=off_r,
-                        off_value=off_v, off_policy=off_p, support_size=V, support_min=-engine.support, num_actions=A,
-                        action_table_stride=biases.numel(), num_waves=waves, tiles_per_wave=tiles, kstep_stride=waves * tiles * 512)
-        for wave in range(waves):
-            hdr.wave_stream_off[wave] = offs[wave]
-        import ctypes as C
-        self.header = hdr
-        self.n_jobs = len(jobs)
-        buf = (MlpJob * len(table))(*table)
-        self.jobs = torch.frombuffer(bytearray(bytes(buf)), dtype=torch.uint8).to(self.device)
-        self.weights = torch.cat(parts).to(device=self.device, dtype=torch.bfloat16).contiguous()
-        self.biases = biases.to(device=self.device, dtype=torch.float32).contiguous()
-        self.act_table = act_table.to(device=self.device, dtype=torch.float32).contiguous()
-        self.row_stride = rs
-        self.weight_bytes_per_wg = int(sum(sum(x.numel() for x in s) for s in streams) * 2)
-
-    def lds_bytes(self, rows_per_wg):
-        return rows_per_wg * self.row_stride * 2
-
-    def rows_per_wg(self, N):
-        return 16 if N <= 16 * 256 or self.lds_bytes(32) > 160 * 1024 else 32
+        self._finish(width, in_width=H, hidden=H, state_off=X, hidden_off=Y0, off_r=off_r, off_v=off_v, off_p=off_p)
 
     def __call__(self, pool, ix, actions, hidden_out, out_reward, out_value, out_policy, rows_per_wg=None):
         """pool [S, N, H] (or a [N, H] matrix of states with ix=None)."""
-        import ctypes as C
-        from ._lib import check, lib
         if pool.dim() == 3:
             N, row_stride, plane_stride = pool.shape[1], pool.stride(1), pool.stride(0)
         else:
             N, row_stride, plane_stride = pool.shape[0], pool.stride(0), 0
-        mt = rows_per_wg or self.rows_per_wg(N)
-        check(lib.hz_mlp_recurrent(C.byref(self.header), self.jobs.data_ptr(), self.weights.data_ptr(),
-                                   self.biases.data_ptr(), self.act_table.data_ptr(), pool.data_ptr(), row_stride,
-                                   None if ix is None else ix.data_ptr(), plane_stride, actions.data_ptr(),
-                                   hidden_out.data_ptr(), out_reward.data_ptr(), out_value.data_ptr(),
-                                   out_policy.data_ptr(), N, mt, C.c_void_p(torch.cuda.current_stream().cuda_stream)),
-              "hz_mlp_recurrent")
+        self._launch(pool, row_stride, ix, plane_stride, actions, hidden_out, out_reward, out_value, out_policy, N,
+                     rows_per_wg)
         return out_reward, out_value, out_policy
+
+
+class FusedInitialTail(_FusedChain):
+    """The small-GEMM tail of initial_inference (core/model.py:61-71) for MuZeroNetFull as ONE launch of the same MFMA
+    kernel: from the output of the first residual block of the representation net (config/hanabi_control/model.py:
+    235-248: Linear-BN-ReLU 1024 -> 512, NewResMLP(512)) through the prediction net (:250-269) to the hidden state,
+    the value scalar and the policy logits.  In PyTorch that is 11 GEMMs of 4096 x <= 512 x <= 1024 plus glue, each
+    bound by its launch; the two large representation layers before it stay hipBLASLt GEMMs.
+
+    __call__(x [N, 1024] bf16, hidden_out [N, H] bf16, out_value [N] f32, out_policy [N, A] f32)"""
+
+    def __init__(self, net, engine, waves=4, tiles=4):
+        super().__init__(engine, waves, tiles)
+        assert engine.full, "laid out for MuZeroNetFull"
+        add_dense, add_group = self.add_dense, self.add_group
+        H, A, h, V = engine.H, engine.A, engine.h, 2 * engine.support + 1
+        rep, ac, va = net._representation, net._prediction_actor, net._prediction_value
+        w3, b3 = _fold(rep[4], rep[5])                     # 1024 -> H
+        IN = w3.shape[1]
+        assert IN % 256 == 0 and H % 256 == 0 and h % 256 == 0 and IN >= 2 * H and 2 * h <= H
+        T0 = IN                                             # image columns: IN [0, IN) | T0 [IN, IN + H) | U | V3
+        T1, S, Z = 0, H, T0                                 # T1 and S reuse the dead input, Z reuses T0
+        Ta, Tv = 0, h                                       # ... and the second head layers reuse T1
+        U, V3 = IN + H, IN + H + h
+        add_dense(w3, b3, IN, 0, T0, relu=True, barrier=False)
+        add_dense(*_fold(rep[7].fc1, rep[7].bn1), H, T0, T1, relu=True)
+        add_dense(*_fold(rep[7].fc2, rep[7].bn2), H, T1, S, relu=True, res_off=T0)
+        wh = torch.cat([_fold(ac[0], ac[1])[0], _fold(va[0], va[1])[0]], 0)
+        bh = torch.cat([_fold(ac[0], ac[1])[1], _fold(va[0], va[1])[1]], 0)
+        add_dense(wh, bh, H, S, Z, relu=True, store_hidden=True)           # actor | value first layers
+        add_group([(*_fold(ac[3].fc1, ac[3].bn1), Z, Ta, None, True), (*_fold(va[3], va[4]), Z + h, Tv, None, True)], h)
+        add_group([(*_fold(ac[3].fc2, ac[3].bn2), Ta, U, Z, True), (*_fold(va[6]), Tv, V3, None, False)], h)
+        add_dense(*_fold(ac[4]), h, U, Z, relu=False, barrier=True)        # policy logits over the dead Z
+        width = V3 + ((V + 63) // 64) * 64
+        self.in_width = IN
+        self._finish(width, in_width=IN, hidden=H, state_off=0, hidden_off=S, off_r=V3, off_v=V3, off_p=Z)
+        self._zeros = None
+
+    def __call__(self, x, hidden_out, out_value, out_policy, rows_per_wg=None):
+        N = x.shape[0]
+        assert x.dtype == torch.bfloat16 and x.shape[1] == self.in_width and x.stride(1) == 1
+        if self._zeros is None or self._zeros[0].shape[0] < N:
+            self._zeros = (torch.zeros(N, dtype=torch.int32, device=x.device), torch.empty(N, dtype=torch.float32, device=x.device))
+        actions, dummy = self._zeros
+        self._launch(x, x.stride(0), None, 0, actions, hidden_out, dummy, out_value, out_policy, N, rows_per_wg)
+        return out_value, out_policy
+
+

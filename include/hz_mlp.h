@@ -49,12 +49,16 @@ typedef struct {
 typedef struct {
   int32_t n_jobs;      /* <= 32 */
   int32_t row_stride;  /* LDS elements per row, multiple of 8, = 8 (mod 128) for conflict-free ds_read_b128 */
-  int32_t hidden;      /* width of the hidden state (multiple of 8) */
+  int32_t hidden;      /* width of the hidden state written by HZ_MLP_STORE_HIDDEN (multiple of 8) */
   int32_t state_off;   /* LDS column where the input hidden state is staged */
   int32_t hidden_off;  /* LDS column of the next hidden state when HZ_MLP_STORE_HIDDEN fires */
   int32_t off_reward, off_value, off_policy; /* LDS columns of the final reward / value / policy logits */
   int32_t support_size, support_min, num_actions;
   int32_t action_table_stride;   /* fp32 elements per action row */
+  int32_t in_width;              /* elements of an input row staged at state_off (multiple of 8; = hidden for the
+                                    recurrent inference, the width of the last big representation layer for the tail
+                                    of the initial inference) */
+  int32_t reserved;
   int32_t num_waves;             /* 4 (stand-alone kernel) or 16 (inside hz_search_run) */
   int32_t tiles_per_wave;        /* 16-column MFMA tiles per job: 4 with 4 waves, 2 with 16 waves */
   int64_t kstep_stride;          /* elements between consecutive k-steps of one wave's stream: 512 * tiles_per_wave when

@@ -202,3 +202,30 @@ def test_fused_mfma_kernel_workgroup_shapes_give_identical_bits(game, shape):
     torch.cuda.synchronize()
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [100, 4096])
+def test_fused_initial_tail_matches_gemm_path(N):
+    """FusedInitialTail (the small-GEMM tail of initial_inference in one MFMA launch) against the layer-by-layer bf16
+    GEMM path it replaces (same rounding points) and the fp32 engine."""
+    from hanabizero_amd.model import InferenceEngine
+    net, fx, sup = build("Hanabi-Full")
+    eng = InferenceEngine(net, sup, dtype=torch.bfloat16, device="cuda")
+    assert eng.fused_tail is not None
+    g = torch.Generator(device="cuda").manual_seed(N)
+    D = int(fx["D"]) * int(fx["stack"])
+    obs = (torch.rand(N, D, device="cuda", generator=g) < 0.15).to(torch.bfloat16)  # sparse 0/1 rows like the encoder's
+    v, p, h = eng.initial(obs)
+    tail, eng.fused_tail = eng.fused_tail, None
+    v_ref, p_ref, h_ref = eng.initial(obs)
+    eng.fused_tail = tail
+    e32 = InferenceEngine(net, sup, dtype=torch.float32, device="cuda")
+    v32, p32, h32 = e32.initial(obs.float())
+
+    def mean_err(a, b):
+        return float(((a.float() - b.float()).abs() / b.float().abs().clamp(min=1.0)).mean())
+    for name, got, ref, truth in [("hidden", h, h_ref, h32), ("policy", p, p_ref, p32), ("value", v, v_ref, v32)]:
+        assert got.shape == ref.shape and torch.isfinite(got.float()).all()
+        assert mean_err(got, truth) <= 1.3 * mean_err(ref, truth) + 1e-4, (name, mean_err(got, truth), mean_err(ref, truth))
+    assert float((h.float() - h32).abs().mean()) < 6e-3
