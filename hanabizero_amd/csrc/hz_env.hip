@@ -406,6 +406,112 @@ __global__ __launch_bounds__(RULES_THREADS) void k_env_rules(EnvCfg g, uint32_t*
   }
 }
 
+// ---- reset, one WAVE per env --------------------------------------------------------------------------------
+// A reset deals players * hand_size cards one after the other; each deal is a std::discrete_distribution draw over the
+// remaining card types (two passes over up to 25 fp64 probabilities, summed in order) -- ~80 us when one lane does it
+// all (k_env_rules mode 0), whatever the number of envs.  Here a wave owns the env: lane uid holds the count of card
+// type uid, the order-sensitive fp64 sums walk the ballot of present types with v_readlane (each deal still adds in the
+// reference's order), and all mt19937 words of the 2 * players * hand_size draws are regenerated by the lanes in
+// parallel (every input of the recurrence is an OLD word as long as fewer than 227 are drawn: see mt_batch_begin).
+// Same state bits and the same generator state as the lane-per-env path (tests/test_hip_env.py).
+__global__ __launch_bounds__(256) void k_env_reset_wave(EnvCfg g, uint32_t* __restrict__ state, uint32_t* __restrict__ mt,
+                                                        const uint8_t* __restrict__ mask) {
+  __shared__ uint32_t st_s[4][32];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int env = blockIdx.x * 4 + wave;
+  if (env >= g.N) return;
+  if (mask != nullptr && mask[env] == 0) return;
+  const int ncards = g.C * g.R, deals = g.P * g.H, n = 2 * deals;
+#define MT(k) mt[(size_t)(k) * g.N + env]
+  int idx0 = (int)MT(624);
+  if (idx0 >= 624) idx0 = 0;
+  idx0 = __builtin_amdgcn_readfirstlane(idx0);
+  const uint32_t wk = lane <= n ? MT(mt_wrap(idx0 + lane)) : 0u;
+  const uint32_t fk = lane < n ? MT(mt_wrap(mt_wrap(idx0 + lane) + 397)) : 0u;
+  const uint32_t wk1 = (uint32_t)__shfl_down((int)wk, 1);
+  const uint32_t y = (wk & 0x80000000u) | (wk1 & 0x7fffffffu);
+  const uint32_t neww = fk ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+  uint32_t out = neww;  // lane k: the k-th draw of this call
+  out ^= (out >> 11);
+  out ^= (out << 7) & 0x9d2c5680u;
+  out ^= (out << 15) & 0xefc60000u;
+  out ^= (out >> 18);
+
+  uint32_t* st = st_s[wave];
+  if (lane < 32) st[lane] = 0u;
+  int cnt = lane < ncards ? g.inst[lane % g.R] : 0;  // HanabiDeck ctor (hanabi_state.cc:53-64): lane = color * R + rank
+  int total = 0;
+  for (int r = 0; r < g.R; ++r) total += g.inst[r];
+  total *= g.C;
+  int pos = 0;
+  for (int deal = 0; deal < deals; ++deal) {
+    // ApplyRandomChance (hanabi_state.cc:282-286) -> PickRandomChance (hanabi_game.cc:106-112): see deal_random
+    const double tot = (double)total;
+    const double q1 = 1.0 / tot, q2 = 2.0 / tot, q3 = 3.0 / tot;
+    const uint64_t present = __ballot(cnt > 0);
+    const int n_out = __popcll((unsigned long long)present);
+    double sum = 0.0;
+    int pick = 0;
+    for (uint64_t m = present; m;) {
+      const int uid = __ffsll((unsigned long long)m) - 1;
+      m &= m - 1;
+      const int c = __builtin_amdgcn_readlane(cnt, uid);
+      sum += c == 1 ? q1 : (c == 2 ? q2 : q3);
+      pick = uid;
+    }
+    if (n_out >= 2) {
+      const double lo = (double)(uint32_t)__builtin_amdgcn_readlane((int)out, pos);
+      const double hi = (double)(uint32_t)__builtin_amdgcn_readlane((int)out, pos + 1);
+      pos += 2;
+      double u = (lo + hi * 4294967296.0) / 18446744073709551616.0;
+      if (u >= 1.0) u = 0x1.fffffffffffffp-1;
+      const double p1 = q1 / sum, p2 = q2 / sum, p3 = q3 / sum;
+      double acc = 0.0;
+      int seen = 0;
+      for (uint64_t m = present; m;) {
+        const int uid = __ffsll((unsigned long long)m) - 1;
+        m &= m - 1;
+        const int c = __builtin_amdgcn_readlane(cnt, uid);
+        const double p = c == 1 ? p1 : (c == 2 ? p2 : p3);
+        acc = (seen == 0) ? p : acc + p;
+        ++seen;
+        const double cp = (seen == n_out) ? 1.0 : acc;
+        if (!(cp < u)) {
+          pick = uid;
+          break;
+        }
+      }
+    }
+    pick = __builtin_amdgcn_readfirstlane(pick);
+    // the chance player deals to the first player whose hand is not full (hanabi_state.cc:157-164): hands fill in order
+    if (lane == 0)
+      st[deal] = (uint32_t)(pick / g.R) | ((uint32_t)(pick % g.R) << 3) | (((1u << g.C) - 1u) << 6) |
+                 (((1u << g.R) - 1u) << 11);  // fresh CardKnowledge (hanabi_hand.cc:24-27, 44-45); deal = player * H + slot
+    if (lane == pick) cnt -= 1;
+    total -= 1;
+  }
+  // deck counters (2 bits per card type, 16 per word), hand sizes, tokens, players: the bits k_env_rules mode 0 leaves
+  if (lane < ncards && cnt != 0) atomicOr(&st[25 + (lane >> 4)], (uint32_t)cnt << ((lane & 15) * 2));
+  if (lane == 0) {
+    uint32_t w30 = (uint32_t)total << 15;
+    for (int pl = 0; pl < g.P; ++pl) w30 |= (uint32_t)g.H << (3 * pl);
+    st[30] = w30;
+    // info, life, current player 0, next player 1 % P (GetSampledStartPlayer without random start, then
+    // AdvanceToNextPlayer once the hands are full), turns_to_play = P
+    st[29] = ((uint32_t)g.max_info << 15) | ((uint32_t)g.max_life << 19) | (0u << 21) | ((uint32_t)(1 % g.P) << 24) |
+             ((uint32_t)g.P << 27);
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (lane < 32) state[(size_t)env * 32 + lane] = st[lane];
+  if (lane < pos) MT(mt_wrap(idx0 + lane)) = neww;
+  if (lane == 0) {
+    const int idx = idx0 + pos;
+    MT(624) = (uint32_t)(idx > 624 ? idx - 624 : idx);
+  }
+#undef MT
+}
+
 // ---- observation kernel: one wave per env ----------------------------------------------------------------
 __device__ __forceinline__ void or_bits(uint32_t* bits, int off, uint32_t value, int nbits) {
   if (value == 0) return;
@@ -640,10 +746,9 @@ extern "C" int hz_env_dims(const hz_env_t* e, int* num_moves, int* obs_len, int*
 
 extern "C" int hz_env_reset(hz_env_t* e, const uint8_t* mask, void* stream) {
   HZ_REQUIRE(e != nullptr, "hz_env_reset: NULL handle");
-  const int blocks = (e->cfg.N + RULES_THREADS - 1) / RULES_THREADS;
-  hipLaunchKernelGGL(k_env_rules, dim3(blocks), dim3(RULES_THREADS), 0, (hipStream_t)stream, e->cfg, e->state, e->mt, 0,
-                     (const int32_t*)nullptr, mask, (int32_t*)nullptr, (uint8_t*)nullptr, (int32_t*)nullptr,
-                     (int32_t*)nullptr);
+  // one wave per env (envs not in the mask leave at once); k_env_rules mode 0 is the lane-per-env form of the same reset
+  hipLaunchKernelGGL(k_env_reset_wave, dim3((e->cfg.N + 3) / 4), dim3(256), 0, (hipStream_t)stream, e->cfg, e->state,
+                     e->mt, mask);
   HZ_HIP(hipGetLastError());
   return 0;
 }
