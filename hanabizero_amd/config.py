@@ -35,7 +35,8 @@ def make_args(**kw):
 
 
 class _HanabiConfig:
-    def __init__(self, args, max_moves, support, training_steps, last_steps, checkpoint_interval, test_episodes):
+    def __init__(self, args, max_moves, support, training_steps, last_steps, checkpoint_interval, test_episodes,
+                 lr_warm_up=0.001):
         # core/config.py:95-131 and the per-game constructors
         self.num_simulations = args.simulations
         self.batch_size, self.td_steps, self.num_actors = args.batch_size, args.td_steps, args.actors
@@ -57,6 +58,11 @@ class _HanabiConfig:
         self.change_temperature = False
         self.init_zero = True
         self.prioritized_replay_eps = 1e-6
+        # learner (core/config.py:98, 136, 153-161; config/hanabi_control/__init__.py:43, 161)
+        self.max_grad_norm, self.weight_decay, self.momentum = 5, 1e-4, 0.9
+        self.priority_reward_ratio = 0
+        self.lr_warm_up = lr_warm_up
+        self.lr_warm_step = int(training_steps * lr_warm_up)
         self.lr_init, self.lr_decay_rate, self.lr_decay_steps = args.lr, args.decay_rate, args.decay_step
         self.value_loss_coeff, self.reward_loss_coeff, self.policy_loss_coeff = args.val_coeff, 1, 1
         self.consistency_coeff = self.const = getattr(args, "const", 0.0)
@@ -127,7 +133,7 @@ class HanabiControlConfigFull(_HanabiConfig):  # Hanabi-Full (__init__.py:128-24
     def __init__(self, args=None):
         args = args or make_args(env="Hanabi-Full")
         super().__init__(args, max_moves=160, support=100, training_steps=3000000, last_steps=100,
-                         checkpoint_interval=2000, test_episodes=80)
+                         checkpoint_interval=2000, test_episodes=80, lr_warm_up=0.0001)
 
     def get_uniform_network(self):
         assert self.env_name in ("Hanabi-Full", "Hanabi-Full-5p")

@@ -1,0 +1,206 @@
+"""hanabizero_amd.learner -- the learner step of HanabiZero on PyTorch-ROCm.
+
+What it replaces: ``update_weights`` (/root/reference/core/train.py:59-314) and the optimiser / learning-rate plumbing
+of ``_train`` (train.py:317-400, ``adjust_lr`` :32-51).  Same losses, same targets, same gradient shaping:
+
+  * targets: ``scalar_transform`` (core/config.py:192-202) then the two-hot ``phi`` over the integer support
+    (config.py:240-253);
+  * losses: cross-entropy of the categorical value / reward heads against those two-hots and of the policy logits against
+    the MCTS visit distributions (config/hanabi_control/__init__.py:119-123; train.py:145-168), summed over the initial
+    step and ``num_unroll_steps`` recurrent steps, weighted by the prioritised-replay importance weights;
+  * gradient shaping: the hidden state's gradient is halved at every unroll step (train.py:169) and the total loss's by
+    ``1 / num_unroll_steps`` (train.py:222-229); ``clip_grad_norm_(max_grad_norm)`` (train.py:241);
+  * priorities: ``(1 - r) * |value - target| + r * mean_k |reward_k - target_k|`` + eps (train.py:141-143, 250-252).
+
+The reference runs the forward passes under fp16 ``autocast`` with a ``GradScaler`` (train.py:125, 153, 225-245).  On
+MI355X the step runs under **bf16** autocast (hipBLASLt GEMMs on the matrix cores; no loss scaling needed with bf16's fp32
+exponent range), or in plain fp32 with ``amp=None`` -- the mode the CPU tests pin the arithmetic in.  The consistency loss
+is asserted off in the reference for Hanabi (train.py:158-160: "will not run here") and is not built.
+
+Ray is gone: instead of ``replay_buffer.update_priorities.remote(...)`` the new priorities are returned to the caller.
+The nets are the state_dict-compatible modules of ``hanabizero_amd.model``, so a learner started from a reference
+checkpoint continues it, and ``hanabizero_amd.dist.broadcast_weights`` ships ``model.get_weights()`` to the actors.
+"""
+import numpy as np
+import torch
+
+
+# ---- targets (core/config.py) ------------------------------------------------------------------------------
+def scalar_transform(x, delta=1.0, epsilon=0.001):
+    """h(x) = sign(x) (sqrt(|x| + 1) - 1) + eps x   (core/config.py:192-202, with the reference's support delta)."""
+    sign = torch.ones_like(x)
+    sign[x < 0] = -1.0
+    return sign * (torch.sqrt(torch.abs(x / delta) + 1) - 1) + epsilon * x / delta
+
+
+def phi(x, support_min, support_max, support_size, delta=1.0):
+    """Two-hot encoding of transformed scalars [B, T] over the integer support (core/config.py:240-253): mass
+    ``x - floor(x)`` on ceil(x) and the rest on floor(x) (an integer x puts everything on itself: the second scatter
+    overwrites the first, exactly as in the reference)."""
+    x = x.clamp(support_min, support_max)
+    x_low, x_high = x.floor(), x.ceil()
+    p_high = x - x_low
+    p_low = 1 - p_high
+    target = torch.zeros(x.shape[0], x.shape[1], support_size, device=x.device, dtype=x.dtype)
+    hi, lo = x_high - support_min / delta, x_low - support_min / delta
+    target.scatter_(2, hi.long().unsqueeze(-1), p_high.unsqueeze(-1))
+    target.scatter_(2, lo.long().unsqueeze(-1), p_low.unsqueeze(-1))
+    return target
+
+
+def scalar_loss(prediction, target):
+    """config/hanabi_control/__init__.py:119-123 (value and reward alike)."""
+    return -(torch.log_softmax(prediction, dim=1) * target).sum(1)
+
+
+# ---- optimiser and schedule (core/train.py:32-51, 327-328) -------------------------------------------------------
+def make_optimizer(model, config):
+    return torch.optim.SGD(model.parameters(), lr=config.lr_init, momentum=config.momentum,
+                           weight_decay=config.weight_decay)
+
+
+def adjust_lr(config, optimizer, step_count):
+    """Linear warm-up over lr_warm_step steps, then step decay floored at 1e-4 (train.py:32-51, lr_type 'step')."""
+    if step_count < config.lr_warm_step:
+        lr = config.lr_init * step_count / config.lr_warm_step
+    else:
+        lr = config.lr_init * config.lr_decay_rate ** ((step_count - config.lr_warm_step) // config.lr_decay_steps)
+        lr = lr if lr >= 0.0001 else 0.0001
+    for group in optimizer.param_groups:
+        group["lr"] = lr
+    return lr
+
+
+# ---- batches (core/reanalyze_worker.py, the parts that do not search) ---------------------------------------------
+def make_batch(games, positions, config, value_fn, weights=None, rng=None):
+    """A learner batch in the reference's layout from finished ``GameHistory`` objects and sampled positions:
+    inputs as BatchWorker_CPU.make_batch assembles them (reanalyze_worker.py:148-168: stacked observations padded with
+    the last frame, actions padded with random ones past the end, mask), value / reward targets as
+    BatchWorker_GPU._prepare_reward_value (:249-304: td_steps-step return bootstrapped from ``value_fn`` of the
+    observation td_steps ahead, zero past the end), policy targets from the stored search statistics as
+    _prepare_policy_non_re (:374-399: child visits, zeros past the end).  ``value_fn(obs [M, stack * D] float32 numpy)
+    -> [M] values`` is the target model (e.g. ``lambda o: engine.initial(torch.from_numpy(o).cuda())[0].cpu().numpy()``).
+    Policy targets re-searched with the current model (reanalyze) come from hanabizero_amd.reanalyze.prepare_policy_re."""
+    rng = rng or np.random
+    U, td, stack, A, g = config.num_unroll_steps, config.td_steps, config.stacked_observations, config.action_space_size, config.discount
+    B = len(games)
+    obs_lst, action_lst, mask_lst, value_obs, value_mask = [], [], [], [], []
+    for game, pos in zip(games, positions):
+        acts = [int(a) for a in game.actions[pos:pos + U]]
+        mask = [1.0] * len(acts) + [0.0] * (U - len(acts))
+        acts += [int(rng.randint(0, A)) for _ in range(U - len(acts))]
+        obs_lst.append(np.asarray(game.obs(pos, extra_len=U, padding=True), dtype=np.float32))
+        action_lst.append(acts)
+        mask_lst.append(mask)
+        traj_len = len(game)
+        game_obs = game.obs(pos + td, U)  # :204-222 bootstrap observations, zero_obs past the end
+        for cur in range(pos, pos + U + 1):
+            boot = cur + td
+            if boot < traj_len:
+                value_mask.append(1.0)
+                beg = cur - pos
+                value_obs.append(np.asarray(game_obs[beg:beg + stack], dtype=np.float32).reshape(-1))
+            else:
+                value_mask.append(0.0)
+                value_obs.append(np.zeros(config.obs_shape, np.float32))
+    values = np.asarray(value_fn(np.stack(value_obs)), dtype=np.float64).reshape(-1) * (g ** td) * np.asarray(value_mask)
+    target_value = np.zeros((B, U + 1), np.float32)
+    target_reward = np.zeros((B, U + 1), np.float32)
+    target_policy = np.zeros((B, U + 1, A), np.float32)
+    k = 0
+    for b, (game, pos) in enumerate(zip(games, positions)):
+        traj_len = len(game)
+        for j, cur in enumerate(range(pos, pos + U + 1)):
+            v = values[k]
+            for i, r in enumerate(game.rewards[cur:cur + td]):
+                v += r * g ** i
+            if cur < traj_len:
+                target_value[b, j], target_reward[b, j] = v, game.rewards[cur]
+                target_policy[b, j] = game.child_visits[cur]
+            k += 1
+    w = np.ones(B, np.float32) if weights is None else np.asarray(weights, np.float32)
+    inputs = (np.stack(obs_lst), np.asarray(action_lst, np.int64), np.asarray(mask_lst, np.float32), np.arange(B), w, np.zeros(B))
+    return inputs, (target_reward[:, :U + 1], target_value, target_policy)
+
+
+# ---- one learner step ------------------------------------------------------------------------------------------
+def _t(a, device, dtype=torch.float32):
+    t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.asarray(a))
+    return t.to(device=device, dtype=dtype)
+
+
+def compute_losses(model, config, obs_batch, action_batch, target_reward, target_value, target_policy, weights,
+                   amp=torch.bfloat16):
+    """The forward part of update_weights (train.py:114-222).  Tensors on the model's device:
+    obs_batch [B, stack * D] (the first stacked window of the batch), action_batch [B, U] long, target_reward [B, U],
+    target_value / target_policy [B, U + 1] / [B, U + 1, A], weights [B].
+    Returns (weighted_loss, dict of per-sample losses and priorities' ingredients)."""
+    U = config.num_unroll_steps
+    B = obs_batch.shape[0]
+    dev = obs_batch.device
+    vs, rs = config.value_support, config.reward_support
+    target_reward_phi = phi(scalar_transform(target_reward, vs.delta), rs.min, rs.max, rs.size, vs.delta)
+    target_value_phi = phi(scalar_transform(target_value, vs.delta), vs.min, vs.max, vs.size, vs.delta)
+
+    def cast():
+        return torch.autocast(device_type=dev.type, dtype=amp) if amp is not None else torch.autocast(dev.type, enabled=False)
+
+    with cast():
+        value, _, policy_logits, hidden_state = model.initial_inference(obs_batch.reshape(B, -1))
+    scaled_value = config.inverse_value_transform(value.float())
+    value_priority = (scaled_value.reshape(B) - target_value[:, 0]).abs().detach()
+    value_loss = scalar_loss(value.float(), target_value_phi[:, 0])
+    policy_loss = -(torch.log_softmax(policy_logits.float(), dim=1) * target_policy[:, 0]).sum(1)
+    reward_loss = torch.zeros(B, device=dev)
+    reward_priority = []
+    with cast():
+        for k in range(U):
+            value, reward, policy_logits, hidden_state = model.recurrent_inference(hidden_state, action_batch[:, k:k + 1])
+            policy_loss = policy_loss - (torch.log_softmax(policy_logits.float(), dim=1) * target_policy[:, k + 1]).sum(1)
+            value_loss = value_loss + scalar_loss(value.float(), target_value_phi[:, k + 1])
+            reward_loss = reward_loss + scalar_loss(reward.float(), target_reward_phi[:, k])
+            if hidden_state.requires_grad:
+                hidden_state.register_hook(lambda grad: grad * 0.5)  # train.py:169
+            scaled_reward = config.inverse_reward_transform(reward.detach().float())
+            reward_priority.append((scaled_reward.reshape(B) - target_reward[:, k]).abs())
+    loss = config.policy_loss_coeff * policy_loss + config.value_loss_coeff * value_loss + config.reward_loss_coeff * reward_loss
+    weighted_loss = (weights * loss).mean()
+    return weighted_loss, dict(loss=loss, policy_loss=policy_loss, value_loss=value_loss, reward_loss=reward_loss,
+                               value_priority=value_priority, reward_priority=torch.stack(reward_priority).mean(0))
+
+
+def update_weights(model, batch, optimizer, config, amp=torch.bfloat16):
+    """One learner step on a batch in the reference's layout (train.py:59-70):
+        batch = ((obs_batch_ori [B, stack + U, D], action_batch [B, U], mask_batch [B, U], indices, weights [B], make_time),
+                 (target_reward [B, U], target_value [B, U + 1], target_policy [B, U + 1, A]))
+    numpy arrays or tensors.  Returns (loss_data, new_priority [B] numpy) with loss_data = (total, weighted, mean loss,
+    0, mean policy, mean reward, mean value, 0.0) as the reference logs it (train.py:255-256)."""
+    (obs_batch_ori, action_batch, mask_batch, indices, weights, make_time), (target_reward, target_value, target_policy) = batch
+    target_reward = np.asarray(target_reward)[:, :config.num_unroll_steps] if not isinstance(target_reward, torch.Tensor) \
+        else target_reward[:, :config.num_unroll_steps]
+    dev = next(model.parameters()).device
+    obs_batch_ori = _t(obs_batch_ori, dev)
+    # non-image branch of train.py:71-74: image_channel = 1, the first `stack` observations are the model input
+    obs_batch = obs_batch_ori[:, 0:config.stacked_observations, :]
+    action_batch = _t(action_batch, dev, torch.long)
+    target_reward, target_value = _t(target_reward, dev), _t(target_value, dev)
+    target_policy, weights = _t(target_policy, dev), _t(weights, dev)
+    B = obs_batch.shape[0]
+    assert B == target_reward.shape[0] and action_batch.shape[1] == config.num_unroll_steps
+
+    model.train()
+    weighted_loss, parts = compute_losses(model, config, obs_batch, action_batch, target_reward, target_value,
+                                          target_policy, weights, amp=amp)
+    total_loss = weighted_loss
+    gradient_scale = 1.0 / config.num_unroll_steps
+    total_loss.register_hook(lambda grad: grad * gradient_scale)  # train.py:222-229
+    optimizer.zero_grad()
+    total_loss.backward()
+    torch.nn.utils.clip_grad_norm_(model.parameters(), config.max_grad_norm)
+    optimizer.step()
+    r = config.priority_reward_ratio
+    new_priority = (1 - r) * (parts["value_priority"] + config.prioritized_replay_eps) + r * parts["reward_priority"]
+    f = lambda t: float(t.detach())
+    loss_data = (f(total_loss), f(weighted_loss), f(parts["loss"].mean()), 0, f(parts["policy_loss"].mean()),
+                 f(parts["reward_loss"].mean()), f(parts["value_loss"].mean()), 0.0)
+    return loss_data, new_priority.detach().cpu().numpy()
