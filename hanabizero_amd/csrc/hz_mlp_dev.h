@@ -62,8 +62,12 @@ __device__ __forceinline__ float row16_support_to_scalar(const uint16_t* row, in
 // Diagnostic build only (-DHZ_MLP_PROFILE, tools/mlp_profile.py): per-phase shader-cycle sums of workgroup 100.
 #ifdef HZ_MLP_PROFILE
 __device__ unsigned long long hz_mlp_prof[16 * 8];
+__device__ unsigned long long hz_mlp_prof_pass[34];  // wave 0 of workgroup 100: s_memtime when it leaves job j's prologue
 extern "C" int hz_mlp_profile_read(unsigned long long* host) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(hz_mlp_prof), sizeof(hz_mlp_prof));
+}
+extern "C" int hz_mlp_profile_read_passes(unsigned long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(hz_mlp_prof_pass), sizeof(hz_mlp_prof_pass));
 }
 #define PROF_NOW() __builtin_amdgcn_s_memtime()
 #define PROF_ADD(var, t0) var += __builtin_amdgcn_s_memtime() - (t0)
@@ -213,6 +217,9 @@ __device__ __forceinline__ void mlp_body(
       }
     }
     PROF_ADD(p_bar, p_j0);
+#ifdef HZ_MLP_PROFILE
+    if (blockIdx.x == 100 && wave == 0 && lane == 0 && j < 32) hz_mlp_prof_pass[j] = PROF_NOW();  // past job j's barrier
+#endif
     if (J.ks == 0) continue;
     const unsigned long long p_j1 = PROF_NOW();
     // epilogue operands first: their latency hides under the k-loop
@@ -380,6 +387,10 @@ __device__ __forceinline__ void mlp_body(
     unsigned long long* o = hz_mlp_prof + wave * 8;
     o[0] = p_staged - p_t0; o[1] = p_bar; o[2] = p_pre; o[3] = p_loop; o[4] = p_epi;
     o[5] = PROF_NOW() - p_jobs_done; o[6] = PROF_NOW() - p_t0; o[7] = (unsigned long long)gstep;
+    if (wave == 0) {
+      hz_mlp_prof_pass[32] = p_t0;
+      hz_mlp_prof_pass[33] = PROF_NOW();
+    }
   }
 #endif
 }

@@ -34,7 +34,8 @@ class MCTS(object):
             H = h0.shape[1]
             if pool is None:
                 pool = torch.empty((S, num, H), dtype=model.dtype, device=roots.device)
-            pool[0].copy_(h0)
+            if h0.data_ptr() != pool[0].data_ptr():  # (the actor has the root inference write plane 0 directly)
+                pool[0].copy_(h0)
             oh = model.onehot_cols
             net_in = torch.empty((num, H + oh), dtype=model.dtype, device=roots.device)
             fused = getattr(model, "fused", None)

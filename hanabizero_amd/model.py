@@ -343,19 +343,23 @@ class InferenceEngine:
 
     # -- entry points -----------------------------------------------------------------------------------
     @torch.no_grad()
-    def initial(self, obs):
+    def initial(self, obs, state_out=None):
+        """(value [N] f32, policy logits [N, A] f32, hidden state [N, H]).  state_out: optional [N, H] buffer of the
+        engine dtype for the hidden state (e.g. plane 0 of the search's pool: saves the copy there)."""
         if self.fused_tail is not None and obs.is_cuda:
             # the two large representation layers as GEMMs, everything after them in one launch of the MFMA kernel
             r, x = self.rep, obs.to(self.dtype)
             x = r[0](x, relu=True)
             x = self._add_relu(r[2](r[1](x, relu=True)), x)
             N = x.shape[0]
-            state = torch.empty((N, self.H), dtype=self.dtype, device=x.device)
+            state = state_out if state_out is not None else torch.empty((N, self.H), dtype=self.dtype, device=x.device)
             value = torch.empty(N, dtype=torch.float32, device=x.device)
             logits = torch.empty((N, self.A), dtype=torch.float32, device=x.device)
             self.fused_tail(x, state, value, logits)
             return value, logits, state
         state = self._representation(obs.to(self.dtype))
+        if state_out is not None:
+            state = state_out.copy_(state)
         logits, value, _ = self._tails(self.pred1(state, relu=True), with_reward=False)
         return self._scalar(value), logits, state
 

@@ -136,9 +136,11 @@ class SelfPlayActor:
                                 _stream()), "hz_actor_draw")
 
     # -- one lock-step, device only --------------------------------------------------------------------------
-    def _step_body(self):
+    def _step_body(self, draw=True):
         cfg, N = self.cfg, self.N
-        value0, logits0, hidden0 = self.engine.initial(self.stack_buf.view(N, self.stack * self.D))
+        if draw:
+            self._draw()
+        value0, logits0, hidden0 = self.engine.initial(self.stack_buf.view(N, self.stack * self.D), state_out=self.pool[0])
         self.roots.prepare(cfg.root_exploration_fraction, self.noise, self.zeros_n, logits0, self.legal)
         self.mcts.run_multi(self.roots, self.engine, hidden0, pool=self.pool)
         self.roots.root_stats_tensors(self.counts, self.values)
@@ -154,6 +156,7 @@ class SelfPlayActor:
                                        self.tmp_packed.data_ptr(), self.tmp_legal.data_ptr(), st), "hz_actor_record_step")
         check(lib.hz_actor_flush(b, st), "hz_actor_flush")  # finished games -> outbox ring
         # reset finished envs (selfplay_worker.py:230-240) and take everybody's current observation
+        # (tried: flush and the draws as parallel graph branches -- the cross-queue dependencies cost what the overlap saves)
         self.env.reset(done)
         self.env.observe(out=self.newest, packed=self.tmp_packed, legal=self.legal)
         # trajectory heads + stack window: shift for running games, refill for new ones (selfplay_worker.py:237, 326-327)
@@ -168,14 +171,12 @@ class SelfPlayActor:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):  # warm-up outside capture (hipBLASLt workspaces, allocator)
             for _ in range(2):
-                self._draw()
                 self._step_body()
                 self.total_moves += self.N
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize(self.device)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, capture_error_mode="thread_local"):  # other threads (e.g. the RCCL watchdog) may call HIP meanwhile
-            self._draw()
             self._step_body()
         self._graph = g
 
@@ -193,7 +194,6 @@ class SelfPlayActor:
         if self.use_graph:
             self._graph.replay()
         else:
-            self._draw()
             self._step_body()
         self.total_moves += self.N
 
@@ -239,7 +239,6 @@ class ActorGroup:
         with torch.cuda.stream(side):
             for _ in range(2):
                 for a in self.actors:
-                    a._draw()
                     a._step_body()
                     a.total_moves += a.N
         torch.cuda.current_stream().wait_stream(side)
@@ -251,7 +250,6 @@ class ActorGroup:
             for a, b in zip(self.actors, branches):
                 b.wait_stream(root)
                 with torch.cuda.stream(b):
-                    a._draw()
                     a._step_body()
             for b in branches:
                 root.wait_stream(b)

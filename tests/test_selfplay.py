@@ -57,7 +57,7 @@ def test_actor_matches_oracle_replay(game, N, sims, stack, steps):
         stack_in = np.stack([np.concatenate(w) for w in windows]).astype(np.float32)
         assert (actor.stack_buf.view(N, -1).cpu().numpy() == stack_in).all(), step
         assert (actor.legal.cpu().numpy() == legal).all()
-        actor._step_body()
+        actor._step_body(draw=False)  # (the draws above are this move's)
         # ---- oracle replay of the same move
         v0, l0, h0 = eng.initial(torch.from_numpy(stack_in).cuda())
         tree = OracleTree(N, A, sims, seed=3, value_delta_max=cfg.value_delta_max)

@@ -54,5 +54,27 @@ def main():
             w, o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7]))
 
 
+    # per pass: when wave 0 got past the pass's barrier, and the weight bytes the workgroup streams in that pass
+    lib.hz_mlp_profile_read_passes.argtypes = [V]
+    pp = np.zeros(34, np.uint64)
+    lib.hz_mlp_profile_read_passes(pp.ctypes.data_as(V))
+    pp = pp.astype(np.int64)
+    import ctypes
+    from hanabizero_amd._lib import MlpJob
+    raw = f.jobs.cpu().numpy().tobytes()
+    tab = (MlpJob * (len(raw) // ctypes.sizeof(MlpJob))).from_buffer_copy(raw)
+    t_prev = pp[32]
+    print("  pass: ticks since the previous pass began | jobs | weight KB of the PREVIOUS pass | B/tick")
+    prev_kb = 0.0
+    for j in range(f.n_jobs):
+        ents = [tab[j * waves + w] for w in range(waves)]
+        kb = sum(e.ks for e in ents) * tiles * 1024 / 1024.0
+        dt = pp[j] - t_prev
+        print("  %2d: %7d | %2d jobs ks=%2d %s| %7.1f | %5.1f" % (j, dt, sum(1 for e in ents if e.ks), max(e.ks for e in ents),
+              "B " if ents[0].flags & 4 else "  ", prev_kb, prev_kb * 1024 / max(dt, 1)))
+        t_prev, prev_kb = pp[j], kb
+    print("  end: %7d (last pass %.1f KB + final stage)" % (pp[33] - t_prev, prev_kb))
+
+
 if __name__ == "__main__":
     main()
