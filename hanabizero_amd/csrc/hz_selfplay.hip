@@ -125,26 +125,81 @@ __device__ __forceinline__ int actor_t(const hz_actor_bufs_t& b, int env) {
   return (int)(len < (long long)(b.max_moves - 1) ? len : (long long)(b.max_moves - 1));
 }
 
+// select_action_env with one wave per env (lane = action): the same fp64 values in the same summation order -- the
+// left-to-right sums walk the lanes with v_readlane -- but the divisions, pow and log of the A actions run side by side.
+__device__ __forceinline__ double readlane_d(double v, int l) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(u & 0xffffffffu), l);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(u >> 32), l);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+__device__ __forceinline__ int select_action_wave(int env, int lane, int A, int32_t* __restrict__ counts,
+                                                  const uint8_t* __restrict__ legal, const double* __restrict__ uniform,
+                                                  float temperature, int deterministic, double* ent_out, int* masked_count) {
+  const bool on = lane < A;
+  const bool unit_t = (temperature == 1.0f);
+  const double inv_t = 1.0 / (double)temperature;
+  int v = on ? counts[(size_t)env * A + lane] : INT32_MIN;
+  if (on && legal[(size_t)env * A + lane] == 0 && v >= 1) {  // utils.py:282-284
+    v = 0;
+    counts[(size_t)env * A + lane] = 0;
+  }
+  *masked_count = on ? v : 0;
+  const double x = on ? (unit_t ? (double)v : pow((double)v, inv_t)) : 0.0;
+  int vmax = v;  // np.argmax: first maximum
+  for (int off = 32; off; off >>= 1) vmax = max(vmax, __shfl_xor(vmax, off));
+  const int best = __ffsll((unsigned long long)__ballot(on && v == vmax)) - 1;
+  double total = 0.0;
+  for (int a = 0; a < A; ++a) total += readlane_d(x, a);  // utils.py:286-287 (Python sum, left to right)
+  if (!(total > 0.0)) {
+    *ent_out = 0.0;
+    return -1;
+  }
+  const double p = x / total;
+  double last = 0.0, mine = 0.0;  // np.random.choice: cdf = cumsum(p); cdf /= cdf[-1]
+  for (int a = 0; a < A; ++a) {
+    last += readlane_d(p, a);
+    if (lane == a) mine = last;
+  }
+  int action = best;
+  if (!deterministic) {
+    const double u = uniform[env];
+    const uint64_t le = __ballot(on && mine / last <= u);  // searchsorted(cdf, u, side='right') = #entries <= u ...
+    const int idx = le ? 64 - __clzll((unsigned long long)le) : 0;  // ... which the serial loop finds as last hit + 1
+    action = idx < A ? idx : A - 1;
+  }
+  // scipy.stats.entropy(pk, base=2): pk /= sum(pk); sum(-pk*log(pk)) / log(2); sum(pk) is `last`
+  const double pk = p / last;
+  const double term = (on && pk > 0.0) ? pk * log(pk) : 0.0;
+  double ent = 0.0;
+  for (int a = 0; a < A; ++a) ent -= readlane_d(term, a);
+  *ent_out = ent / log(2.0);
+  return action;
+}
+
 __global__ __launch_bounds__(256) void k_actor_record_search(hz_actor_bufs_t b, int32_t* __restrict__ counts,
                                                              const float* __restrict__ root_values,
                                                              const uint8_t* __restrict__ legal,
                                                              const double* __restrict__ uniform, float temperature,
                                                              int deterministic, int32_t* __restrict__ out_action,
                                                              double* __restrict__ out_entropy) {
-  const int env = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int env = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (env >= b.num_envs) return;
   const int A = b.num_actions, T = b.max_moves;
   double ent;
-  const int action = select_action_env(env, A, counts, legal, uniform, temperature, deterministic, &ent);
-  out_action[env] = action;
-  if (out_entropy) out_entropy[env] = ent;
+  int mc;
+  const int action = select_action_wave(env, lane, A, counts, legal, uniform, temperature, deterministic, &ent, &mc);
   const int t = actor_t(b, env);
-  b.action[(size_t)env * T + t] = (int8_t)action;
-  b.value[(size_t)env * T + t] = root_values[env];
-  int16_t* vrow = b.visits + ((size_t)env * T + t) * A;
-  const int32_t* c = counts + (size_t)env * A;
-  for (int a = 0; a < A; ++a) vrow[a] = (int16_t)c[a];  // masked counts (store_search_stats gets the mutated list)
-  b.ent_sum[env] += ent;
+  if (lane < A) b.visits[((size_t)env * T + t) * A + lane] = (int16_t)mc;  // masked counts (store_search_stats gets the mutated list)
+  if (lane == 0) {
+    out_action[env] = action;
+    if (out_entropy) out_entropy[env] = ent;
+    b.action[(size_t)env * T + t] = (int8_t)action;
+    b.value[(size_t)env * T + t] = root_values[env];
+    b.ent_sum[env] += ent;
+  }
 }
 
 __global__ __launch_bounds__(256) void k_actor_record_step(hz_actor_bufs_t b, const int32_t* __restrict__ reward,
@@ -297,7 +352,7 @@ extern "C" int hz_actor_record_search(const hz_actor_bufs_t* bufs, int32_t* coun
   HZ_REQUIRE(counts && root_values && legal && out_action, "hz_actor_record_search: NULL argument");
   HZ_REQUIRE(deterministic || uniform, "hz_actor_record_search: uniform samples required when sampling");
   HZ_REQUIRE(temperature > 0.0f, "hz_actor_record_search: temperature must be > 0");
-  hipLaunchKernelGGL(k_actor_record_search, dim3((bufs->num_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, *bufs,
+  hipLaunchKernelGGL(k_actor_record_search, dim3((bufs->num_envs + 3) / 4), dim3(256), 0, (hipStream_t)stream, *bufs,
                      counts, root_values, legal, uniform, temperature, deterministic, out_action, out_entropy);
   HZ_HIP(hipGetLastError());
   return 0;
