@@ -276,7 +276,7 @@ class InferenceEngine:
             self.bw3 = self._stack([_fold(rw[3]), _fold(ac[3]), _fold(va[3])], self.out_pad, False)
         self.V = 2 * self.support + 1
         self.fused = FusedRecurrent(net, self) if self.use_fused else None
-        self.fused_tail = FusedInitialTail(net, self) if (self.use_fused and self.full) else None
+        self.fused_tail = FusedInitialTail(net, self, 8, 4) if (self.use_fused and self.full) else None  # 8 x 4: fastest stand-alone shape
         self._net, self._fused_shapes = net, {(4, 4): self.fused}
 
     def fused_shape(self, waves, tiles):
