@@ -89,7 +89,8 @@ __device__ __constant__ const uint64_t hz_exp2f_tab[32] = {
     0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull,
     0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
 
-__device__ __forceinline__ float hz_expf(float x) {
+// `tab`: the 32-entry table above, or a copy of it that is cheaper to gather from (LDS in the persistent search kernel)
+__device__ __forceinline__ float hz_expf(float x, const uint64_t* tab = hz_exp2f_tab) {
   const uint32_t ux = __float_as_uint(x);
   const uint32_t abstop = (ux >> 20) & 0x7ff;
   if (abstop >= (0x42b00000u >> 20)) {  // |x| >= 88 or NaN
@@ -109,7 +110,7 @@ __device__ __forceinline__ float hz_expf(float x) {
   const uint64_t ki = (uint64_t)__double_as_longlong(kd);
   kd -= Shift;
   const double r = __builtin_fma(InvLn2N, xd, -kd);  // as contracted by the host build
-  uint64_t t = hz_exp2f_tab[ki & 31];
+  uint64_t t = tab[ki & 31];
   t += ki << (52 - 5);
   const double s = __longlong_as_double((long long)t);
   z = __builtin_fma(C0, r, C1);

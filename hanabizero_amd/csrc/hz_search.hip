@@ -46,6 +46,7 @@ struct SearchLds {
   float* rew_s;     // [16]
   float* val_s;     // [16]
   float* pol_s;     // [16][A]
+  uint64_t* exp_s;  // [32] hz_exp2f_tab
 };
 
 __device__ __forceinline__ TraverseOut search_traverse_out(const hz_mlp_header_t& H, const SearchArgs& a, const SearchLds& L,
@@ -91,6 +92,8 @@ __device__ __forceinline__ RowFrag search_backup_descent(const TreeView& tv, con
   float mn, mx;
   int rv, a0;
   float4 first;
+  TP_ON(1);
+  TP(0);
   backprop_body<false, true>(tv, tree, lane, wave, L.lds_q, sim + 1, no, mn, mx, rv, first, a0, &tl);
   RowFrag f;
   f.v[0] = f.v[1] = make_uint4(0u, 0u, 0u, 0u);
@@ -98,7 +101,9 @@ __device__ __forceinline__ RowFrag search_backup_descent(const TreeView& tv, con
   if (more) {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     int entry;
+    TP(5);
     traverse_body<true>(tv, tree, lane, sim + 1, mn, mx, rv, to, true, root_row, &entry, &tl);
+    TP(13);
     f = search_request_row(tv, H, a, entry, tree, lane);
   }
   return f;
@@ -131,11 +136,17 @@ __global__ __launch_bounds__(1024, 1) void k_search(TreeView tv, hz_mlp_header_t
   const bool mine = tree < tv.N;
   SearchLds L;
   L.image = lds;
-  L.prec_s = reinterpret_cast<float4*>(lds + (size_t)16 * H.row_stride);  // (row_stride % 8 == 0: 16-B aligned)
+  L.exp_s = reinterpret_cast<uint64_t*>(lds + (size_t)16 * H.row_stride);  // (row_stride % 8 == 0: 16-B aligned)
+  L.prec_s = reinterpret_cast<float4*>(L.exp_s + 32);
   L.path_s = reinterpret_cast<int32_t*>(L.prec_s + 16 * (tv.S + 1));
   L.lds_q = reinterpret_cast<float*>(L.path_s + 16 * (tv.S + 1));
   L.act_s = reinterpret_cast<int32_t*>(L.lds_q + 16 * tv.S);
+  if (threadIdx.x < 32) L.exp_s[threadIdx.x] = hz_exp2f_tab[threadIdx.x];
   TreeLocal tl;
+  tl.exp_tab = L.exp_s;
+  tl.pbc_reg = (tv.S < 64 && lane <= tv.S) ? tv.pbc_tab[lane] : 0.0f;
+  tl.sqrt_reg = sqrtf((float)lane + 1.0f);
+  __syncthreads();
   tl.path = L.path_s + wave * (tv.S + 1);
   tl.prec = L.prec_s + wave * (tv.S + 1);
   tl.root_vsum = 0.0f; tl.root_visit = 0; tl.path_len = 0;
@@ -198,7 +209,7 @@ extern "C" int hz_search_run(hz_tree_t* t, int num_simulations, const hz_mlp_hea
   HZ_REQUIRE(H->in_width > 0 && H->in_width % 8 == 0, "hz_search_run: in_width must be a positive multiple of 8");
   HZ_REQUIRE(H->in_width == H->hidden && H->hidden <= 1024, "hz_search_run: the recurrent inference maps a hidden state (<= 1024 wide) to a hidden state");
   const size_t lds_bytes = (size_t)16 * H->row_stride * sizeof(uint16_t) + (size_t)16 * (t->S + 1) * (16 + 4) +
-                           (size_t)16 * t->S * sizeof(float) + (size_t)(16 * 3 + 16 * t->A) * sizeof(float);
+                           (size_t)16 * t->S * sizeof(float) + (size_t)(16 * 3 + 16 * t->A + 2) * sizeof(float) + 32 * 8 + 256;  // (+256: slack behind the last array)
   HZ_REQUIRE(lds_bytes <= 160 * 1024, "hz_search_run: %zu B of LDS per workgroup exceed 160 KiB", lds_bytes);
   static size_t configured = 0;
   if (lds_bytes > configured) {

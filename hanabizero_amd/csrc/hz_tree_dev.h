@@ -63,13 +63,14 @@ __device__ __forceinline__ uint32_t pack_vc(int visit, int child) { return ((uin
 
 // masked softmax -> priors, the arithmetic of CNode::expand (cnode.cpp:49-114).
 // lane a holds logit a; `legal_mask` bit a set = legal.  Returns this lane's prior.
-__device__ __forceinline__ float expand_prior(float logit, uint64_t legal_mask, int lane, int A) {
+__device__ __forceinline__ float expand_prior(float logit, uint64_t legal_mask, int lane, int A,
+                                              const uint64_t* exp_tab = hz_exp2f_tab) {
   const bool legal = (legal_mask >> lane) & 1ull;
   // policy_max = max over legal, non-NaN logits, starting from FLOAT_MIN (cnode.cpp:59,68-78)
   float m = (legal && logit == logit) ? logit : -INFINITY;
   m = hz_wave_max(m);
   const float policy_max = fmaxf(m, HZ_FLOAT_MIN);
-  const float tp = legal ? hz_expf(logit - policy_max) : 0.0f;  // cnode.cpp:87
+  const float tp = legal ? hz_expf(logit - policy_max, exp_tab) : 0.0f;  // cnode.cpp:87
   // policy_sum: 1e-4 + terms in action order over the legal children (cnode.cpp:57,88)
   float policy_sum = 0.0001f;
   uint64_t mm = legal_mask;
@@ -123,6 +124,8 @@ struct TreeLocal {
   float root_vsum;  // the root's value_sum / visit_count (also stored to HBM for the read-outs)
   int root_visit;
   int path_len;     // nodes on the last descent's path
+  float pbc_reg, sqrt_reg;  // per-lane tables of the descent (pb_c's log factor, sqrt(n + 1)), loaded / computed once
+  const uint64_t* exp_tab;  // hz_exp2f_tab in LDS
 };
 
 template <bool LOCAL = false>
@@ -139,8 +142,8 @@ __device__ __forceinline__ void traverse_body(const TreeView& tv, int tree, int 
   // pb_c's first factor for every possible parent visit count, one per lane (S + 1 <= 64: no dependent table load
   // on the critical path of a level); larger S falls back to the table in memory
   const bool tab_in_regs = S < 64;
-  const float pbc_reg = (tab_in_regs && lane <= S) ? tv.pbc_tab[lane] : 0.0f;
-  const float sqrt_reg = sqrtf((float)lane + 1.0f);  // sqrt(parent visits + 1), same trick
+  const float pbc_reg = LOCAL ? tl->pbc_reg : ((tab_in_regs && lane <= S) ? tv.pbc_tab[lane] : 0.0f);
+  const float sqrt_reg = LOCAL ? tl->sqrt_reg : sqrtf((float)lane + 1.0f);  // sqrt(parent visits + 1), same trick
 
   int e = 0;
   int pvc = root_visit;
@@ -347,7 +350,7 @@ __device__ __forceinline__ void backprop_body(const TreeView& tv, int tree, int 
     }
   }
   const uint64_t all = (A >= 64) ? ~0ull : ((1ull << A) - 1ull);
-  const float prior = expand_prior(logit, all, lane, A);
+  const float prior = expand_prior(logit, all, lane, A, LOCAL ? tl->exp_tab : hz_exp2f_tab);
   TP(1);
   if (on) {
     float4 r;

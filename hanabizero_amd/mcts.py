@@ -45,7 +45,7 @@ class MCTS(object):
                 val = torch.empty(num, dtype=torch.float32, device=roots.device)
                 pol = torch.empty((num, roots.action_num), dtype=torch.float32, device=roots.device)
                 fused16 = model.fused_shape(16, 2) if self.persistent else None
-                if fused16 is not None and fused16.lds_bytes(16) + 16 * (24 * (S + 1) + 4 * roots.action_num + 16) <= 160 * 1024:
+                if fused16 is not None and fused16.lds_bytes(16) + 16 * (24 * (S + 1) + 4 * roots.action_num + 16) + 512 <= 160 * 1024:
                     # the whole loop below as ONE persistent kernel: a workgroup keeps 16 trees for all simulations
                     roots.search_tensors(fused16, pool, S - 1, rew, val, pol)
                     return

@@ -14,9 +14,15 @@ os.makedirs(os.path.dirname(out), exist_ok=True)
 src = os.path.join(ROOT, "hanabizero_amd", "csrc")
 files = [os.path.join(src, f) for f in ("hz_tree.hip", "hz_env.hip", "hz_selfplay.hip", "hz_netglue.hip", "hz_mlp.hip",
                                         "hz_search.hip")]
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                       "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt", "-w",
-                       "-DHZ_SEARCH_PROFILE", "-I" + src, "-I" + os.path.join(ROOT, "include"), "-o", out] + files)
+base = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+        "-fhip-fp32-correctly-rounded-divide-sqrt", "-w", "-I" + src, "-I" + os.path.join(ROOT, "include")]
+objs = []
+for f in files:  # the tree stamps (TP macros of hz_tree_dev.h) only inside the search kernel's translation unit
+    o = os.path.join(ROOT, "gpurun_out", os.path.basename(f) + ".prof.o")
+    extra = ["-DHZ_SEARCH_PROFILE", "-DHZ_TREE_PROFILE"] if f.endswith("hz_search.hip") else []
+    subprocess.check_call(base + extra + ["-c", "-o", o, f])
+    objs.append(o)
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
 os.environ["HANABIZERO_HIP_LIB"] = out
 
 import numpy as np  # noqa: E402
@@ -47,6 +53,18 @@ def main():
               % (w, p[w, 0], p[w, 1], p[w, 2], p[w, 3], p[w].sum()))
     print("  per simulation (mean over waves): tree %.0f, wait %.0f, inference %.0f, wait %.0f"
           % tuple(p.mean(0) / (cfg.num_simulations - 1)))
+    # the tree phase of the wave that owns tree 400, last simulation with a descent (stamps of hz_tree_dev.h)
+    lib.hz_tree_profile_read.argtypes = [C.c_void_p]
+    tp = np.zeros(16, np.uint64)
+    lib.hz_tree_profile_read(tp.ctypes.data_as(C.c_void_p))
+    tp = tp.astype(np.int64)
+    names = ["start", "expand done", "leaf value/reward", "backup loop", "min/max", "fence"] + ["level %d" % d for d in range(1, 8)] + ["end"]
+    prev = tp[0]
+    for i, nme in enumerate(names):
+        if tp[i] == 0 or tp[i] < tp[0]:
+            continue
+        print("    %-20s +%6d  (at %6d)" % (nme, tp[i] - prev, tp[i] - tp[0]))
+        prev = tp[i]
 
 
 if __name__ == "__main__":
