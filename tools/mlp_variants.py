@@ -12,8 +12,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 STRIP = ["-DHZ_MLP_X_NOEPI", "-DHZ_MLP_X_NOFINAL", "-DHZ_MLP_X_NOSTAGE"]
-VARIANTS = [("baseline", []), ("fair", ["-DHZ_MLP_X_FAIR"]), ("fair, no epi/final/staging", STRIP + ["-DHZ_MLP_X_FAIR"])]
-SHAPES = [(8, 4), (16, 2)]
+VARIANTS = [("baseline", []), ("no epilogues", ["-DHZ_MLP_X_NOEPI"]), ("no epi/final/staging", STRIP)]
+SHAPES = [(4, 4), (8, 4), (16, 2)]
 
 
 def main():
