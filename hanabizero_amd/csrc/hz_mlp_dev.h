@@ -98,7 +98,8 @@ enum { STAGE_GATHER = 0, STAGE_REGS = 1 };
 struct RowFrag {
   uint4 v[2];
 };
-template <int RT, int NW, int NT, int STAGE = STAGE_GATHER>
+// FINAL = false: stop after the last layer (logits stay in the image; the caller's waves read them there).
+template <int RT, int NW, int NT, int STAGE = STAGE_GATHER, bool FINAL = true>
 __device__ __forceinline__ void mlp_body(
     const hz_mlp_header_t& H, const hz_mlp_job_t* __restrict__ jobs, const uint16_t* __restrict__ wstream,
     const float* __restrict__ bias, const float* __restrict__ act_tab, const uint16_t* __restrict__ state_src,
@@ -359,10 +360,10 @@ __device__ __forceinline__ void mlp_body(
   }
   const unsigned long long p_jobs_done = PROF_NOW();
   (void)p_jobs_done;
-  __syncthreads();
+  if (FINAL) __syncthreads();  // (without the final stage the caller's own barrier follows)
   // heads -> scalars / policy logits: 16 lanes per (row, head) pair, 16 pairs in flight per workgroup pass
 #ifndef HZ_MLP_X_NOFINAL
-  {
+  if (FINAL) {
     const int l16 = tid & 15, slot = tid >> 4;
     for (int pair = slot; pair < 2 * MT; pair += NTHR / 16) {
       const int r = pair >> 1, head = pair & 1;

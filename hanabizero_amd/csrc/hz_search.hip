@@ -89,6 +89,20 @@ __device__ __forceinline__ RowFrag search_backup_descent(const TreeView& tv, con
   no.reward_logits = nullptr; no.value_logits = nullptr; no.policy_logits = nullptr;
   no.reward_stride = 0; no.value_stride = 0; no.policy_stride = 0;
   no.support_size = 0; no.support_min = 0; no.dtype = 0; no.out_rewards = nullptr; no.out_values = nullptr;
+  // the leaf's heads, straight from the row image the inference left behind (the arithmetic of the stand-alone kernel's
+  // final stage): lanes 0-15 turn the reward logits into a scalar, lanes 16-31 the value logits; lane a takes policy logit a
+  {
+    const uint16_t* row = L.image + (size_t)wave * H.row_stride;
+    const float x = row16_support_to_scalar(row + (((lane >> 4) & 1) ? H.off_value : H.off_reward), H.support_size,
+                                            H.support_min, lane & 15);
+    if (lane == 0) L.rew_s[wave] = x;
+    if (lane == 16) L.val_s[wave] = x;
+    if (lane < tv.A) {
+      float pl = bf2f(row[H.off_policy + lane]);
+      if (pl != pl) pl = 0.0f;  // core/mcts.py:48-49
+      L.pol_s[wave * tv.A + lane] = pl;
+    }
+  }
   float mn, mx;
   int rv, a0;
   float4 first;
@@ -111,7 +125,7 @@ __device__ __forceinline__ RowFrag search_backup_descent(const TreeView& tv, con
 
 __device__ __forceinline__ void search_inference(const hz_mlp_header_t& H, const SearchArgs& a, const SearchLds& L, int sim,
                                                  int n_rows, int row0, const RowFrag& rows) {
-  mlp_body<1, 16, 2, STAGE_REGS>(H, a.jobs, a.wstream, a.bias, a.act_tab, a.pool, a.row_stride, nullptr, a.plane_stride,
+  mlp_body<1, 16, 2, STAGE_REGS, false>(H, a.jobs, a.wstream, a.bias, a.act_tab, a.pool, a.row_stride, nullptr, a.plane_stride,
                                  L.act_s - row0, a.pool + (size_t)(sim + 1) * a.plane_stride, L.rew_s - row0,
                                  L.val_s - row0, L.pol_s - (size_t)row0 * H.num_actions, n_rows, L.image, row0, rows);
 }
