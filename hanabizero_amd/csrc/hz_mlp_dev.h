@@ -17,39 +17,46 @@ __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
   return *reinterpret_cast<const uint32_t*>(&h);
 }
 
-// inverse_scalar_transform of LDS rows of bf16 logits, one (row, head) pair per 16-lane row of the wave: lane l16
-// owns logits [16*l16, 16*l16 + 16) (two ds_read_b128), DPP reductions across the 16 lanes; V <= 256.
-// Same maths as hz_tree.hip support_to_scalar.
-__device__ __forceinline__ float row16_support_to_scalar(const uint16_t* row, int V, int support_min, int l16) {
-  uint32_t w[8];
-  const int base = 16 * l16;
+// inverse_scalar_transform of LDS rows of bf16 logits, one (row, head) pair per 32-lane half of the wave: lane l32
+// owns logits [8*l32, 8*l32 + 8) (one ds_read_b128), DPP reductions inside each 16-lane row, one cross-row exchange;
+// V <= 256.  Same maths as hz_tree.hip support_to_scalar.
+__device__ __forceinline__ float half32_max(float v) {
+  v = hz_row16_max(v);
+  return fmaxf(v, __shfl_xor(v, 16));
+}
+__device__ __forceinline__ float half32_sum(float v) {
+  v = hz_row16_sum(v);
+  return v + __shfl_xor(v, 16);
+}
+__device__ __forceinline__ float row32_support_to_scalar(const uint16_t* row, int V, int support_min, int l32) {
+  uint32_t w[4];
+  const int base = 8 * l32;
   if (base < V) {
     const uint4 a = *reinterpret_cast<const uint4*>(row + base);
-    const uint4 b = *reinterpret_cast<const uint4*>(row + base + 8);
-    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
   } else {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) w[k] = 0;
+    for (int k = 0; k < 4; ++k) w[k] = 0;
   }
-  float x[16];
+  float x[8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
+  for (int k = 0; k < 4; ++k) {
     x[2 * k] = (base + 2 * k < V) ? __uint_as_float(w[k] << 16) : -INFINITY;
     x[2 * k + 1] = (base + 2 * k + 1 < V) ? __uint_as_float(w[k] & 0xffff0000u) : -INFINITY;
   }
   float m = -INFINITY;
 #pragma unroll
-  for (int k = 0; k < 16; ++k) m = fmaxf(m, x[k]);
-  m = hz_row16_max(m);
+  for (int k = 0; k < 8; ++k) m = fmaxf(m, x[k]);
+  m = half32_max(m);
   float se = 0.0f, sw = 0.0f;
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
+  for (int k = 0; k < 8; ++k) {
     const float e = (base + k < V) ? __expf(x[k] - m) : 0.0f;
     se += e;
     sw += e * (float)(support_min + base + k);
   }
-  se = hz_row16_sum(se);
-  sw = hz_row16_sum(sw);
+  se = half32_sum(se);
+  sw = half32_sum(sw);
   const float v = sw / se;
   const float eps = 0.001f;
   const float t = (sqrtf(1.0f + 4.0f * eps * (fabsf(v) + 1.0f + eps)) - 1.0f) / (2.0f * eps);
@@ -361,16 +368,16 @@ __device__ __forceinline__ void mlp_body(
   const unsigned long long p_jobs_done = PROF_NOW();
   (void)p_jobs_done;
   if (FINAL) __syncthreads();  // (without the final stage the caller's own barrier follows)
-  // heads -> scalars / policy logits: 16 lanes per (row, head) pair, 16 pairs in flight per workgroup pass
+  // heads -> scalars / policy logits: 32 lanes per (row, head) pair
 #ifndef HZ_MLP_X_NOFINAL
   if (FINAL) {
-    const int l16 = tid & 15, slot = tid >> 4;
-    for (int pair = slot; pair < 2 * MT; pair += NTHR / 16) {
+    const int l32 = tid & 31, slot = tid >> 5;
+    for (int pair = slot; pair < 2 * MT; pair += NTHR / 32) {
       const int r = pair >> 1, head = pair & 1;
-      if (row0 + r < n_rows) {
+      if (row0 + r < n_rows) {  // (uniform over the 32 lanes of a pair)
         const uint16_t* row = lds + (size_t)r * rs;
-        const float x = row16_support_to_scalar(row + (head ? H.off_value : H.off_reward), H.support_size, H.support_min, l16);
-        if (l16 == 0) (head ? out_value : out_reward)[row0 + r] = x;
+        const float x = row32_support_to_scalar(row + (head ? H.off_value : H.off_reward), H.support_size, H.support_min, l32);
+        if (l32 == 0) (head ? out_value : out_reward)[row0 + r] = x;
       }
     }
     for (int i = tid; i < MT * H.num_actions; i += NTHR) {

@@ -90,13 +90,13 @@ __device__ __forceinline__ RowFrag search_backup_descent(const TreeView& tv, con
   no.reward_stride = 0; no.value_stride = 0; no.policy_stride = 0;
   no.support_size = 0; no.support_min = 0; no.dtype = 0; no.out_rewards = nullptr; no.out_values = nullptr;
   // the leaf's heads, straight from the row image the inference left behind (the arithmetic of the stand-alone kernel's
-  // final stage): lanes 0-15 turn the reward logits into a scalar, lanes 16-31 the value logits; lane a takes policy logit a
+  // final stage): lanes 0-31 turn the reward logits into a scalar, lanes 32-63 the value logits; lane a takes policy logit a
   {
     const uint16_t* row = L.image + (size_t)wave * H.row_stride;
-    const float x = row16_support_to_scalar(row + (((lane >> 4) & 1) ? H.off_value : H.off_reward), H.support_size,
-                                            H.support_min, lane & 15);
+    const float x = row32_support_to_scalar(row + ((lane >> 5) ? H.off_value : H.off_reward), H.support_size,
+                                            H.support_min, lane & 31);
     if (lane == 0) L.rew_s[wave] = x;
-    if (lane == 16) L.val_s[wave] = x;
+    if (lane == 32) L.val_s[wave] = x;
     if (lane < tv.A) {
       float pl = bf2f(row[H.off_policy + lane]);
       if (pl != pl) pl = 0.0f;  // core/mcts.py:48-49
