@@ -74,6 +74,7 @@ __device__ __forceinline__ RowFrag search_first_descent(const TreeView& tv, cons
   int entry;
   tl.root_visit = tv.root_visit[tree];
   tl.root_vsum = tv.root_vsum[tree];
+  tl.publish = a.sims == 1;
   root_row = make_float4(0.f, 0.f, 0.f, 0.f);
   if (lane < tv.A) root_row = tv.rec[(size_t)tree * tv.S * tv.A + lane];  // from now on kept in registers, patched per backup
   traverse_body<true>(tv, tree, lane, 0, tv.mm_min[tree], tv.mm_max[tree], tl.root_visit, to, true, root_row, &entry, &tl);
@@ -108,6 +109,7 @@ __device__ __forceinline__ RowFrag search_backup_descent(const TreeView& tv, con
   float4 first;
   TP_ON(1);
   TP(0);
+  tl.publish = !more;  // the last backup's root sums and min / max are the ones the read-outs see
   backprop_body<false, true>(tv, tree, lane, wave, L.lds_q, sim + 1, no, mn, mx, rv, first, a0, &tl);
   RowFrag f;
   f.v[0] = f.v[1] = make_uint4(0u, 0u, 0u, 0u);
@@ -116,6 +118,7 @@ __device__ __forceinline__ RowFrag search_backup_descent(const TreeView& tv, con
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     int entry;
     TP(5);
+    tl.publish = sim + 2 == a.sims;  // the last descent
     traverse_body<true>(tv, tree, lane, sim + 1, mn, mx, rv, to, true, root_row, &entry, &tl);
     TP(13);
     f = search_request_row(tv, H, a, entry, tree, lane);

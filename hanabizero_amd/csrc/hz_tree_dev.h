@@ -124,6 +124,8 @@ struct TreeLocal {
   float root_vsum;  // the root's value_sum / visit_count (also stored to HBM for the read-outs)
   int root_visit;
   int path_len;     // nodes on the last descent's path
+  bool publish;     // store this call's bookkeeping scalars (leaf entry, path length, root sums, min / max) to HBM: only
+                    // the last descent's and the last backup's are ever read (the read-outs after the search)
   float pbc_reg, sqrt_reg;  // per-lane tables of the descent (pb_c's log factor, sqrt(n + 1)), loaded / computed once
   const uint64_t* exp_tab;  // hz_exp2f_tab in LDS
 };
@@ -218,10 +220,12 @@ __device__ __forceinline__ void traverse_body(const TreeView& tv, int tree, int 
     pvc = child_visit;
   }
   if (lane == 0) {
-    to.ix[tree] = e;     // parent->hidden_state_index_x (entry index == hidden_state_index_x)
-    to.iy[tree] = tree;  // parent->hidden_state_index_y
     to.la[tree] = action;
-    tv.path_len[tree] = depth + 1;
+    if (!LOCAL || tl->publish) {
+      to.ix[tree] = e;     // parent->hidden_state_index_x (entry index == hidden_state_index_x)
+      to.iy[tree] = tree;  // parent->hidden_state_index_y
+      tv.path_len[tree] = depth + 1;
+    }
   }
   if (LOCAL) tl->path_len = depth + 1;
   if (out_entry) *out_entry = e;
@@ -393,7 +397,7 @@ __device__ __forceinline__ void backprop_body(const TreeView& tv, int tree, int 
     if (act && k == npairs - 1) {  // the leaf: CNode::expand sets reward and hidden index (cnode.cpp:50-53)
       r.z = leaf_reward;
       child = e_new;
-      tv.ref[(size_t)tree * S + e_new] = pr;
+      if (!LOCAL) tv.ref[(size_t)tree * S + e_new] = pr;
     }
     // the backup chain, deepest node first: value_sum += G; G = reward + discount * G   (cnode.cpp:320-331)
     float myG = 0.0f;
@@ -422,7 +426,7 @@ __device__ __forceinline__ void backprop_body(const TreeView& tv, int tree, int 
   out_first_action = __builtin_amdgcn_readfirstlane(pr) & 255;
   const float new_root_vsum = old_root_vsum + G;  // the root (search_path[0])
   out_root_visit = old_root_visit + 1;
-  if (lane == 0) {
+  if (lane == 0 && (!LOCAL || tl->publish)) {
     tv.root_vsum[tree] = new_root_vsum;
     tv.root_visit[tree] = out_root_visit;
   }
@@ -441,7 +445,7 @@ __device__ __forceinline__ void backprop_body(const TreeView& tv, int tree, int 
   }
   out_mx = fmaxf(hz_wave_max(vmax), HZ_FLOAT_MIN);  // CMinMaxStats::update from the cleared state (cminimax.cpp:17-29)
   out_mn = fminf(hz_wave_min(vmin), HZ_FLOAT_MAX);
-  if (lane == 0) {
+  if (lane == 0 && (!LOCAL || tl->publish)) {
     tv.mm_max[tree] = out_mx;
     tv.mm_min[tree] = out_mn;
   }
