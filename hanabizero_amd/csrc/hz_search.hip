@@ -150,7 +150,11 @@ __global__ __launch_bounds__(1024, 1) void k_search(TreeView tv, hz_mlp_header_t
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int row0 = blockIdx.x * 16;
   const int tree = row0 + wave;
+#ifdef HZ_SEARCH_X_HALFTREES  // experiment: only 8 of the 16 waves do tree work (is the tree phase issue-bound?)
+  const bool mine = tree < tv.N && wave < 8;
+#else
   const bool mine = tree < tv.N;
+#endif
   SearchLds L;
   L.image = lds;
   L.exp_s = reinterpret_cast<uint64_t*>(lds + (size_t)16 * H.row_stride);  // (row_stride % 8 == 0: 16-B aligned)

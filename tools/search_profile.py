@@ -19,7 +19,7 @@ base = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-f
 objs = []
 for f in files:  # the tree stamps (TP macros of hz_tree_dev.h) only inside the search kernel's translation unit
     o = os.path.join(ROOT, "gpurun_out", os.path.basename(f) + ".prof.o")
-    extra = ["-DHZ_SEARCH_PROFILE", "-DHZ_TREE_PROFILE"] if f.endswith("hz_search.hip") else []
+    extra = ["-DHZ_SEARCH_PROFILE", "-DHZ_TREE_PROFILE"] + sys.argv[2:] if f.endswith("hz_search.hip") else []
     subprocess.check_call(base + extra + ["-c", "-o", o, f])
     objs.append(o)
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
