@@ -21,9 +21,16 @@ def _to_dev(a, device):
     return t.to(device) if device.type == "cuda" else t
 
 
+_DTYPES = dict(action=np.int8, reward=np.int8, value=np.float32, visits=np.int16, legal=np.uint8, obs=np.int32,
+               meta=np.int32)  # the packed record format of SelfPlayActor.drain
+
+
 def gather_records(rec, dst=0, group=None, device=None):
     """rec: dict of numpy arrays with a leading games axis (SelfPlayActor.drain()) or None.
-    Returns on `dst` the concatenation over ranks (rank order), elsewhere None.  Collective: every rank must call."""
+    Returns on `dst` the concatenation over ranks (rank order), elsewhere None.  Collective: every rank must call.
+    Two collectives per call whatever the number of fields: an all_gather of the ranks' array shapes (every rank trims its
+    records to its own longest finished game, so the time extents differ) and one gather of a byte buffer holding all
+    seven arrays padded to the element-wise maximum shape."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return rec
     world, rank = dist.get_world_size(group), dist.get_rank(group)
@@ -31,34 +38,51 @@ def gather_records(rec, dst=0, group=None, device=None):
     device = torch.device(device) if device is not None else (
         torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu"))
     n = 0 if rec is None else int(rec["meta"].shape[0])
-    counts = torch.tensor([n], dtype=torch.int64, device=device)
-    all_counts = [torch.zeros_like(counts) for _ in range(world)]
-    dist.all_gather(all_counts, counts, group=group)
-    all_counts = [int(c.item()) for c in all_counts]
-    mx = max(all_counts)
+    shp = np.ones(1 + 3 * len(_FIELDS), np.int64)
+    shp[0] = n
+    if n:
+        for i, k in enumerate(_FIELDS):
+            assert rec[k].dtype == _DTYPES[k] and rec[k].ndim <= 4, (k, rec[k].dtype, rec[k].shape)
+            tail = rec[k].shape[1:]
+            shp[1 + 3 * i:1 + 3 * i + len(tail)] = tail
+    mine = torch.from_numpy(shp).to(device)
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine, group=group)
+    every = torch.stack(every).cpu().numpy()
+    counts = [int(c) for c in every[:, 0]]
+    mx = max(counts)
     if mx == 0:
         return None
-    # every rank trims its records to its own longest finished game (SelfPlayActor.drain): agree on the element-wise
-    # maximum of the tail shapes (dtypes are the same everywhere) and pad to it
-    spec = None if rec is None else {k: (tuple(rec[k].shape[1:]), rec[k].dtype.str) for k in _FIELDS}
-    specs = [None] * world
-    dist.all_gather_object(specs, spec, group=group)
-    have = [s for s in specs if s is not None]
-    spec = {k: (tuple(max(s[k][0][d] for s in have) for d in range(len(have[0][k][0]))), have[0][k][1]) for k in _FIELDS}
-    out = {} if rank == dst else None
+    have = every[every[:, 0] > 0]
+    tails = {k: tuple(int(x) for x in have[:, 1 + 3 * i:4 + 3 * i].max(0)) for i, k in enumerate(_FIELDS)}
+    sizes = {k: mx * int(np.prod(tails[k])) * np.dtype(_DTYPES[k]).itemsize for k in _FIELDS}
+    buf = np.zeros(sum(sizes.values()), np.uint8)
+    off = 0
     for k in _FIELDS:
-        shape, dt = spec[k]
-        pad = np.zeros((mx,) + tuple(shape), dtype=np.dtype(dt))
         if n:
-            pad[(slice(0, n),) + tuple(slice(0, d) for d in rec[k].shape[1:])] = rec[k]
-        t = _to_dev(pad.view(np.uint8).reshape(mx, -1), device)
-        bufs = [torch.empty_like(t) for _ in range(world)] if rank == dst else None
-        dist.gather(t, bufs, dst=dst, group=group)
-        if rank == dst:
-            parts = [b.cpu().numpy()[:c].reshape(-1).view(np.dtype(dt)).reshape((c,) + tuple(shape))
-                     for b, c in zip(bufs, all_counts) if c]
-            out[k] = np.concatenate(parts, 0)
-    return out
+            view = buf[off:off + sizes[k]].view(_DTYPES[k]).reshape((mx,) + tails[k])
+            src = rec[k].reshape(rec[k].shape + (1,) * (4 - rec[k].ndim))
+            view[(slice(0, n),) + tuple(slice(0, d) for d in src.shape[1:])] = src
+        off += sizes[k]
+    t = _to_dev(buf, device)
+    bufs = [torch.empty_like(t) for _ in range(world)] if rank == dst else None
+    dist.gather(t, bufs, dst=dst, group=group)
+    if rank != dst:
+        return None
+    out = {k: [] for k in _FIELDS}
+    for r, c in enumerate(counts):
+        if not c:
+            continue
+        b = bufs[r].cpu().numpy()
+        off = 0
+        for i, k in enumerate(_FIELDS):
+            full = b[off:off + sizes[k]].view(_DTYPES[k]).reshape((mx,) + tails[k])
+            out[k].append(full[:c])
+            off += sizes[k]
+    # drop the padding axes again (every field has its own rank: meta / action 2-D, visits 3-D, ...)
+    ranks = dict(action=2, reward=2, value=2, visits=3, legal=3, obs=3, meta=2)
+    res = {k: np.concatenate(out[k], 0) for k in _FIELDS}
+    return {k: v.reshape(v.shape[:ranks[k]]) for k, v in res.items()}
 
 
 def broadcast_weights(state_dict, src=0, group=None, device=None):
