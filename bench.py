@@ -258,8 +258,8 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from hanabizero_amd.config import make_config
-    from hanabizero_amd.dist import gather_records
-    from hanabizero_amd.selfplay import SelfPlayActor, record_nbytes
+    from hanabizero_amd.dist import gather_packed
+    from hanabizero_amd.selfplay import SelfPlayActor, packed_layout
 
     game, N, S, stack = WORKLOADS[args.workload]
     cfg = make_config(game, simulations=S, stack=stack, p_mcts_num=N)
@@ -294,15 +294,17 @@ def main():
     flush_s = 0.0
 
     def flush():
+        """Finished games -> the replay owner (rank 0): one packed byte buffer per actor, gathered device to device
+        (hanabizero_amd.dist.gather_packed), landing in pinned host memory on rank 0 where `unpack_packed` views it."""
         nonlocal games, rec_bytes, flush_s
-        tf = time.perf_counter()
         torch.cuda.synchronize()
         tf0 = time.perf_counter()
         for a in actors:
-            got = gather_records(a.drain(), dst=0)
-            if rank == 0 and got is not None:
-                games += int(got["meta"].shape[0])
-                rec_bytes += record_nbytes(got)
+            got = gather_packed(a.drain_packed(), a.A, a.W, dst=0)
+            if rank == 0 and got:
+                for buf, n, tmax in got:
+                    games += n
+                    rec_bytes += packed_layout(n, tmax, a.A, a.W)[1]
         flush_s += time.perf_counter() - tf0
 
     for _ in range(args.warmup):  # includes graph capture (2 eager steps + capture) on the first call

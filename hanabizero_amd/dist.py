@@ -85,6 +85,61 @@ def gather_records(rec, dst=0, group=None, device=None):
     return {k: v.reshape(v.shape[:ranks[k]]) for k, v in res.items()}
 
 
+_pinned = {}
+
+
+def _pinned_bytes(key, nbytes):
+    buf = _pinned.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, pin_memory=torch.cuda.is_available())
+        _pinned[key] = buf
+    return buf[:nbytes]
+
+
+def gather_packed(packed, A, W, dst=0, group=None):
+    """The device-resident form of gather_records: `packed` = SelfPlayActor.drain_packed() (uint8 device tensor, n, tmax)
+    or None.  Two collectives: all_gather of (n, tmax), one gather of the byte buffers (padded to the longest; device to
+    device over xGMI under "nccl": the sending ranks never copy their records to the host).  Returns on `dst` a list of
+    (host uint8 numpy buffer in pinned memory, n, tmax) per rank with games -- `unpack_packed` views them without a
+    copy; the buffers are reused by the next call -- elsewhere None.  Works without a process group (world 1)."""
+    from .selfplay import packed_layout
+    n, tmax = (0, 0) if packed is None else (int(packed[1]), int(packed[2]))
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        if not n:
+            return []
+        host = _pinned_bytes(("r", 0), packed[0].numel())
+        host.copy_(packed[0], non_blocking=True)
+        torch.cuda.synchronize() if packed[0].is_cuda else None
+        return [(host.numpy(), n, tmax)]
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    backend = dist.get_backend(group)
+    device = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    mine = torch.tensor([n, tmax], dtype=torch.int64, device=device)
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine, group=group)
+    every = torch.stack(every).cpu().numpy()
+    sizes = [packed_layout(int(a), int(b), A, W)[1] if a else 0 for a, b in every]
+    mxb = max(sizes)
+    if mxb == 0:
+        return [] if rank == dst else None
+    send = torch.zeros(mxb, dtype=torch.uint8, device=device)
+    if n:
+        send[:packed[0].numel()] = packed[0].to(device)
+    bufs = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+    dist.gather(send, bufs, dst=dst, group=group)
+    if rank != dst:
+        return None
+    out = []
+    for r in range(world):
+        if sizes[r]:
+            host = _pinned_bytes(("r", r), sizes[r])
+            host.copy_(bufs[r][:sizes[r]], non_blocking=True)
+            out.append((host, int(every[r, 0]), int(every[r, 1])))
+    if device.type == "cuda":
+        torch.cuda.synchronize()
+    return [(h.numpy(), a, b) for h, a, b in out]
+
+
 def broadcast_weights(state_dict, src=0, group=None, device=None):
     """Broadcast a model state_dict from `src` in place (tensors are moved to `device` for nccl)."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:

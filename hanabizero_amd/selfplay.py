@@ -221,6 +221,35 @@ class SelfPlayActor:
         return rec
 
 
+    def drain_packed(self):
+        """The games finished since the last drain as ONE byte buffer that stays on the device: (uint8 tensor, n, tmax)
+        or None.  `packed_layout(n, tmax, A, W)` describes it; hanabizero_amd.dist.gather_packed moves such buffers to the
+        replay owner GPU-to-GPU (no host copy on the sending ranks), `unpack_packed` views one on the host."""
+        if self.stream is not None:
+            self.stream.synchronize()
+        count = int(self.out_count.item())
+        n = count - self._drained
+        if n <= 0:
+            return None
+        if n > self.cap:
+            raise RuntimeError("outbox overflow: %d games finished since the last drain, capacity %d" % (n, self.cap))
+        idx = torch.arange(self._drained, count, device=self.device) % self.cap
+        meta = self.out_meta.index_select(0, idx)
+        tmax = int(meta[:, 0].max().item())
+        layout, total = packed_layout(n, tmax, self.A, self.W)
+        buf = torch.zeros(total, dtype=torch.uint8, device=self.device)
+        for k, shp, dt, off in layout:
+            if k == "meta":
+                src = meta
+            else:
+                t = tmax + 1 if k in ("legal", "obs") else tmax
+                src = self.out[k].index_select(0, idx)[:, :t]
+            flat = src.contiguous().view(torch.uint8).reshape(-1)
+            buf[off:off + flat.numel()] = flat
+        self._drained = count
+        return buf, n, tmax
+
+
 class ActorGroup:
     """Several SelfPlayActors of one GPU stepped by ONE hipGraph whose branches (one per actor, forked onto side streams
     inside the capture) have no edges between them, so the runtime may overlap one actor's latency-bound tree kernels
@@ -261,6 +290,30 @@ class ActorGroup:
         for a in self.actors:
             a.total_moves += a.N
         self._graph.replay()
+
+
+_PACKED_FIELDS = ("meta", "action", "reward", "value", "visits", "legal", "obs")  # order inside a packed buffer
+
+
+def packed_layout(n, tmax, A, W):
+    """[(field, shape, numpy dtype, byte offset)], total bytes of the packed form of n games trimmed to tmax moves
+    (SelfPlayActor.drain_packed): every array starts on a 16-byte boundary."""
+    shapes = dict(meta=((n, 4), np.int32), action=((n, tmax), np.int8), reward=((n, tmax), np.int8),
+                  value=((n, tmax), np.float32), visits=((n, tmax, A), np.int16), legal=((n, tmax + 1, A), np.uint8),
+                  obs=((n, tmax + 1, W), np.int32))
+    out, off = [], 0
+    for k in _PACKED_FIELDS:
+        shp, dt = shapes[k]
+        out.append((k, shp, dt, off))
+        off += (int(np.prod(shp)) * np.dtype(dt).itemsize + 15) // 16 * 16
+    return out, off
+
+
+def unpack_packed(buf, n, tmax, A, W):
+    """Zero-copy views of a packed byte buffer (numpy uint8, host) as the dict drain() returns."""
+    layout, total = packed_layout(n, tmax, A, W)
+    assert buf.nbytes >= total
+    return {k: buf[off:off + int(np.prod(shp)) * np.dtype(dt).itemsize].view(dt).reshape(shp) for k, shp, dt, off in layout}
 
 
 def unpack_record(rec, i):

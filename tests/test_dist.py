@@ -45,6 +45,32 @@ def _worker(rank, world, port, counts, q):
                 sl = (slice(3 * r, 3 * r + 3),) + tuple(slice(0, d) for d in w[k].shape[1:])
                 ok &= bool((got[k][sl] == w[k]).all())
         ok &= bool((got["action"][:3, 4:] == 0).all())  # rank 0's rows are zero-padded up to rank 1's extent
+    # the device-resident form: packed byte buffers (here CPU tensors over gloo), different (n, tmax) per rank, one empty
+    from hanabizero_amd.dist import gather_packed
+    from hanabizero_amd.selfplay import packed_layout, unpack_packed
+    A, W = 11, 7
+
+    def pack(rec_):
+        n_, tmax_ = rec_["meta"].shape[0], rec_["action"].shape[1]
+        layout, total = packed_layout(n_, tmax_, A, W)
+        buf = np.zeros(total, np.uint8)
+        for k, shp, dt, off in layout:
+            raw = np.ascontiguousarray(rec_[k]).view(np.uint8).reshape(-1)
+            buf[off:off + raw.size] = raw
+        return torch.from_numpy(buf), n_, tmax_
+    for rnd, ns in enumerate([(3, 2), (0, 4), (0, 0)]):
+        mine = _fake_rec(ns[rank], 50 + 10 * rnd + rank, T=5 + 3 * rank, A=A, W=W) if ns[rank] else None
+        got = gather_packed(None if mine is None else pack(mine), A, W, dst=0)
+        if rank == 0:
+            want = [(r, _fake_rec(c, 50 + 10 * rnd + r, T=5 + 3 * r, A=A, W=W)) for r, c in enumerate(ns) if c]
+            ok &= len(got) == len(want)
+            for (buf, n_, tmax_), (r, w) in zip(got, want):
+                view = unpack_packed(buf, n_, tmax_, A, W)
+                ok &= n_ == ns[r] and tmax_ == 5 + 3 * r
+                for k in w:
+                    ok &= bool((view[k] == w[k]).all()) and view[k].dtype == w[k].dtype
+        else:
+            ok &= got is None
     sd = {"b": torch.full((3,), float(rank)), "a": torch.arange(4.0) * (rank + 1)}
     out = broadcast_weights(sd, src=0)
     ok &= bool((out["b"] == 0).all()) and bool((out["a"] == torch.arange(4.0)).all())

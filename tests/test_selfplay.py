@@ -208,3 +208,24 @@ def test_persistent_search_kernel_equals_launch_per_phase(game, N, sims):
     assert torch.equal(a[3][0], b[3][0]) and torch.equal(a[3][1], b[3][1])
     assert torch.equal(a[5], b[5])
     assert int(a[0].sum()) == N * (sims - 1)
+
+
+def test_packed_drain_equals_drain():
+    """drain_packed (one byte buffer that stays on the device) carries exactly what drain() returns."""
+    from hanabizero_amd.selfplay import packed_layout, unpack_packed
+    recs = []
+    for packed in (False, True):
+        cfg, eng, actor = make("Hanabi-Small", 64, 10, 2, torch.bfloat16, True, seed=33)
+        for _ in range(40):
+            actor.step()
+        torch.cuda.synchronize()
+        if packed:
+            buf, n, tmax = actor.drain_packed()
+            assert buf.is_cuda and buf.numel() == packed_layout(n, tmax, actor.A, actor.W)[1]
+            recs.append(unpack_packed(buf.cpu().numpy(), n, tmax, actor.A, actor.W))
+            assert actor.drain_packed() is None
+        else:
+            recs.append(actor.drain())
+    assert recs[0]["meta"].shape[0] > 10
+    for k in recs[0]:
+        assert recs[0][k].dtype == recs[1][k].dtype and (recs[0][k] == recs[1][k]).all(), k
