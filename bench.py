@@ -227,7 +227,7 @@ def main():
     ap.add_argument("--share-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--no-fused-mlp", action="store_true", help="hipBLASLt GEMM chain instead of the fused MFMA kernel")
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
-    ap.add_argument("--flush-every", type=int, default=10, help="drain + gather finished games every this many steps")
+    ap.add_argument("--flush-every", type=int, default=40, help="drain + gather finished games every this many steps (the outbox ring holds 4 x envs games: ~58 steps of Hanabi-Full) and once at the end of the timed loop")
     ap.add_argument("--actors-per-gpu", type=int, default=1,
                     help="split this GPU's envs over this many concurrent actors (own hipGraph + stream each)")
     ap.add_argument("--branch-graph", action="store_true", help="with --actors-per-gpu > 1: one hipGraph with a branch per actor")
