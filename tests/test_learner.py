@@ -178,3 +178,87 @@ def test_bf16_learner_step_on_gpu_and_weights_reach_the_engine():
         out = net.cuda().initial_inference(obs)
     assert np.allclose(v.cpu().numpy(), np.asarray(out.value).reshape(-1), atol=0.25, rtol=0.05)
     assert torch.isfinite(h.float()).all() and p.shape == (64, cfg.action_space_size)
+
+
+def test_replay_buffer_bookkeeping():
+    from hanabizero_amd.replay import ReplayBuffer
+    cfg = _cfg()
+
+    class G:
+        def __init__(self, T):
+            self.T = T
+
+        def __len__(self):
+            return self.T
+    rb = ReplayBuffer(cfg, transition_top=40, seed=1)
+    rb.save_pools([(G(10), None), (G(7), np.arange(7) + 1.0)])
+    assert rb.get_total_len() == 17 and rb.size() == 2 and rb.priorities[:10].tolist() == [1.0] * 10
+    assert rb.priorities[10:].tolist() == list(np.arange(7) + 1.0)
+    rb.save_game(G(5), True, 0)                       # new games enter at the current maximum priority
+    assert rb.priorities[-5:].tolist() == [7.0] * 5
+    games, pos, idx, w, mt = rb.prepare_batch_context(6, beta=0.4)
+    assert len(set(idx.tolist())) == 6 and w.max() == 1.0 and all(0 <= p < len(g) for g, p in zip(games, pos))
+    p = rb.priorities ** 0.6
+    p /= p.sum()
+    want = (22 * p[idx]) ** -0.4
+    assert np.allclose(w, want / want.max(), rtol=1e-6)
+    rb.update_priorities(idx, np.full(6, 0.5), mt)
+    assert (rb.priorities[idx] == 0.5).all()
+    for _ in range(4):
+        rb.save_game(G(9), True, 0)
+    dropped = rb.remove_to_fit()                       # 58 positions > 40: oldest games go, look-ups stay consistent
+    assert dropped >= 1 and rb.get_total_len() == sum(len(g) for g in rb.buffer) <= 40 + 9
+    gid, gpos = rb.game_look_up[0]
+    assert gid - rb.base_idx == 0 and gpos == 0
+
+
+@pytest.mark.gpu
+def test_self_play_to_learner_loop_on_one_gpu():
+    """actor -> drain_packed -> gather_packed -> ReplayBuffer.ingest_packed -> make_batch -> update_weights ->
+    InferenceEngine.load -> actor keeps playing with the new weights (the loop of core/train.py + workers, Ray-free)."""
+    from hanabizero_amd.dist import gather_packed
+    from hanabizero_amd.learner import make_batch, make_optimizer, update_weights
+    from hanabizero_amd.model import InferenceEngine
+    from hanabizero_amd.replay import ReplayBuffer
+    from hanabizero_amd.selfplay import SelfPlayActor
+    cfg = _cfg("Hanabi-Small", stack=2)
+    cfg.batch_size = 32
+    torch.manual_seed(0)
+    net = cfg.get_uniform_network()
+    for p in net.parameters():
+        if float(p.detach().abs().sum()) == 0.0:
+            torch.nn.init.normal_(p, std=0.1)
+    net.eval()
+    eng = InferenceEngine(net, cfg.value_support.max, dtype=torch.bfloat16, device="cuda")
+    actor = SelfPlayActor(cfg, eng, 128, seed=3)
+    rb = ReplayBuffer(cfg)
+    for step in range(30):
+        actor.step()
+        if step % 10 == 9:  # random-init nets lose a Hanabi-Small game in a handful of moves: drain often
+            for buf, n, tmax in gather_packed(actor.drain_packed(), actor.A, actor.W):
+                rb.ingest_packed(buf, n, tmax)
+    assert rb.size() > 50 and rb.get_total_len() > 10 * cfg.batch_size
+    g0 = rb.buffer[0]
+    assert len(g0.child_visits) == len(g0) and abs(sum(g0.child_visits[0]) - 1.0) < 1e-6
+    learner = cfg.get_uniform_network().cuda()
+    learner.load_state_dict(net.state_dict())
+    opt = make_optimizer(learner, cfg)
+    for grp in opt.param_groups:
+        grp["lr"] = 0.02
+    value_fn = lambda o: eng.initial(torch.from_numpy(o).cuda())[0].float().cpu().numpy()
+    losses = []
+    for it in range(6):
+        games, pos, idx, w, mt = rb.prepare_batch_context(cfg.batch_size, beta=0.4)
+        batch = make_batch(games, pos, cfg, value_fn, weights=w, rng=np.random.RandomState(it))
+        loss_data, prio = update_weights(learner, batch, opt, cfg, amp=torch.bfloat16)
+        rb.update_priorities(idx, prio, mt)
+        losses.append(loss_data[1])
+    assert np.isfinite(losses).all()
+    learner.eval()
+    eng.load(learner.cpu())            # selfplay_worker.py:177-184: the actor picks the new weights up
+    actor._graph = None                # (the captured graph holds the old fused tables: capture again)
+    before = int(actor.out_count.item())
+    for _ in range(8):
+        actor.step()
+    torch.cuda.synchronize()
+    assert int(actor.illegal_steps) == 0 and int(actor.out_count.item()) > before
