@@ -181,7 +181,8 @@ def test_select_action_kernel_edge_cases():
     assert act.tolist() == [10, 0, -1, 1, 0]
 
 
-@pytest.mark.parametrize("game,N,sims", [("Hanabi-Small", 100, 12), ("Hanabi-Full", 50, 50), ("Hanabi-Full", 1000, 20)])
+@pytest.mark.parametrize("game,N,sims", [("Hanabi-Small", 100, 12), ("Hanabi-Full", 50, 50), ("Hanabi-Full", 1000, 20),
+                                         ("Hanabi-Full-5p", 70, 30)])
 def test_persistent_search_kernel_equals_launch_per_phase(game, N, sims):
     """hz_search_run (all simulations in one persistent kernel, a workgroup per 16 trees) against the launch-per-phase
     search (hz_tree_traverse -> hz_mlp_recurrent -> hz_tree_backprop_traverse ...): bit-identical trees, hidden-state
