@@ -1,15 +1,17 @@
 // hz_mlp.hip -- the whole recurrent inference of one simulation (hidden-state gather + dynamics + reward/value/policy
 // heads + scalar transforms) as ONE MFMA kernel for gfx950.  See include/hz_mlp.h for what it replaces and why.
 //
-// Work split: workgroup = 256 threads = 4 waves = MT rows (16 or 32) of the batch.  The rows' activations live in an
-// LDS image (bf16, one image row per batch row) for the whole layer chain.  The chain is a table of jobs; in job j wave
-// w produces 64 output columns (4 MFMA tiles) of one layer:
+// Work split (body in hz_mlp_dev.h, shared with the persistent search kernel hz_search.hip): a workgroup of NW waves
+// (4, 8 or 16) owns MT rows (16 or 32) of the batch.  The rows' activations live in an LDS image (bf16, one image row per
+// batch row) for the whole layer chain.  The chain is a table of jobs; in job j wave w produces 16 * NT output columns
+// (NT MFMA tiles: 4, or 2 with 16 waves) of one layer:
 //     D[n][row] += W[n][k] * X[k][row]      v_mfma_f32_16x16x32_bf16, A = weights, B = activations (ds_read_b128)
 // so a lane ends up with 4 consecutive output columns of one batch row -> one ds_write_b64 per tile into the image.
-// Each wave's weights are ONE contiguous stream in execution order (1 KiB-contiguous dwordx4 fragment loads), held in an
-// 8-slot register ring: 7 k-steps (28 KiB per wave, 112 KiB per CU) are always in flight, across job, layer and
-// barrier boundaries (barriers wait for LDS traffic only), so the kernel runs at the per-CU L2 streaming rate -- every
-// weight byte is fetched once per workgroup and that stream is the bound, not the matrix cores.
+// Each wave's weights are ONE stream in execution order (1 KiB-contiguous dwordx4 fragment loads; the waves' streams are
+// interleaved k-step by k-step in memory), prefetched HZ_RING - 1 = 3 k-steps ahead in a register ring across job, layer
+// and barrier boundaries (barriers wait for LDS traffic only).  The kernel is bound by the CU's L2 port: every weight byte
+// is fetched once per workgroup and that stream, not the matrix cores, sets the time (DESIGN.md section 4 has the
+// measurements: ring depth, burst size and stream layout do not matter; the layer boundaries do).
 #include "hz_mlp_dev.h"
 #include "hz_tree.h"
 

@@ -9,11 +9,13 @@
  * each workgroup's rows' activations in LDS across all layers and streams the (eval-mode, BatchNorm-folded, bf16)
  * weights through v_mfma_f32_16x16x32_bf16 (fp32 accumulate): the matrix cores do exactly the net GEMMs, nothing else.
  *
- * The layer chain is DATA: a list of "jobs".  Job j of wave w (4 waves per workgroup) computes 64 output columns
- *     out[:, dst_off : dst_off+64] = act( in[:, src_off : src_off + 32*ks] @ W_jw^T + b_jw [+ action row] [+ residual] )
- * over the workgroup's rows, reading and writing one LDS image row per batch row.  Every wave owns ONE contiguous weight
- * stream (its jobs' fragments in execution order), prefetched 7 k-steps ahead in a register ring across job and layer
- * boundaries.  hanabizero_amd/model.py::FusedRecurrent builds the job table and the streams from a module.
+ * The layer chain is DATA: a list of "jobs".  Job j of wave w (num_waves = 4, 8 or 16 waves per workgroup) computes
+ * C = 16 * tiles_per_wave output columns (64, or 32 with 16 waves)
+ *     out[:, dst_off : dst_off+C] = act( in[:, src_off : src_off + 32*ks] @ W_jw^T + b_jw [+ action row] [+ residual] )
+ * over the workgroup's rows, reading and writing one LDS image row per batch row.  Every wave owns ONE weight stream
+ * (its jobs' fragments in execution order; the streams are interleaved k-step by k-step), prefetched 3 k-steps ahead
+ * in a register ring across job and layer boundaries.  hanabizero_amd/model.py::FusedRecurrent (recurrent inference)
+ * and ::FusedInitialTail (the small-GEMM tail of the initial inference) build job tables and streams from a module.
  * Numerics: the rounding points of the bf16 PyTorch path (bf16 activations between layers, fp32 accumulation and
  * epilogue); checked against the reference's fp32 nets at the north-star tolerance (tests/test_model.py).
  * Conventions as include/hz_tree.h.
