@@ -211,6 +211,22 @@ __device__ __forceinline__ void mlp_body(
     J.res_off = __builtin_amdgcn_readlane(jr, jb + 3);
     J.bias_off = __builtin_amdgcn_readlane(jr, jb + 4);
     J.flags = __builtin_amdgcn_readlane(jr, jb + 5);
+    // epilogue operands first, and BEFORE the layer barrier: they depend on nothing the other waves produce, their
+    // latency hides under the k-loop, and their address arithmetic stays off the path between barrier and first MFMA
+    float4 bv[NT], av[NT][RT];
+    if (J.ks != 0) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        bv[t] = *reinterpret_cast<const float4*>(bias + J.bias_off + 16 * t + c4);
+        // unconditional loads (row num_actions of the table is all zeros): a load under a branch would make the
+        // compiler wait for EVERY outstanding load (vmcnt(0)) in the epilogue and drain the weight ring once per job
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const int arow = (J.flags & HZ_MLP_ACTION_ROW) ? act[rt] : H.num_actions;
+          av[t][rt] = *reinterpret_cast<const float4*>(act_tab + (size_t)arow * H.action_table_stride + J.bias_off + 16 * t + c4);
+        }
+      }
+    }
     const unsigned long long p_j0 = PROF_NOW();
 #ifndef HZ_MLP_X_NOBAR  // (experiment switch, tools/mlp_variants.py)
     if (J.flags & HZ_MLP_BARRIER) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // LDS only: loads stay in flight
@@ -230,19 +246,15 @@ __device__ __forceinline__ void mlp_body(
 #endif
     if (J.ks == 0) continue;
     const unsigned long long p_j1 = PROF_NOW();
-    // epilogue operands first: their latency hides under the k-loop
-    float4 bv[NT], av[NT][RT];
+    // the first activation fragments right behind the barrier: this LDS round trip is the one latency nothing hides
+    const uint16_t* src = lds + (size_t)r0 * rs + J.src_off + kq;
+    bf16x8 bq[4][RT];  // activation fragments, 3 k-steps ahead of their use
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      bv[t] = *reinterpret_cast<const float4*>(bias + J.bias_off + 16 * t + c4);
-      // unconditional loads (row num_actions of the table is all zeros): a load under a branch would make the
-      // compiler wait for EVERY outstanding load (vmcnt(0)) in the epilogue and drain the weight ring once per job
+    for (int d = 0; d < 3; ++d)
+      if (d < J.ks) {
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {
-        const int arow = (J.flags & HZ_MLP_ACTION_ROW) ? act[rt] : H.num_actions;
-        av[t][rt] = *reinterpret_cast<const float4*>(act_tab + (size_t)arow * H.action_table_stride + J.bias_off + 16 * t + c4);
+        for (int rt = 0; rt < RT; ++rt) bq[d][rt] = *reinterpret_cast<const bf16x8*>(src + (size_t)(16 * rt) * rs + 32 * d);
       }
-    }
     f32x4 acc[NT][RT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -258,14 +270,6 @@ __device__ __forceinline__ void mlp_body(
 #else
 #define HZ_ACC(U) acc
 #endif
-    const uint16_t* src = lds + (size_t)r0 * rs + J.src_off + kq;
-    bf16x8 bq[4][RT];  // activation fragments, 3 k-steps ahead of their use (LDS latency never exposed)
-#pragma unroll
-    for (int d = 0; d < 3; ++d)
-      if (d < J.ks) {
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) bq[d][rt] = *reinterpret_cast<const bf16x8*>(src + (size_t)(16 * rt) * rs + 32 * d);
-      }
     __builtin_amdgcn_sched_barrier(0);
 
 #define HZ_MLP_STEP(S, U)                                                                                            \
