@@ -307,7 +307,15 @@ def main():
                     rec_bytes += packed_layout(n, tmax, a.A, a.W)[1]
         flush_s += time.perf_counter() - tf0
 
-    for _ in range(args.warmup):  # includes graph capture (2 eager steps + capture) on the first call
+    if not args.no_graph:  # capture (2 eager lock-steps + the capture itself) is set-up, whatever --warmup says
+        if group is not None:
+            group._capture() if group._graph is None else None
+        else:
+            for a in actors:
+                a._capture() if a._graph is None else None
+        step_all()  # the first replay instantiates / uploads the graph (tens of ms): set-up as well
+        torch.cuda.synchronize()
+    for _ in range(args.warmup):
         step_all()
     flush()
     torch.cuda.synchronize()
