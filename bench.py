@@ -63,7 +63,7 @@ def kernel_timing(actor, sample_sims=(4, 16, 28, 40), clones=8, replays=5):
     cfg, roots, eng = actor.cfg, actor.roots, actor.engine
     N, S, oh = actor.N, actor.S, eng.onehot_cols
     actor._draw()
-    value0, logits0, hidden0 = eng.initial(actor.stack_buf.view(N, actor.stack * actor.D))
+    value0, logits0, hidden0 = actor.root_inference()
     roots.prepare(cfg.root_exploration_fraction, actor.noise, actor.zeros_n, logits0, actor.legal)
     actor.pool[0].copy_(hidden0)
     net_in = torch.empty((N, eng.H + oh), dtype=eng.dtype, device=actor.device)

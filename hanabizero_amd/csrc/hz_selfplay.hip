@@ -406,7 +406,8 @@ extern "C" int hz_actor_begin_move(const hz_actor_bufs_t* bufs, const uint8_t* d
   hipLaunchKernelGGL(k_actor_begin_move<U>, grid, block, 0, (hipStream_t)stream, *bufs, done, packed, legal,      \
                      (const uint8_t*)newest, (long long)newest_row_bytes, (uint8_t*)stack_buf,                    \
                      (long long)stack_row_bytes, stack, (long long)obs_bytes)
-  if ((al & 3) == 0) HZ_BEGIN_MOVE(uint32_t);
+  if ((al & 15) == 0) HZ_BEGIN_MOVE(uint4);  // slot-padded windows (InferenceEngine.pad_observations)
+  else if ((al & 3) == 0) HZ_BEGIN_MOVE(uint32_t);
   else if ((al & 1) == 0) HZ_BEGIN_MOVE(uint16_t);  // bf16 observations of odd width
   else HZ_BEGIN_MOVE(uint8_t);
 #undef HZ_BEGIN_MOVE

@@ -65,9 +65,12 @@ class SelfPlayActor:
         self.mcts = MCTS(config)
         dt = engine.dtype
         z = lambda *s, dtype: torch.zeros(s, dtype=dtype, device=d)
-        # model input ring and search state (static addresses: the whole step can be graph-captured)
-        self.stack_buf = z(N, self.stack, self.D, dtype=dt)
-        self.newest = z(N, self.D, dtype=dt)
+        # model input window and search state (static addresses: the whole step can be graph-captured).  Every slot of
+        # the window is padded to a multiple of 8 elements (zero weights on the pad columns): 16-byte aligned rows for
+        # the first GEMM and for the window shift
+        self.Dp = engine.pad_observations(self.D, self.stack) if hasattr(engine, "pad_observations") else self.D
+        self.stack_buf = z(N, self.stack, self.Dp, dtype=dt)
+        self.newest = z(N, self.Dp, dtype=dt)
         self.legal = z(N, self.A, dtype=torch.uint8)
         self.pool = z(self.S, N, engine.H, dtype=dt)
         self.noise = z(N, self.A, dtype=torch.float32)
@@ -136,11 +139,16 @@ class SelfPlayActor:
                                 _stream()), "hz_actor_draw")
 
     # -- one lock-step, device only --------------------------------------------------------------------------
+    def root_inference(self, state_out=None):
+        """initial_inference of every env's current (slot-padded) observation window: (value, policy logits, state)."""
+        return self.engine.initial(self.stack_buf.view(self.N, self.stack * self.Dp), state_out=state_out,
+                                   padded=self.Dp != self.D)
+
     def _step_body(self, draw=True):
         cfg, N = self.cfg, self.N
         if draw:
             self._draw()
-        value0, logits0, hidden0 = self.engine.initial(self.stack_buf.view(N, self.stack * self.D), state_out=self.pool[0])
+        value0, logits0, hidden0 = self.root_inference(state_out=self.pool[0])
         self.roots.prepare(cfg.root_exploration_fraction, self.noise, self.zeros_n, logits0, self.legal)
         self.mcts.run_multi(self.roots, self.engine, hidden0, pool=self.pool)
         self.roots.root_stats_tensors(self.counts, self.values)
@@ -163,7 +171,7 @@ class SelfPlayActor:
         es = self.newest.element_size()
         check(lib.hz_actor_begin_move(b, done.data_ptr(), self.tmp_packed.data_ptr(), self.legal.data_ptr(),
                                       self.newest.data_ptr(), self.newest.stride(0) * es, self.stack_buf.data_ptr(),
-                                      self.stack_buf.stride(0) * es, self.stack, self.D * es, st), "hz_actor_begin_move")
+                                      self.stack_buf.stride(0) * es, self.stack, self.Dp * es, st), "hz_actor_begin_move")
 
     def _capture(self):
         self.roots.set_params(self.cfg.pb_c_base, self.cfg.pb_c_init, self.cfg.discount, self.cfg.value_delta_max)

@@ -55,11 +55,14 @@ def test_actor_matches_oracle_replay(game, N, sims, stack, steps):
         actor._draw()
         noise, uni = actor.noise.cpu().numpy(), actor.uniform.cpu().numpy()
         stack_in = np.stack([np.concatenate(w) for w in windows]).astype(np.float32)
-        assert (actor.stack_buf.view(N, -1).cpu().numpy() == stack_in).all(), step
+        assert (actor.stack_buf[:, :, :D].reshape(N, -1).float().cpu().numpy() == stack_in).all(), step
         assert (actor.legal.cpu().numpy() == legal).all()
         actor._step_body(draw=False)  # (the draws above are this move's)
         # ---- oracle replay of the same move
-        v0, l0, h0 = eng.initial(torch.from_numpy(stack_in).cuda())
+        # (the same first-layer GEMM as the actor: observation slots padded to actor.Dp columns)
+        win = np.zeros((N, stack, actor.Dp), np.float32)
+        win[:, :, :D] = stack_in.reshape(N, stack, D)
+        v0, l0, h0 = eng.initial(torch.from_numpy(win.reshape(N, -1)).cuda(), padded=actor.Dp != D)
         tree = OracleTree(N, A, sims, seed=3, value_delta_max=cfg.value_delta_max)
         tree.prepare(cfg.root_exploration_fraction, noise, np.zeros(N, np.float32), l0.cpu().numpy(), legal)
         pool = [h0]
@@ -192,7 +195,7 @@ def test_persistent_search_kernel_equals_launch_per_phase(game, N, sims):
     cfg, eng, actor = make(game, N, sims, 2, torch.bfloat16, use_graph=False)
     A = cfg.action_space_size
     g = torch.Generator(device="cuda").manual_seed(N)
-    value0, logits0, hidden0 = eng.initial(actor.stack_buf.view(N, -1))
+    value0, logits0, hidden0 = actor.root_inference()
     noise = torch.rand(N, A, device="cuda", generator=g)
     noise = noise / noise.sum(1, keepdim=True)
     res = []
