@@ -448,7 +448,8 @@ __global__ __launch_bounds__(256) void k_env_reset_wave(EnvCfg g, uint32_t* __re
   for (int deal = 0; deal < deals; ++deal) {
     // ApplyRandomChance (hanabi_state.cc:282-286) -> PickRandomChance (hanabi_game.cc:106-112): see deal_random
     const double tot = (double)total;
-    const double q1 = 1.0 / tot, q2 = 2.0 / tot, q3 = 3.0 / tot;
+    // (2.0 / tot == 2 * (1.0 / tot) bit for bit: scaling by two commutes with the rounding of the quotient)
+    const double q1 = 1.0 / tot, q2 = q1 + q1, q3 = 3.0 / tot;
     const uint64_t present = __ballot(cnt > 0);
     const int n_out = __popcll((unsigned long long)present);
     double sum = 0.0;
@@ -466,7 +467,7 @@ __global__ __launch_bounds__(256) void k_env_reset_wave(EnvCfg g, uint32_t* __re
       pos += 2;
       double u = (lo + hi * 4294967296.0) / 18446744073709551616.0;
       if (u >= 1.0) u = 0x1.fffffffffffffp-1;
-      const double p1 = q1 / sum, p2 = q2 / sum, p3 = q3 / sum;
+      const double p1 = q1 / sum, p2 = p1 + p1, p3 = q3 / sum;
       double acc = 0.0;
       int seen = 0;
       for (uint64_t m = present; m;) {
