@@ -64,6 +64,24 @@ __device__ __forceinline__ float hz_row16_sum(float v) {
   return v;
 }
 
+// Left-to-right sum of x over lanes 0 .. n-1 (x = +0.0f in lanes that do not take part), seeded with `init`, in exactly
+// the order a serial loop over the lanes adds them: a systolic pass -- every step each lane adds its x to what its left
+// neighbour held (v_add_f32 with DPP wave_shr:1; lane 0 takes `init`) -- after which lane i holds init + x_0 + ... + x_i.
+// n steps of one VALU instruction instead of n trips of a ballot-walking readlane loop.  Returns the total (lane n-1's).
+// Adding +0.0f for a skipped lane is exact as long as the running sum is not -0.0f, which a sum seeded with a
+// non-negative `init` never is.
+__device__ __forceinline__ float hz_ordered_sum(float x, int n, float init) {
+  float acc = 0.0f;
+  // (steps beyond n change nothing in lanes < n -- each recomputes the value it already holds -- so the loop runs in
+  // groups of four without a remainder)
+  for (int s = 0; s < n; s += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      acc = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(init), __float_as_int(acc), 0x138, 0xf, 0xf, false)) + x;
+  }
+  return hz_readlane_f(acc, n - 1);
+}
+
 // max / min over the 64 lanes (callers mask with +-inf): 16-lane DPP butterflies, then the four row results
 __device__ __forceinline__ float hz_wave_max(float v) {
   v = hz_row16_max(v);

@@ -72,13 +72,7 @@ __device__ __forceinline__ float expand_prior(float logit, uint64_t legal_mask, 
   const float policy_max = fmaxf(m, HZ_FLOAT_MIN);
   const float tp = legal ? hz_expf(logit - policy_max, exp_tab) : 0.0f;  // cnode.cpp:87
   // policy_sum: 1e-4 + terms in action order over the legal children (cnode.cpp:57,88)
-  float policy_sum = 0.0001f;
-  uint64_t mm = legal_mask;
-  while (mm) {
-    const int a = __ffsll((unsigned long long)mm) - 1;
-    mm &= mm - 1;
-    policy_sum += hz_readlane_f(tp, a);
-  }
+  const float policy_sum = legal_mask ? hz_ordered_sum(tp, 64 - __clzll((unsigned long long)legal_mask), 0.0001f) : 0.0001f;
   float prior = legal ? tp / policy_sum : 0.0f;  // cnode.cpp:98-103
   if (prior != prior) prior = 0.0f;              // cnode.cpp:107-109
   (void)A;
@@ -168,10 +162,14 @@ __device__ __forceinline__ void traverse_body(const TreeView& tv, int tree, int 
     uint64_t vm = __ballot(on && visit > 0);
     const int nvis = __popcll((unsigned long long)vm);
     float total = 0.0f;
-    while (vm) {
-      const int a = __ffsll((unsigned long long)vm) - 1;
-      vm &= vm - 1;
-      total += hz_readlane_f(qsa, a);
+    if (nvis > 4) {  // many visited children (the root, late in the search): one systolic pass over the lanes
+      total = hz_ordered_sum((on && visit > 0) ? qsa : 0.0f, 64 - __clzll((unsigned long long)vm), 0.0f);
+    } else {
+      while (vm) {
+        const int a = __ffsll((unsigned long long)vm) - 1;
+        vm &= vm - 1;
+        total += hz_readlane_f(qsa, a);
+      }
     }
     const bool root_mean = is_root && nvis > 0;  // cnode.cpp:228-236: the root leaves its own q out
     const float mean_q = (root_mean ? total : parent_q + total) / (float)(root_mean ? nvis : nvis + 1);
