@@ -318,6 +318,9 @@ def main():
     for _ in range(args.warmup):
         step_all()
     flush()
+    if world > 1:  # the record gather's point-to-point channels exist before the timed region even if no game has ended yet
+        w = torch.zeros(16, dtype=torch.uint8, device=device if args.backend == "nccl" else "cpu")
+        dist.gather(w, [torch.empty_like(w) for _ in range(world)] if rank == 0 else None, dst=0)
     torch.cuda.synchronize()
     barrier()
     games, rec_bytes, flush_s = 0, 0, 0.0

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_recurrent(
     float* __restrict__ out_value, float* __restrict__ out_policy, int n_rows) {
   extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
   mlp_body<RT, NW, NT>(H, jobs, wstream, bias, act_tab, state_src, state_row_stride, plane_index, plane_stride, actions,
-                       hidden_out, out_reward, out_value, out_policy, n_rows, lds, (int)blockIdx.x * 16 * RT, RowFrag());
+                       hidden_out, out_reward, out_value, out_policy, n_rows, lds, (int)blockIdx.x * 16 * RT, nullptr);
 }
 
 extern "C" int hz_mlp_recurrent(const hz_mlp_header_t* H, const hz_mlp_job_t* jobs, const void* wstream,

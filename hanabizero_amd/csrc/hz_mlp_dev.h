@@ -99,7 +99,7 @@ extern "C" int hz_mlp_profile_read_passes(unsigned long long* host) {
 // for the stand-alone kernel, 16 x 2 inside the persistent search kernel, whose 16 waves also own one tree each).
 // `lds`: the row image, MT * row_stride bf16.
 // The input rows of a workgroup: gathered here from state_src (STAGE_GATHER), or handed over by the caller's waves in
-// registers (STAGE_REGS: wave w holds row w, lane l its l-th 16-B chunk in row_frag.v[l / 64]; needs NW == 16 * RT) and
+// registers (STAGE_REGS: wave w holds rows w, 16 + w, ..; lane l its l-th 16-B chunk in row_frag[rt].v[l / 64]; NW == 16) and
 // written into the image here, after the weight ring has been started -- the rows' load latency hides under it.
 enum { STAGE_GATHER = 0, STAGE_REGS = 1 };
 struct RowFrag {
@@ -113,7 +113,7 @@ __device__ __forceinline__ void mlp_body(
     long long state_row_stride, const int32_t* __restrict__ plane_index, long long plane_stride,
     const int32_t* __restrict__ actions, uint16_t* __restrict__ hidden_out, float* __restrict__ out_reward,
     float* __restrict__ out_value, float* __restrict__ out_policy, int n_rows, uint16_t* lds, int row0,
-    const RowFrag& row_frag) {
+    const RowFrag* row_frag) {
   constexpr int NTHR = 64 * NW;
   constexpr bool PRESTAGED = STAGE == STAGE_REGS;
   constexpr int MT = 16 * RT;
@@ -183,11 +183,13 @@ __device__ __forceinline__ void mlp_body(
   }
 #endif
   if (STAGE == STAGE_REGS) {
-    static_assert(STAGE != STAGE_REGS || NW == 16 * RT, "one wave per row");
+    static_assert(STAGE != STAGE_REGS || NW == 16, "wave w holds rows w, 16 + w, ...");
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
-      if (lane + 64 * u < chunks)
-        *reinterpret_cast<uint4*>(lds + (size_t)wave * rs + H.state_off + (lane + 64 * u) * 8) = row_frag.v[u];
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        if (lane + 64 * u < chunks)
+          *reinterpret_cast<uint4*>(lds + (size_t)(16 * rt + wave) * rs + H.state_off + (lane + 64 * u) * 8) = row_frag[rt].v[u];
   }
   __syncthreads();
   int act[RT];  // (read after the barrier: in STAGE_REGS mode the caller's waves have only just written them)
@@ -248,9 +250,12 @@ __device__ __forceinline__ void mlp_body(
     const unsigned long long p_j1 = PROF_NOW();
     // the first activation fragments right behind the barrier: this LDS round trip is the one latency nothing hides
     const uint16_t* src = lds + (size_t)r0 * rs + J.src_off + kq;
-    bf16x8 bq[4][RT];  // activation fragments, 3 k-steps ahead of their use
+    // activation fragments, BQD - 1 k-steps ahead of their use (RT = 2 has the registers for one step ahead only; its
+    // four MFMAs per k-step cover the LDS round trip)
+    constexpr int BQD = RT == 1 ? 4 : 2;
+    bf16x8 bq[BQD][RT];
 #pragma unroll
-    for (int d = 0; d < 3; ++d)
+    for (int d = 0; d < BQD - 1; ++d)
       if (d < J.ks) {
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) bq[d][rt] = *reinterpret_cast<const bf16x8*>(src + (size_t)(16 * rt) * rs + 32 * d);
@@ -281,13 +286,14 @@ __device__ __forceinline__ void mlp_body(
       _Pragma("unroll") for (int t = 0; t < 2 * NT; ++t)                                                             \
           wf[((U) + HZ_RING - 2 + t / NT) % HZ_RING][t % NT] = wp(gstep + (S) + HZ_RING - 2 + t / NT, t % NT);          \
     }                                                                                                                \
-    if (HZ_MLP_BREAD) { /* unconditional: the last three trips read past the K range, into fragments nobody uses */ \
+    if (HZ_MLP_BREAD) { /* unconditional: the last trips read past the K range, into fragments nobody uses */       \
       _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                                              \
-          bq[((U) + 3) % 4][rt] = *reinterpret_cast<const bf16x8*>(src + (size_t)(16 * rt) * rs + 32 * ((S) + 3));   \
+          bq[((U) + BQD - 1) % BQD][rt] =                                                                            \
+              *reinterpret_cast<const bf16x8*>(src + (size_t)(16 * rt) * rs + 32 * ((S) + BQD - 1));                 \
     }                                                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                               \
     _Pragma("unroll") for (int t = 0; t < NT; ++t) _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                  \
-        HZ_ACC(U)[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[(U) % HZ_RING][t], bq[(U) % 4][rt], HZ_ACC(U)[t][rt], 0, 0, 0); \
+        HZ_ACC(U)[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[(U) % HZ_RING][t], bq[(U) % BQD][rt], HZ_ACC(U)[t][rt], 0, 0, 0); \
     __builtin_amdgcn_sched_barrier(0);                                                                               \
   }
 

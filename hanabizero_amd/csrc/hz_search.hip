@@ -82,7 +82,7 @@ __device__ __forceinline__ RowFrag search_first_descent(const TreeView& tv, cons
 }
 
 __device__ __forceinline__ RowFrag search_backup_descent(const TreeView& tv, const hz_mlp_header_t& H, const SearchArgs& a,
-                                                         const SearchLds& L, int row0, int tree, int lane, int wave, int sim,
+                                                         const SearchLds& L, int row0, int tree, int lane, int srow, int sim,
                                                          bool more, TreeLocal& tl, float4& root_row) {
   const TraverseOut to = search_traverse_out(H, a, L, row0);
   NetOut no;
@@ -93,15 +93,15 @@ __device__ __forceinline__ RowFrag search_backup_descent(const TreeView& tv, con
   // the leaf's heads, straight from the row image the inference left behind (the arithmetic of the stand-alone kernel's
   // final stage): lanes 0-31 turn the reward logits into a scalar, lanes 32-63 the value logits; lane a takes policy logit a
   {
-    const uint16_t* row = L.image + (size_t)wave * H.row_stride;
+    const uint16_t* row = L.image + (size_t)srow * H.row_stride;
     const float x = row32_support_to_scalar(row + ((lane >> 5) ? H.off_value : H.off_reward), H.support_size,
                                             H.support_min, lane & 31);
-    if (lane == 0) L.rew_s[wave] = x;
-    if (lane == 32) L.val_s[wave] = x;
+    if (lane == 0) L.rew_s[srow] = x;
+    if (lane == 32) L.val_s[srow] = x;
     if (lane < tv.A) {
       float pl = bf2f(row[H.off_policy + lane]);
       if (pl != pl) pl = 0.0f;  // core/mcts.py:48-49
-      L.pol_s[wave * tv.A + lane] = pl;
+      L.pol_s[srow * tv.A + lane] = pl;
     }
   }
   float mn, mx;
@@ -110,7 +110,7 @@ __device__ __forceinline__ RowFrag search_backup_descent(const TreeView& tv, con
   TP_ON(1);
   TP(0);
   tl.publish = !more;  // the last backup's root sums and min / max are the ones the read-outs see
-  backprop_body<false, true>(tv, tree, lane, wave, L.lds_q, sim + 1, no, mn, mx, rv, first, a0, &tl);
+  backprop_body<false, true>(tv, tree, lane, srow, L.lds_q, sim + 1, no, mn, mx, rv, first, a0, &tl);
   RowFrag f;
   f.v[0] = f.v[1] = make_uint4(0u, 0u, 0u, 0u);
   if (lane == a0) root_row = first;  // the one record of the root's row this backup changed
@@ -126,9 +126,10 @@ __device__ __forceinline__ RowFrag search_backup_descent(const TreeView& tv, con
   return f;
 }
 
+template <int RT>
 __device__ __forceinline__ void search_inference(const hz_mlp_header_t& H, const SearchArgs& a, const SearchLds& L, int sim,
-                                                 int n_rows, int row0, const RowFrag& rows) {
-  mlp_body<1, 16, 2, STAGE_REGS, false>(H, a.jobs, a.wstream, a.bias, a.act_tab, a.pool, a.row_stride, nullptr, a.plane_stride,
+                                                 int n_rows, int row0, const RowFrag* rows) {
+  mlp_body<RT, 16, 2, STAGE_REGS, false>(H, a.jobs, a.wstream, a.bias, a.act_tab, a.pool, a.row_stride, nullptr, a.plane_stride,
                                  L.act_s - row0, a.pool + (size_t)(sim + 1) * a.plane_stride, L.rew_s - row0,
                                  L.val_s - row0, L.pol_s - (size_t)row0 * H.num_actions, n_rows, L.image, row0, rows);
 }
@@ -144,61 +145,86 @@ extern "C" int hz_search_profile_read(unsigned long long* host) {
 #define SP_NOW() 0ull
 #endif
 
+// RT = 16-row tiles per workgroup: 1 = one tree per wave (a workgroup per CU covers 4096 trees on 256 CUs); 2 = two trees
+// per wave, taken one after the other in the tree phases, and 32 rows per weight fragment in the inference -- for more
+// trees than 16 x #CUs, where the workgroups would otherwise queue and stream the weights once per 16 rows.
+template <int RT>
 __global__ __launch_bounds__(1024, 1) void k_search(TreeView tv, hz_mlp_header_t H, SearchArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+  constexpr int MT = 16 * RT;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int row0 = blockIdx.x * 16;
-  const int tree = row0 + wave;
-#ifdef HZ_SEARCH_X_HALFTREES  // experiment: only 8 of the 16 waves do tree work (is the tree phase issue-bound?)
-  const bool mine = tree < tv.N && wave < 8;
-#else
-  const bool mine = tree < tv.N;
-#endif
+  const int row0 = blockIdx.x * MT;
   SearchLds L;
   L.image = lds;
-  L.exp_s = reinterpret_cast<uint64_t*>(lds + (size_t)16 * H.row_stride);  // (row_stride % 8 == 0: 16-B aligned)
+  L.exp_s = reinterpret_cast<uint64_t*>(lds + (size_t)MT * H.row_stride);  // (row_stride % 8 == 0: 16-B aligned)
   L.prec_s = reinterpret_cast<float4*>(L.exp_s + 32);
-  L.path_s = reinterpret_cast<int32_t*>(L.prec_s + 16 * (tv.S + 1));
-  L.lds_q = reinterpret_cast<float*>(L.path_s + 16 * (tv.S + 1));
-  L.act_s = reinterpret_cast<int32_t*>(L.lds_q + 16 * tv.S);
+  L.path_s = reinterpret_cast<int32_t*>(L.prec_s + MT * (tv.S + 1));
+  L.lds_q = reinterpret_cast<float*>(L.path_s + MT * (tv.S + 1));
+  L.act_s = reinterpret_cast<int32_t*>(L.lds_q + MT * tv.S);
+  L.rew_s = reinterpret_cast<float*>(L.act_s + MT);
+  L.val_s = L.rew_s + MT;
+  L.pol_s = L.val_s + MT;
   if (threadIdx.x < 32) L.exp_s[threadIdx.x] = hz_exp2f_tab[threadIdx.x];
-  TreeLocal tl;
-  tl.exp_tab = L.exp_s;
-  tl.pbc_reg = (tv.S < 64 && lane <= tv.S) ? tv.pbc_tab[lane] : 0.0f;
-  tl.sqrt_reg = sqrtf((float)lane + 1.0f);
+  TreeLocal tl[RT];
+  bool mine[RT];
+  RowFrag rows[RT];
+  float4 root_row[RT];
+#pragma unroll
+  for (int s = 0; s < RT; ++s) {
+    const int srow = 16 * s + wave;
+#ifdef HZ_SEARCH_X_HALFTREES  // experiment: only 8 of the 16 waves do tree work (is the tree phase issue-bound?)
+    mine[s] = row0 + srow < tv.N && wave < 8;
+#else
+    mine[s] = row0 + srow < tv.N;
+#endif
+    tl[s].exp_tab = L.exp_s;
+    tl[s].pbc_reg = (tv.S < 64 && lane <= tv.S) ? tv.pbc_tab[lane] : 0.0f;
+    tl[s].sqrt_reg = sqrtf((float)lane + 1.0f);
+    tl[s].path = L.path_s + srow * (tv.S + 1);
+    tl[s].prec = L.prec_s + srow * (tv.S + 1);
+    tl[s].root_vsum = 0.0f; tl[s].root_visit = 0; tl[s].path_len = 0; tl[s].publish = false;
+    rows[s].v[0] = rows[s].v[1] = make_uint4(0u, 0u, 0u, 0u);
+    root_row[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   __syncthreads();
-  tl.path = L.path_s + wave * (tv.S + 1);
-  tl.prec = L.prec_s + wave * (tv.S + 1);
-  tl.root_vsum = 0.0f; tl.root_visit = 0; tl.path_len = 0;
-  L.rew_s = reinterpret_cast<float*>(L.act_s + 16);
-  L.val_s = L.rew_s + 16;
-  L.pol_s = L.val_s + 16;
   unsigned long long p_tree = 0, p_wait1 = 0, p_mlp = 0, p_wait2 = 0;
   (void)p_tree; (void)p_wait1; (void)p_mlp; (void)p_wait2;
   unsigned long long t0 = SP_NOW();
-  RowFrag rows;
-  rows.v[0] = rows.v[1] = make_uint4(0u, 0u, 0u, 0u);
-  float4 root_row = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (mine) rows = search_first_descent(tv, H, a, L, row0, tree, lane, tl, root_row);
+#pragma unroll
+  for (int s = 0; s < RT; ++s)
+    if (mine[s]) rows[s] = search_first_descent(tv, H, a, L, row0, row0 + 16 * s + wave, lane, tl[s], root_row[s]);
   for (int sim = 0; sim < a.sims; ++sim) {
     unsigned long long t1 = SP_NOW();
     // (no barrier here: the inference's own barrier after staging orders the waves' rows and actions)
     unsigned long long t2 = SP_NOW();
-    search_inference(H, a, L, sim, tv.N, row0, rows);
+    search_inference<RT>(H, a, L, sim, tv.N, row0, rows);
     unsigned long long t3 = SP_NOW();
     __syncthreads();  // leaf outputs visible; the row image is free again
     unsigned long long t4 = SP_NOW();
-    if (mine) rows = search_backup_descent(tv, H, a, L, row0, tree, lane, wave, sim, sim + 1 < a.sims, tl, root_row);
+#pragma unroll
+    for (int s = 0; s < RT; ++s)
+      if (mine[s])
+        rows[s] = search_backup_descent(tv, H, a, L, row0, row0 + 16 * s + wave, lane, 16 * s + wave, sim, sim + 1 < a.sims,
+                                        tl[s], root_row[s]);
     p_tree += t1 - t0; p_wait1 += t2 - t1; p_mlp += t3 - t2; p_wait2 += t4 - t3;
     t0 = t4;
   }
 #ifdef HZ_SEARCH_PROFILE
-  if (blockIdx.x == 100 && lane == 0) {
+  if (blockIdx.x == 100 / RT && lane == 0) {
     unsigned long long* o = hz_search_prof + wave * 4;
     o[0] = p_tree + (SP_NOW() - t0); o[1] = p_wait1; o[2] = p_mlp; o[3] = p_wait2;
   }
 #endif
+}
+
+// 0 = choose by the tree count (two trees per wave once one per wave would need more workgroups than the device has
+// compute units), 16 / 32 = force (tests, tools)
+static int g_search_rows_per_workgroup = 0;
+extern "C" int hz_search_set_rows_per_workgroup(int rows) {
+  HZ_REQUIRE(rows == 0 || rows == 16 || rows == 32, "hz_search_set_rows_per_workgroup: %d (0 = auto, 16 or 32)", rows);
+  g_search_rows_per_workgroup = rows;
+  return 0;
 }
 
 extern "C" int hz_search_run(hz_tree_t* t, int num_simulations, const hz_mlp_header_t* H, const hz_mlp_job_t* jobs,
@@ -229,19 +255,37 @@ extern "C" int hz_search_run(hz_tree_t* t, int num_simulations, const hz_mlp_hea
              "hz_search_run: kstep_stride must be a multiple of 8 and at least one k-step (512 * tiles_per_wave)");
   HZ_REQUIRE(H->in_width > 0 && H->in_width % 8 == 0, "hz_search_run: in_width must be a positive multiple of 8");
   HZ_REQUIRE(H->in_width == H->hidden && H->hidden <= 1024, "hz_search_run: the recurrent inference maps a hidden state (<= 1024 wide) to a hidden state");
-  const size_t lds_bytes = (size_t)16 * H->row_stride * sizeof(uint16_t) + (size_t)16 * (t->S + 1) * (16 + 4) +
-                           (size_t)16 * t->S * sizeof(float) + (size_t)(16 * 3 + 16 * t->A + 2) * sizeof(float) + 32 * 8 + 256;  // (+256: slack behind the last array)
+  int rows_wg = g_search_rows_per_workgroup;
+  if (rows_wg == 0) {
+    static int n_cu = 0;
+    if (n_cu == 0) {
+      int dev = 0;
+      HZ_HIP(hipGetDevice(&dev));
+      HZ_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    rows_wg = (t->N + 15) / 16 > n_cu ? 32 : 16;
+  }
+  auto lds_for = [&](int mt) {
+    return (size_t)mt * H->row_stride * sizeof(uint16_t) + (size_t)mt * (t->S + 1) * (16 + 4) + (size_t)mt * t->S * sizeof(float) +
+           (size_t)(mt * 3 + mt * t->A + 2) * sizeof(float) + 32 * 8 + 256;  // (+256: slack behind the last array)
+  };
+  if (rows_wg == 32 && lds_for(32) > 160 * 1024 && g_search_rows_per_workgroup == 0) rows_wg = 16;
+  const size_t lds_bytes = lds_for(rows_wg);
   HZ_REQUIRE(lds_bytes <= 160 * 1024, "hz_search_run: %zu B of LDS per workgroup exceed 160 KiB", lds_bytes);
-  static size_t configured = 0;
-  if (lds_bytes > configured) {
-    HZ_HIP(hipFuncSetAttribute((const void*)k_search, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    configured = lds_bytes;
+  static size_t configured[2] = {0, 0};
+  const void* fn = rows_wg == 32 ? (const void*)k_search<2> : (const void*)k_search<1>;
+  if (lds_bytes > configured[rows_wg == 32]) {
+    HZ_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    configured[rows_wg == 32] = lds_bytes;
   }
   SearchArgs a;
   a.jobs = jobs; a.wstream = (const uint16_t*)wstream; a.bias = biases; a.act_tab = action_table;
   a.pool = (uint16_t*)pool; a.plane_stride = plane_stride; a.row_stride = row_stride;
   a.ix = ix; a.iy = iy; a.la = la; a.rew = rewards; a.val = values; a.pol = policy; a.sims = num_simulations;
-  hipLaunchKernelGGL(k_search, dim3((t->N + 15) / 16), dim3(1024), lds_bytes, (hipStream_t)stream, view(t), *H, a);
+  if (rows_wg == 32)
+    hipLaunchKernelGGL(k_search<2>, dim3((t->N + 31) / 32), dim3(1024), lds_bytes, (hipStream_t)stream, view(t), *H, a);
+  else
+    hipLaunchKernelGGL(k_search<1>, dim3((t->N + 15) / 16), dim3(1024), lds_bytes, (hipStream_t)stream, view(t), *H, a);
   HZ_HIP(hipGetLastError());
   t->next_entry = num_simulations + 1;
   return 0;

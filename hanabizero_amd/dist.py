@@ -13,6 +13,13 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+_SHORT_CIRCUIT = True  # tests clear this to drive the collectives themselves through a one-rank "nccl" group on one GPU
+
+
+def _alone(group):
+    return not dist.is_initialized() or (_SHORT_CIRCUIT and dist.get_world_size(group) == 1)
+
+
 _FIELDS = ("action", "reward", "value", "visits", "legal", "obs", "meta")
 
 
@@ -31,7 +38,7 @@ def gather_records(rec, dst=0, group=None, device=None):
     Two collectives per call whatever the number of fields: an all_gather of the ranks' array shapes (every rank trims its
     records to its own longest finished game, so the time extents differ) and one gather of a byte buffer holding all
     seven arrays padded to the element-wise maximum shape."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if _alone(group):
         return rec
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     backend = dist.get_backend(group)
@@ -104,7 +111,7 @@ def gather_packed(packed, A, W, dst=0, group=None):
     copy; the buffers are reused by the next call -- elsewhere None.  Works without a process group (world 1)."""
     from .selfplay import packed_layout
     n, tmax = (0, 0) if packed is None else (int(packed[1]), int(packed[2]))
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if _alone(group):
         if not n:
             return []
         host = _pinned_bytes(("r", 0), packed[0].numel())
@@ -142,7 +149,7 @@ def gather_packed(packed, A, W, dst=0, group=None):
 
 def broadcast_weights(state_dict, src=0, group=None, device=None):
     """Broadcast a model state_dict from `src` in place (tensors are moved to `device` for nccl)."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if _alone(group):
         return state_dict
     backend = dist.get_backend(group)
     device = torch.device(device) if device is not None else (

@@ -622,27 +622,35 @@ class FusedRecurrent(_FusedChain):
         wh = torch.cat([_fold(rw[0], rw[1])[0], _fold(ac[0], ac[1])[0], _fold(va[0], va[1])[0]], 0)
         bh = torch.cat([_fold(rw[0], rw[1])[1], _fold(ac[0], ac[1])[1], _fold(va[0], va[1])[1]], 0)
         if full:   # NewDynamicNet + 3-layer heads (config/hanabi_control/model.py:93-125, 250-269)
-            Z = 3 * H
+            # Row image, 3 H wide (every region is reused as soon as its contents are dead, so that 32 rows of it and
+            # the 32 trees' search state fit the 160 KiB of a workgroup -- hz_search.hip):
+            #   [0, H) X state | [H, 2H) Y1 | [2H, 3H) Y0 = the next hidden state;  the heads' first layer (3 h wide)
+            #   lands on X and the lower half of Y1, their second layers behind it (upper Y1, Y0), the third layers back
+            #   on the first layer's thirds (the actor's in place over its own residual), the policy logits on the
+            #   reward head's dead second layer.
+            assert 3 * h <= 2 * H
+            Y1, Y0 = H, 2 * H
+            Z = X
             add_dense(w1s, b1, H, X, Y0, relu=True, barrier=False, act_w=w1a)
             add_dense(w2, b2, H, Y0, Y1, relu=True)
             add_dense(w3, b3, H, Y1, Y0, relu=True, res_off=X)
             add_dense(wh, bh, H, Y0, Z, relu=True, store_hidden=True)
-            Tr, Ta, Tv = X, X + h, Y1                       # X and Y1 are dead: second head layers land there
+            Tr, Ta, Tv = Z + 3 * h, Z + 4 * h, Z + 5 * h
             heads2 = [(_fold(rw[3], rw[4]), Z, Tr), (_fold(ac[3].fc1, ac[3].bn1), Z + h, Ta), (_fold(va[3], va[4]), Z + 2 * h, Tv)]
             first = True
             for (w, b), src, dst in heads2:
                 add_dense(w, b, h, src, dst, relu=True, barrier=first)
                 first = False
-            R3, U, V3 = Y1 + h, Y0, Y0 + h                  # reward logits | actor hidden | value logits
+            R3, U, V3 = Z, Z + h, Z + 2 * h                 # reward logits | actor hidden | value logits
             wr3, br3 = _fold(rw[6])
             wa3, ba3 = _fold(ac[3].fc2, ac[3].bn2)
             wv3, bv3 = _fold(va[6])
             add_dense(wr3, br3, h, Tr, R3, relu=False, barrier=True)
-            add_dense(wa3, ba3, h, Ta, U, relu=True, res_off=Z + h, barrier=False)
-            add_dense(wv3, bv3, h, Tv, V3, relu=False, barrier=False)
+            add_dense(wa3, ba3, h, Ta, U, relu=True, res_off=Z + h, barrier=False)  # (in place: a lane reads the residual
+            add_dense(wv3, bv3, h, Tv, V3, relu=False, barrier=False)               #  element it then overwrites)
             wp4, bp4 = _fold(ac[4])
-            add_dense(wp4, bp4, h, U, Z, relu=False, barrier=True)
-            off_r, off_v, off_p, width = R3, V3, Z, Z + 3 * h
+            add_dense(wp4, bp4, h, U, Tr, relu=False, barrier=True)
+            off_r, off_v, off_p, width = R3, V3, Tr, max(3 * H, Z + 6 * h)
         else:      # DynamicNet + 2-layer heads (model.py:61-91, 138-149)
             Z = Y1
             add_dense(w1s, b1, H, X, Y0, relu=True, res_off=X, barrier=False, act_w=w1a)

@@ -5,7 +5,8 @@
  * (core/model.py:74-84) and multi_back_propagate (cytree.pyx:87-94) -- for all trees, as ONE kernel launch per move.
  * A workgroup owns 16 trees for the whole search: one wavefront per tree for descent / expand / backup (the code of
  * hz_tree_traverse / hz_tree_backprop), all 16 wavefronts together for the fused MFMA inference of those 16 rows (the
- * code of hz_mlp_recurrent, 16 waves x 2 tiles).  Results are bit-identical to the launch-per-phase path
+ * code of hz_mlp_recurrent, 16 waves x 2 tiles).  With more trees than 16 per compute unit of the device a workgroup owns
+ * 32 (two per wavefront, searched one after the other between inferences of 32 rows per weight fragment).  Results are bit-identical to the launch-per-phase path
  * (hz_tree_traverse -> hz_mlp_recurrent -> hz_tree_backprop_traverse ...): same arithmetic, same order.
  * Conventions as include/hz_tree.h.
  */
@@ -32,6 +33,10 @@ int hz_search_run(hz_tree_t* t, int num_simulations, const hz_mlp_header_t* H, c
                   const void* wstream, const float* biases, const float* action_table, void* pool,
                   int64_t plane_stride, int64_t row_stride, int32_t* ix, int32_t* iy, int32_t* la, float* rewards,
                   float* values, float* policy, void* stream);
+
+/* Trees per workgroup of the following hz_search_run calls of this process: 0 = chosen from the tree count (default),
+ * 16 or 32 = forced (tests, measurements).  The results do not depend on it. */
+int hz_search_set_rows_per_workgroup(int rows);
 
 #ifdef __cplusplus
 }

@@ -3,6 +3,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -78,11 +79,16 @@ def _worker(rank, world, port, counts, q):
     dist.destroy_process_group()
 
 
-def test_gather_and_broadcast_world2_gloo():
+def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
+    return port
+
+
+def test_gather_and_broadcast_world2_gloo():
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     counts = [(3, 5), (0, 2), (4, 0), (0, 0)]
@@ -93,3 +99,46 @@ def test_gather_and_broadcast_world2_gloo():
     for p in procs:
         p.join(60)
     assert res == [(0, True), (1, True)]
+
+
+@pytest.mark.gpu
+def test_collectives_over_rccl_one_rank():
+    """The same three exchange steps through the "nccl" (= RCCL) backend with device tensors: one rank on the one GPU of
+    the test box (RCCL refuses two ranks on one device), with the single-rank short cut switched off so that
+    all_gather / gather / broadcast really go through the RCCL communicator -- tensor placement, dtypes and call
+    signatures are what differs from gloo."""
+    import hanabizero_amd.dist as hd
+    from hanabizero_amd.selfplay import packed_layout, unpack_packed
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(device)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+    hd._SHORT_CIRCUIT = False
+    try:
+        dist.barrier()
+        rec = _fake_rec(5, 3, T=7)
+        got = hd.gather_records(rec, dst=0)
+        for k in rec:
+            assert got[k].dtype == rec[k].dtype and (got[k] == rec[k]).all(), k
+        assert hd.gather_records(None, dst=0) is None
+        A, W = 11, 7
+        layout, total = packed_layout(5, 7, A, W)
+        buf = np.zeros(total, np.uint8)
+        for k, shp, dt, off in layout:
+            raw = np.ascontiguousarray(rec[k]).view(np.uint8).reshape(-1)
+            buf[off:off + raw.size] = raw
+        out = hd.gather_packed((torch.from_numpy(buf).to(device), 5, 7), A, W, dst=0)
+        assert len(out) == 1 and out[0][1:] == (5, 7)
+        view = unpack_packed(out[0][0], 5, 7, A, W)
+        for k in rec:
+            assert (view[k] == rec[k]).all(), k
+        assert hd.gather_packed(None, A, W, dst=0) == []
+        sd = {"w": torch.arange(6.0).reshape(2, 3), "b": torch.ones(3, dtype=torch.bfloat16)}
+        bw = hd.broadcast_weights(sd, src=0)
+        assert bw["w"].is_cuda and (bw["w"].cpu() == sd["w"]).all() and bw["b"].dtype == torch.bfloat16
+        t = torch.tensor([1.5], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)  # bench.py's max-over-ranks of the elapsed time
+        assert float(t.item()) == 1.5
+    finally:
+        hd._SHORT_CIRCUIT = True
+        dist.destroy_process_group()

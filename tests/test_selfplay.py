@@ -191,6 +191,7 @@ def test_persistent_search_kernel_equals_launch_per_phase(game, N, sims):
     search (hz_tree_traverse -> hz_mlp_recurrent -> hz_tree_backprop_traverse ...): bit-identical trees, hidden-state
     pools and leaf outputs; the launch-per-phase path itself is pinned to the oracle by the tests above."""
     from hanabizero_amd import cytree
+    from hanabizero_amd._lib import check, lib
     from hanabizero_amd.mcts import MCTS
     cfg, eng, actor = make(game, N, sims, 2, torch.bfloat16, use_graph=False)
     A = cfg.action_space_size
@@ -199,18 +200,21 @@ def test_persistent_search_kernel_equals_launch_per_phase(game, N, sims):
     noise = torch.rand(N, A, device="cuda", generator=g)
     noise = noise / noise.sum(1, keepdim=True)
     res = []
-    for persistent in (False, True):
+    for persistent in (False, 16, 32):  # launch per phase; one / two trees per wavefront of the persistent kernel
+        check(lib.hz_search_set_rows_per_workgroup(int(persistent)), "hz_search_set_rows_per_workgroup")
         roots = cytree.Roots(N, A, sims, tie_seed=5, tree_id_base=17)
         roots.prepare(cfg.root_exploration_fraction, noise, torch.zeros(N, device="cuda"), logits0, actor.legal)
         pool = torch.zeros(sims, N, eng.H, dtype=eng.dtype, device="cuda")
-        MCTS(cfg, persistent=persistent).run_multi(roots, eng, hidden0, pool=pool)
+        MCTS(cfg, persistent=bool(persistent)).run_multi(roots, eng, hidden0, pool=pool)
         torch.cuda.synchronize()
         res.append((roots.distributions_tensor(), roots.values_tensor(), roots.trajectories_tensor(),
                     roots.minmax_tensors(), roots.path_len_tensor(), pool))
-    a, b = res
-    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[4], b[4])
-    assert torch.equal(a[3][0], b[3][0]) and torch.equal(a[3][1], b[3][1])
-    assert torch.equal(a[5], b[5])
+    check(lib.hz_search_set_rows_per_workgroup(0), "hz_search_set_rows_per_workgroup")
+    a = res[0]
+    for b in res[1:]:
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[4], b[4])
+        assert torch.equal(a[3][0], b[3][0]) and torch.equal(a[3][1], b[3][1])
+        assert torch.equal(a[5], b[5])
     assert int(a[0].sum()) == N * (sims - 1)
 
 
