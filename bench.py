@@ -258,7 +258,7 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from hanabizero_amd.config import make_config
-    from hanabizero_amd.dist import gather_packed
+    from hanabizero_amd.dist import gather_packed, reserve_landing
     from hanabizero_amd.selfplay import SelfPlayActor, packed_layout
 
     game, N, S, stack = WORKLOADS[args.workload]
@@ -290,6 +290,8 @@ def main():
             dist.barrier()
 
     games, rec_bytes = 0, 0
+    if rank == 0:  # the replay owner's pinned landing buffers (about 4.5 KB per finished Hanabi-Full game)
+        reserve_landing(16384 * N, world)
 
     flush_s = 0.0
 
@@ -302,9 +304,9 @@ def main():
         for a in actors:
             got = gather_packed(a.drain_packed(), a.A, a.W, dst=0)
             if rank == 0 and got:
-                for buf, n, tmax in got:
+                for buf, n, moves in got:
                     games += n
-                    rec_bytes += packed_layout(n, tmax, a.A, a.W)[1]
+                    rec_bytes += packed_layout(n, moves, a.A, a.W)[1]
         flush_s += time.perf_counter() - tf0
 
     if not args.no_graph:  # capture (2 eager lock-steps + the capture itself) is set-up, whatever --warmup says

@@ -80,6 +80,7 @@ def _load():
         "hz_actor_record_search": [C.POINTER(ActorBufs), V, V, V, V, F, I, V, V, V],
         "hz_actor_record_step": [C.POINTER(ActorBufs), V, V, V, V, V, V, V],
         "hz_actor_flush": [C.POINTER(ActorBufs), V],
+        "hz_actor_pack": [C.POINTER(ActorBufs), I64, I, I64, V, V, I64, V],
         "hz_actor_begin_move": [C.POINTER(ActorBufs), V, V, V, V, I64, V, I64, I, I64, V],
         # include/hz_mlp.h
         "hz_mlp_recurrent": [C.POINTER(MlpHeader), V, V, V, V, V, I64, V, I64, V, V, V, V, V, I, I, V],
@@ -95,6 +96,8 @@ def _load():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = I
+    lib.hz_actor_packed_bytes.argtypes = [I, I64, I, I, V]
+    lib.hz_actor_packed_bytes.restype = I64
     lib.hz_tree_hbm_bytes.argtypes = [V]
     lib.hz_tree_hbm_bytes.restype = I64
     lib.hz_env_hbm_bytes.argtypes = [V]

@@ -228,8 +228,12 @@ __global__ __launch_bounds__(256) void k_actor_record_step(hz_actor_bufs_t b, co
 __global__ __launch_bounds__(1024) void k_actor_slots(hz_actor_bufs_t b, const uint8_t* __restrict__ done) {
   __shared__ int wave_total[16];
   __shared__ long long base_s;
+  __shared__ int moves_s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) base_s = *b.out_count;
+  if (tid == 0) {
+    base_s = *b.out_count;
+    moves_s = 0;
+  }
   __syncthreads();
   long long base = base_s;
   for (int start = 0; start < b.num_envs; start += 1024) {
@@ -246,12 +250,16 @@ __global__ __launch_bounds__(1024) void k_actor_slots(hz_actor_bufs_t b, const u
       tot += c;
     }
     if (env < b.num_envs) b.slot[env] = d ? (int32_t)((base + off + before) % (long long)b.outbox_games) : -1;
-    if (d) b.finished[(int)(base - base_s) + off + before] = env;
+    if (d) {
+      b.finished[(int)(base - base_s) + off + before] = env;
+      atomicAdd(&moves_s, b.meta[(size_t)env * 4]);  // its length (k_actor_record_step has just written the meta row)
+    }
     base += tot;
     __syncthreads();
   }
   if (tid == 0) {
-    *b.out_count = base;
+    b.out_count[0] = base;
+    b.out_count[1] += moves_s;
     *b.num_finished = (int)(base - base_s);
   }
 }
@@ -298,6 +306,61 @@ __global__ __launch_bounds__(256) void k_actor_flush(FlushTable ft, const int32_
     const int s = slot[row];
     if (s < 0) continue;
     copy_row_block(ft.src[k] + (size_t)row * (size_t)rb, ft.dst[k] + (size_t)s * (size_t)rb, rb, threadIdx.x, blockDim.x);
+  }
+}
+
+// Outbox ring rows [first, first + n) -> one packed byte buffer of seven sections, the games back to back (ragged: game j
+// owns len_j rows of the per-move sections and len_j + 1 rows of the observation / legal-mask sections).
+// k_actor_pack_starts: exclusive prefix sums of the games' lengths, one workgroup.
+__global__ __launch_bounds__(1024) void k_actor_pack_starts(const int32_t* __restrict__ out_meta, long long first, int n, int cap,
+                                                           int32_t* __restrict__ starts) {
+  __shared__ int wave_total[16];
+  __shared__ int base_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) base_s = 0;
+  __syncthreads();
+  for (int j0 = 0; j0 < n; j0 += 1024) {
+    const int j = j0 + tid;
+    const int len = j < n ? out_meta[(size_t)((first + j) % (long long)cap) * 4] : 0;
+    int incl = len;  // inclusive scan inside the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int up = __shfl_up(incl, d);
+      if (lane >= d) incl += up;
+    }
+    if (lane == 63) wave_total[wave] = incl;
+    __syncthreads();
+    int off = base_s;
+    for (int w = 0; w < wave; ++w) off += wave_total[w];
+    if (j < n) starts[j] = off + incl - len;
+    __syncthreads();
+    if (tid == 1023) base_s = off + incl;
+    __syncthreads();
+  }
+  if (tid == 0) starts[n] = base_s;  // total moves
+}
+
+struct PackTable {
+  const uint8_t* src[7];
+  long long src_row_bytes[7];  // a ring row
+  long long unit_bytes[7];     // bytes per move (per game for the meta section)
+  long long dst_off[7];        // section start in the packed buffer
+  int extra[7];                // rows beyond the game's length (1 for observations and legal masks)
+};
+
+__global__ __launch_bounds__(256) void k_actor_pack(PackTable pt, const int32_t* __restrict__ out_meta,
+                                                    const int32_t* __restrict__ starts, long long first, int n, int cap,
+                                                    int moves, uint8_t* __restrict__ out) {
+  const int k = blockIdx.y;
+  for (int j = blockIdx.x; j < n; j += gridDim.x) {
+    const long long row = (first + j) % (long long)cap;
+    const int len = out_meta[(size_t)row * 4], st = starts[j];
+    if (len < 0 || st < 0 || st + len > moves) continue;  // (the caller's total does not cover this game: never the case)
+    const long long rows_before = k == 0 ? j : (long long)st + (pt.extra[k] ? j : 0);
+    const long long nrows = k == 0 ? 1 : len + pt.extra[k];
+    copy_row_block(pt.src[k] + (size_t)row * (size_t)pt.src_row_bytes[k],
+                   out + pt.dst_off[k] + (size_t)rows_before * (size_t)pt.unit_bytes[k], nrows * pt.unit_bytes[k], threadIdx.x,
+                   blockDim.x);
   }
 }
 
@@ -388,6 +451,52 @@ extern "C" int hz_actor_flush(const hz_actor_bufs_t* bufs, void* stream) {
   const int gx = bufs->num_envs < 256 ? bufs->num_envs : 256;
   hipLaunchKernelGGL(k_actor_flush, dim3(gx, 7), dim3(256), 0, (hipStream_t)stream, ft, bufs->slot, bufs->finished,
                      bufs->num_finished);
+  HZ_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int64_t hz_actor_packed_bytes(int n, int64_t moves, int num_actions, int packed_words, int64_t* offsets) {
+  if (n < 0 || moves < 0 || num_actions <= 0 || packed_words <= 0) return -1;
+  const long long A = num_actions, W = packed_words, m = moves, g = n;
+  // meta action reward value visits legal obs
+  const long long bytes[7] = {16 * g, m, m, 4 * m, 2 * m * A, (m + g) * A, 4 * (m + g) * W};
+  long long off = 0;
+  for (int k = 0; k < 7; ++k) {
+    if (offsets) offsets[k] = off;
+    off += (bytes[k] + 15) / 16 * 16;
+  }
+  return off;
+}
+
+extern "C" int hz_actor_pack(const hz_actor_bufs_t* bufs, int64_t first, int n, int64_t moves, int32_t* starts, void* out,
+                             int64_t out_bytes, void* stream) {
+  HZ_ACTOR_CHECK(bufs, "hz_actor_pack");
+  HZ_REQUIRE(bufs->out_action && bufs->out_reward && bufs->out_value && bufs->out_visits && bufs->out_legal &&
+                 bufs->out_obs && bufs->out_meta && out && starts, "hz_actor_pack: NULL outbox array");
+  HZ_REQUIRE(first >= 0 && n >= 1 && n <= bufs->outbox_games && moves >= n && moves <= (int64_t)n * bufs->max_moves,
+             "hz_actor_pack: first=%lld n=%d moves=%lld outside the outbox (capacity %d, %d moves per game)",
+             (long long)first, n, (long long)moves, bufs->outbox_games, bufs->max_moves);
+  int64_t offs[7];
+  const int64_t total = hz_actor_packed_bytes(n, moves, bufs->num_actions, bufs->packed_words, offs);
+  HZ_REQUIRE(out_bytes >= total, "hz_actor_pack: %lld B buffer, %lld B needed", (long long)out_bytes, (long long)total);
+  const long long A = bufs->num_actions, W = bufs->packed_words, T = bufs->max_moves;
+  PackTable pt;
+  const void* src[7] = {bufs->out_meta, bufs->out_action, bufs->out_reward, bufs->out_value, bufs->out_visits, bufs->out_legal,
+                        bufs->out_obs};
+  const long long srb[7] = {16, T, T, 4 * T, 2 * T * A, (T + 1) * A, 4 * (T + 1) * W};
+  const long long unit[7] = {16, 1, 1, 4, 2 * A, A, 4 * W};
+  for (int k = 0; k < 7; ++k) {
+    pt.src[k] = (const uint8_t*)src[k];
+    pt.src_row_bytes[k] = srb[k];
+    pt.unit_bytes[k] = unit[k];
+    pt.dst_off[k] = offs[k];
+    pt.extra[k] = k >= 5;
+  }
+  hipLaunchKernelGGL(k_actor_pack_starts, dim3(1), dim3(1024), 0, (hipStream_t)stream, bufs->out_meta, (long long)first, n,
+                     bufs->outbox_games, starts);
+  // (the alignment padding between sections is never read by unpack; it keeps whatever the buffer held)
+  hipLaunchKernelGGL(k_actor_pack, dim3(n < 8192 ? n : 8192, 7), dim3(256), 0, (hipStream_t)stream, pt, bufs->out_meta, starts,
+                     (long long)first, n, bufs->outbox_games, (int)moves, (uint8_t*)out);
   HZ_HIP(hipGetLastError());
   return 0;
 }

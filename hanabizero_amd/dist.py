@@ -97,31 +97,38 @@ _pinned = {}
 
 def _pinned_bytes(key, nbytes):
     buf = _pinned.get(key)
-    if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, pin_memory=torch.cuda.is_available())
+    if buf is None or buf.numel() < nbytes:  # grows geometrically: pinning host memory costs milliseconds
+        size = max(int(nbytes), 1, 2 * (buf.numel() if buf is not None else 0))
+        buf = torch.zeros(size, dtype=torch.uint8, pin_memory=torch.cuda.is_available())  # (zeros: touch every page now)
         _pinned[key] = buf
     return buf[:nbytes]
 
 
+def reserve_landing(nbytes, ranks=1):
+    """Pin the replay owner's landing buffers (one per sending rank) ahead of time, so that no drain has to."""
+    for r in range(ranks):
+        _pinned_bytes(("r", r), int(nbytes))
+
+
 def gather_packed(packed, A, W, dst=0, group=None):
-    """The device-resident form of gather_records: `packed` = SelfPlayActor.drain_packed() (uint8 device tensor, n, tmax)
-    or None.  Two collectives: all_gather of (n, tmax), one gather of the byte buffers (padded to the longest; device to
+    """The device-resident form of gather_records: `packed` = SelfPlayActor.drain_packed() (uint8 device tensor, n games, their total moves)
+    or None.  Two collectives: all_gather of (n, moves), one gather of the byte buffers (padded to the longest; device to
     device over xGMI under "nccl": the sending ranks never copy their records to the host).  Returns on `dst` a list of
-    (host uint8 numpy buffer in pinned memory, n, tmax) per rank with games -- `unpack_packed` views them without a
+    (host uint8 numpy buffer in pinned memory, n, moves) per rank with games -- `unpack_packed` views them without a
     copy; the buffers are reused by the next call -- elsewhere None.  Works without a process group (world 1)."""
     from .selfplay import packed_layout
-    n, tmax = (0, 0) if packed is None else (int(packed[1]), int(packed[2]))
+    n, moves = (0, 0) if packed is None else (int(packed[1]), int(packed[2]))
     if _alone(group):
         if not n:
             return []
         host = _pinned_bytes(("r", 0), packed[0].numel())
         host.copy_(packed[0], non_blocking=True)
         torch.cuda.synchronize() if packed[0].is_cuda else None
-        return [(host.numpy(), n, tmax)]
+        return [(host.numpy(), n, moves)]
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     backend = dist.get_backend(group)
     device = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
-    mine = torch.tensor([n, tmax], dtype=torch.int64, device=device)
+    mine = torch.tensor([n, moves], dtype=torch.int64, device=device)
     every = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(every, mine, group=group)
     every = torch.stack(every).cpu().numpy()

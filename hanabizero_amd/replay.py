@@ -48,13 +48,13 @@ class ReplayBuffer:
         self.buffer.append(game)
         self.game_look_up += [(self.base_idx + len(self.buffer) - 1, pos) for pos in range(len(game))]
 
-    def ingest_packed(self, buf, n, tmax, action_space=None):
+    def ingest_packed(self, buf, n, moves, action_space=None):
         """All games of one packed byte buffer (SelfPlayActor.drain_packed / dist.gather_packed) -> GameHistory objects
         (GameHistory.from_packed), turn rewards reshaped as DataWorker.put does (selfplay_worker.py:32-37), stored at the
         maximum priority (--use_max_priority, train.sh).  Returns the number of games."""
         cfg = self.config
         W = (cfg.obs_shape // cfg.stacked_observations + 31) // 32
-        rec = unpack_packed(buf, n, tmax, cfg.action_space_size, W)
+        rec = unpack_packed(buf, n, moves, cfg.action_space_size, W)
         for i in range(n):
             g = reshape_turn_rewards(GameHistory.from_packed(unpack_record(rec, i), action_space, cfg))
             self.save_game(g, True, 0, None)

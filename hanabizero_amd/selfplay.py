@@ -91,7 +91,7 @@ class SelfPlayActor:
         self.cap = int(outbox_games or max(4 * N, 1024))
         self.out = {k: torch.zeros((self.cap,) + v.shape[1:], dtype=v.dtype, device=d) for k, v in self.traj.items()}
         self.out_meta = z(self.cap, 4, dtype=torch.int32)
-        self.out_count = z(1, dtype=torch.int64)
+        self.out_count = z(2, dtype=torch.int64)   # games finished so far | their total moves since the last drain
         self.slot = z(N, dtype=torch.int32)
         self.tmp_packed = z(N, W, dtype=torch.int32)
         self.tmp_legal = z(N, A, dtype=torch.uint8)
@@ -211,7 +211,7 @@ class SelfPlayActor:
         with a leading games axis, or None.  Must be called at least once per `cap` finished games."""
         if self.stream is not None:
             self.stream.synchronize()
-        count = int(self.out_count.item())
+        count = int(self.out_count[0].item())
         n = count - self._drained
         if n <= 0:
             return None
@@ -225,37 +225,35 @@ class SelfPlayActor:
             t = tmax + 1 if k in ("legal", "obs") else tmax
             rec[k] = v.index_select(0, idx)[:, :t].contiguous().cpu().numpy()
         rec["meta"] = meta.cpu().numpy()
+        with torch.cuda.stream(self.stream if self.stream is not None else torch.cuda.current_stream()):
+            self.out_count[1:].zero_()
         self._drained = count
         return rec
 
 
     def drain_packed(self):
-        """The games finished since the last drain as ONE byte buffer that stays on the device: (uint8 tensor, n, tmax)
-        or None.  `packed_layout(n, tmax, A, W)` describes it; hanabizero_amd.dist.gather_packed moves such buffers to the
+        """The games finished since the last drain as ONE byte buffer that stays on the device: (uint8 tensor, n games,
+        their total moves) or None.  `packed_layout(n, moves, A, W)` describes it; hanabizero_amd.dist.gather_packed moves such buffers to the
         replay owner GPU-to-GPU (no host copy on the sending ranks), `unpack_packed` views one on the host."""
         if self.stream is not None:
             self.stream.synchronize()
-        count = int(self.out_count.item())
+        count, moves = (int(x) for x in self.out_count.tolist())  # the one host round trip of a drain
         n = count - self._drained
         if n <= 0:
             return None
         if n > self.cap:
             raise RuntimeError("outbox overflow: %d games finished since the last drain, capacity %d" % (n, self.cap))
-        idx = torch.arange(self._drained, count, device=self.device) % self.cap
-        meta = self.out_meta.index_select(0, idx)
-        tmax = int(meta[:, 0].max().item())
-        layout, total = packed_layout(n, tmax, self.A, self.W)
-        buf = torch.zeros(total, dtype=torch.uint8, device=self.device)
-        for k, shp, dt, off in layout:
-            if k == "meta":
-                src = meta
-            else:
-                t = tmax + 1 if k in ("legal", "obs") else tmax
-                src = self.out[k].index_select(0, idx)[:, :t]
-            flat = src.contiguous().view(torch.uint8).reshape(-1)
-            buf[off:off + flat.numel()] = flat
+        total = int(lib.hz_actor_packed_bytes(n, moves, self.A, self.W, None))
+        buf = torch.empty(total, dtype=torch.uint8, device=self.device)
+        starts = torch.empty(n + 1, dtype=torch.int32, device=self.device)
+        with torch.cuda.stream(self.stream if self.stream is not None else torch.cuda.current_stream()):
+            check(lib.hz_actor_pack(C.byref(self.bufs), self._drained, n, moves, starts.data_ptr(), buf.data_ptr(), total,
+                                    _stream()), "hz_actor_pack")
+            self.out_count[1:].zero_()
+        if self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)  # the caller reads `buf` on its own stream
         self._drained = count
-        return buf, n, tmax
+        return buf, n, moves
 
 
 class ActorGroup:
@@ -303,12 +301,14 @@ class ActorGroup:
 _PACKED_FIELDS = ("meta", "action", "reward", "value", "visits", "legal", "obs")  # order inside a packed buffer
 
 
-def packed_layout(n, tmax, A, W):
-    """[(field, shape, numpy dtype, byte offset)], total bytes of the packed form of n games trimmed to tmax moves
-    (SelfPlayActor.drain_packed): every array starts on a 16-byte boundary."""
-    shapes = dict(meta=((n, 4), np.int32), action=((n, tmax), np.int8), reward=((n, tmax), np.int8),
-                  value=((n, tmax), np.float32), visits=((n, tmax, A), np.int16), legal=((n, tmax + 1, A), np.uint8),
-                  obs=((n, tmax + 1, W), np.int32))
+def packed_layout(n, moves, A, W):
+    """[(field, shape, numpy dtype, byte offset)], total bytes of the packed form of n games with `moves` moves in total
+    (SelfPlayActor.drain_packed, include/hz_selfplay.h hz_actor_pack): the games lie back to back in every section --
+    game j at rows [start_j, start_j + len_j) of the per-move sections and [start_j + j, start_j + j + len_j + 1) of
+    legal / obs, start_j = len_0 + .. + len_(j-1), len_j = meta[j][0] -- and every section starts on a 16-byte boundary."""
+    shapes = dict(meta=((n, 4), np.int32), action=((moves,), np.int8), reward=((moves,), np.int8),
+                  value=((moves,), np.float32), visits=((moves, A), np.int16), legal=((moves + n, A), np.uint8),
+                  obs=((moves + n, W), np.int32))
     out, off = [], 0
     for k in _PACKED_FIELDS:
         shp, dt = shapes[k]
@@ -317,22 +317,55 @@ def packed_layout(n, tmax, A, W):
     return out, off
 
 
-def unpack_packed(buf, n, tmax, A, W):
-    """Zero-copy views of a packed byte buffer (numpy uint8, host) as the dict drain() returns."""
-    layout, total = packed_layout(n, tmax, A, W)
+def unpack_packed(buf, n, moves, A, W):
+    """Zero-copy views of a packed byte buffer (numpy uint8, host): the seven sections plus "start" [n] = the games'
+    first rows.  `unpack_record(rec, i)` cuts game i out of it."""
+    layout, total = packed_layout(n, moves, A, W)
     assert buf.nbytes >= total
-    return {k: buf[off:off + int(np.prod(shp)) * np.dtype(dt).itemsize].view(dt).reshape(shp) for k, shp, dt, off in layout}
+    rec = {k: buf[off:off + int(np.prod(shp)) * np.dtype(dt).itemsize].view(dt).reshape(shp) for k, shp, dt, off in layout}
+    lens = rec["meta"][:, 0].astype(np.int64)
+    assert int(lens.sum()) == moves, "packed buffer: the games' lengths add up to %d, not %d" % (int(lens.sum()), moves)
+    rec["start"] = np.cumsum(lens) - lens
+    return rec
+
+
+def pack_records(rec, A, W):
+    """Host-side packer: a drain() dict (arrays padded to the longest game) -> (uint8 numpy buffer, n, moves) in the format
+    of drain_packed (tests, and actors that drained with drain())."""
+    n = int(rec["meta"].shape[0])
+    lens = rec["meta"][:, 0].astype(np.int64)
+    moves = int(lens.sum())
+    layout, total = packed_layout(n, moves, A, W)
+    buf = np.zeros(total, np.uint8)
+    views = {k: buf[off:off + int(np.prod(shp)) * np.dtype(dt).itemsize].view(dt).reshape(shp) for k, shp, dt, off in layout}
+    views["meta"][:] = rec["meta"]
+    s = 0
+    for i in range(n):
+        T = int(lens[i])
+        for k in ("action", "reward", "value", "visits"):
+            views[k][s:s + T] = rec[k][i, :T]
+        for k in ("legal", "obs"):
+            views[k][s + i:s + i + T + 1] = rec[k][i, :T + 1]
+        s += T
+    return buf, n, moves
 
 
 def unpack_record(rec, i):
-    """Game i of a drained batch -> the dict GameHistory.from_packed takes."""
+    """Game i of a drained batch (drain(): padded arrays; unpack_packed(): ragged sections) -> the dict
+    GameHistory.from_packed takes."""
     meta = rec["meta"][i]
     T = int(meta[0])
+    if "start" in rec:
+        s = int(rec["start"][i])
+        cut = {k: rec[k][s:s + T] for k in ("action", "reward", "value", "visits")}
+        cut.update({k: rec[k][s + i:s + i + T + 1] for k in ("legal", "obs")})
+    else:
+        cut = {k: rec[k][i, :T] for k in ("action", "reward", "value", "visits")}
+        cut.update({k: rec[k][i, :T + 1] for k in ("legal", "obs")})
     return dict(len=T, score=int(meta[1]), env_id=int(meta[2]),
                 visit_entropy_sum=float(np.array([meta[3]], np.int32).view(np.float32)[0]),
-                action=rec["action"][i, :T], reward=rec["reward"][i, :T], value=rec["value"][i, :T],
-                visits=rec["visits"][i, :T], legal=rec["legal"][i, :T + 1],
-                obs_bits=rec["obs"][i, :T + 1].view(np.uint32))
+                action=cut["action"], reward=cut["reward"], value=cut["value"], visits=cut["visits"], legal=cut["legal"],
+                obs_bits=cut["obs"].view(np.uint32))
 
 
 def record_nbytes(rec):

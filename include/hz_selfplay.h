@@ -66,7 +66,7 @@ typedef struct {
   uint8_t* out_legal;
   int32_t* out_obs;
   int32_t* out_meta;
-  int64_t* out_count;     /* [1] games finished so far */
+  int64_t* out_count;     /* [2] games finished so far; total moves of the games finished since the caller last zeroed [1] */
   int32_t* slot;          /* [N] scratch: outbox row of the env's finished game, -1 while it runs */
   int32_t* finished;      /* [N] scratch: the envs whose game just ended, ascending */
   int32_t* num_finished;  /* [1] scratch: how many */
@@ -89,6 +89,19 @@ int hz_actor_record_step(const hz_actor_bufs_t* bufs, const int32_t* reward, con
 /* hz_rows_scatter of all six trajectory arrays and the meta rows by bufs->slot, one launch over bufs->finished
  * (one workgroup per row and array). */
 int hz_actor_flush(const hz_actor_bufs_t* bufs, void* stream);
+
+/* Outbox ring rows [first, first + n) (mod capacity) as ONE packed byte buffer, the games back to back (ragged; `moves` =
+ * the sum of their lengths, which out_count[1] accumulates): sections
+ *   meta [n][4] i32 | action [moves] i8 | reward [moves] i8 | value [moves] f32 | visits [moves][A] i16 |
+ *   legal [moves + n][A] u8 | obs [moves + n][W] i32
+ * each starting on a 16-byte boundary; game j starts at row start_j = len_0 + .. + len_(j-1) of the per-move sections
+ * and at row start_j + j of the last two (which hold len_j + 1 rows per game: the terminal observation is stored).
+ * hz_actor_packed_bytes returns the total and, if `offsets` is not NULL, the seven section offsets.  `starts`:
+ * [n + 1] i32 DEVICE scratch (receives the start rows and the total).  This is what travels to the replay owner
+ * (ReplayBuffer.save_pools' payload, /root/reference/core/selfplay_worker.py:75-78). */
+int64_t hz_actor_packed_bytes(int n, int64_t moves, int num_actions, int packed_words, int64_t* offsets /* [7] or NULL */);
+int hz_actor_pack(const hz_actor_bufs_t* bufs, int64_t first, int n, int64_t moves, int32_t* starts, void* out,
+                  int64_t out_bytes, void* stream);
 
 /* After hz_env_reset(done) + hz_env_observe(newest, packed, legal): traj_len = done ? 0 : t+1, ent_sum = done ? 0 : ent_sum,
  * obs[traj_len] / legal[traj_len] = the current observation, and the model's input window (selfplay_worker.py:237,

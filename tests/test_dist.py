@@ -14,7 +14,7 @@ def _fake_rec(n, seed, T=6, A=11, W=7):
     return dict(action=rng.randint(0, A, (n, T)).astype(np.int8), reward=rng.randint(-2, 3, (n, T)).astype(np.int8),
                 value=rng.rand(n, T).astype(np.float32), visits=rng.randint(0, 9, (n, T, A)).astype(np.int16),
                 legal=rng.randint(0, 2, (n, T + 1, A)).astype(np.uint8), obs=rng.randint(-2**31, 2**31 - 1, (n, T + 1, W)).astype(np.int32),
-                meta=rng.randint(0, 100, (n, 4)).astype(np.int32))
+                meta=np.concatenate([rng.randint(1, T + 1, (n, 1)), rng.randint(0, 100, (n, 3))], 1).astype(np.int32))
 
 
 def _worker(rank, world, port, counts, q):
@@ -48,28 +48,25 @@ def _worker(rank, world, port, counts, q):
         ok &= bool((got["action"][:3, 4:] == 0).all())  # rank 0's rows are zero-padded up to rank 1's extent
     # the device-resident form: packed byte buffers (here CPU tensors over gloo), different (n, tmax) per rank, one empty
     from hanabizero_amd.dist import gather_packed
-    from hanabizero_amd.selfplay import packed_layout, unpack_packed
+    from hanabizero_amd.selfplay import pack_records, unpack_packed, unpack_record
     A, W = 11, 7
 
     def pack(rec_):
-        n_, tmax_ = rec_["meta"].shape[0], rec_["action"].shape[1]
-        layout, total = packed_layout(n_, tmax_, A, W)
-        buf = np.zeros(total, np.uint8)
-        for k, shp, dt, off in layout:
-            raw = np.ascontiguousarray(rec_[k]).view(np.uint8).reshape(-1)
-            buf[off:off + raw.size] = raw
-        return torch.from_numpy(buf), n_, tmax_
+        buf, n_, moves_ = pack_records(rec_, A, W)
+        return torch.from_numpy(buf), n_, moves_
     for rnd, ns in enumerate([(3, 2), (0, 4), (0, 0)]):
         mine = _fake_rec(ns[rank], 50 + 10 * rnd + rank, T=5 + 3 * rank, A=A, W=W) if ns[rank] else None
         got = gather_packed(None if mine is None else pack(mine), A, W, dst=0)
         if rank == 0:
             want = [(r, _fake_rec(c, 50 + 10 * rnd + r, T=5 + 3 * r, A=A, W=W)) for r, c in enumerate(ns) if c]
             ok &= len(got) == len(want)
-            for (buf, n_, tmax_), (r, w) in zip(got, want):
-                view = unpack_packed(buf, n_, tmax_, A, W)
-                ok &= n_ == ns[r] and tmax_ == 5 + 3 * r
-                for k in w:
-                    ok &= bool((view[k] == w[k]).all()) and view[k].dtype == w[k].dtype
+            for (buf, n_, moves_), (r, w) in zip(got, want):
+                view = unpack_packed(buf, n_, moves_, A, W)
+                ok &= n_ == ns[r] and moves_ == int(w["meta"][:, 0].sum())
+                for i in range(n_):
+                    a, b = unpack_record(view, i), unpack_record(w, i)
+                    for k in a:
+                        ok &= bool(np.array_equal(np.asarray(a[k]), np.asarray(b[k])))
         else:
             ok &= got is None
     sd = {"b": torch.full((3,), float(rank)), "a": torch.arange(4.0) * (rank + 1)}
@@ -108,7 +105,7 @@ def test_collectives_over_rccl_one_rank():
     all_gather / gather / broadcast really go through the RCCL communicator -- tensor placement, dtypes and call
     signatures are what differs from gloo."""
     import hanabizero_amd.dist as hd
-    from hanabizero_amd.selfplay import packed_layout, unpack_packed
+    from hanabizero_amd.selfplay import pack_records, unpack_packed, unpack_record
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
     device = torch.device("cuda", 0)
     torch.cuda.set_device(device)
@@ -122,16 +119,14 @@ def test_collectives_over_rccl_one_rank():
             assert got[k].dtype == rec[k].dtype and (got[k] == rec[k]).all(), k
         assert hd.gather_records(None, dst=0) is None
         A, W = 11, 7
-        layout, total = packed_layout(5, 7, A, W)
-        buf = np.zeros(total, np.uint8)
-        for k, shp, dt, off in layout:
-            raw = np.ascontiguousarray(rec[k]).view(np.uint8).reshape(-1)
-            buf[off:off + raw.size] = raw
-        out = hd.gather_packed((torch.from_numpy(buf).to(device), 5, 7), A, W, dst=0)
-        assert len(out) == 1 and out[0][1:] == (5, 7)
-        view = unpack_packed(out[0][0], 5, 7, A, W)
-        for k in rec:
-            assert (view[k] == rec[k]).all(), k
+        buf, n_, moves_ = pack_records(rec, A, W)
+        out = hd.gather_packed((torch.from_numpy(buf).to(device), n_, moves_), A, W, dst=0)
+        assert len(out) == 1 and out[0][1:] == (n_, moves_)
+        view = unpack_packed(out[0][0], n_, moves_, A, W)
+        for i in range(n_):
+            a, b = unpack_record(view, i), unpack_record(rec, i)
+            for k in a:
+                assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), (i, k)
         assert hd.gather_packed(None, A, W, dst=0) == []
         sd = {"w": torch.arange(6.0).reshape(2, 3), "b": torch.ones(3, dtype=torch.bfloat16)}
         bw = hd.broadcast_weights(sd, src=0)

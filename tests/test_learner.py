@@ -235,8 +235,8 @@ def test_self_play_to_learner_loop_on_one_gpu():
     for step in range(30):
         actor.step()
         if step % 10 == 9:  # random-init nets lose a Hanabi-Small game in a handful of moves: drain often
-            for buf, n, tmax in gather_packed(actor.drain_packed(), actor.A, actor.W):
-                rb.ingest_packed(buf, n, tmax)
+            for buf, n, moves in gather_packed(actor.drain_packed(), actor.A, actor.W):
+                rb.ingest_packed(buf, n, moves)
     assert rb.size() > 50 and rb.get_total_len() > 10 * cfg.batch_size
     g0 = rb.buffer[0]
     assert len(g0.child_visits) == len(g0) and abs(sum(g0.child_visits[0]) - 1.0) < 1e-6
@@ -257,8 +257,8 @@ def test_self_play_to_learner_loop_on_one_gpu():
     learner.eval()
     eng.load(learner.cpu())            # selfplay_worker.py:177-184: the actor picks the new weights up
     actor._graph = None                # (the captured graph holds the old fused tables: capture again)
-    before = int(actor.out_count.item())
+    before = int(actor.out_count[0].item())
     for _ in range(8):
         actor.step()
     torch.cuda.synchronize()
-    assert int(actor.illegal_steps) == 0 and int(actor.out_count.item()) > before
+    assert int(actor.illegal_steps) == 0 and int(actor.out_count[0].item()) > before

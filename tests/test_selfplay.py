@@ -219,21 +219,32 @@ def test_persistent_search_kernel_equals_launch_per_phase(game, N, sims):
 
 
 def test_packed_drain_equals_drain():
-    """drain_packed (one byte buffer that stays on the device) carries exactly what drain() returns."""
-    from hanabizero_amd.selfplay import packed_layout, unpack_packed
+    """drain_packed (one ragged byte buffer that stays on the device, hz_actor_pack) carries exactly the games drain()
+    returns, and the host-side packer (pack_records) produces the same bytes section by section."""
+    from hanabizero_amd.selfplay import pack_records, packed_layout, unpack_packed, unpack_record
     recs = []
     for packed in (False, True):
         cfg, eng, actor = make("Hanabi-Small", 64, 10, 2, torch.bfloat16, True, seed=33)
-        for _ in range(40):
-            actor.step()
-        torch.cuda.synchronize()
-        if packed:
-            buf, n, tmax = actor.drain_packed()
-            assert buf.is_cuda and buf.numel() == packed_layout(n, tmax, actor.A, actor.W)[1]
-            recs.append(unpack_packed(buf.cpu().numpy(), n, tmax, actor.A, actor.W))
-            assert actor.drain_packed() is None
-        else:
-            recs.append(actor.drain())
-    assert recs[0]["meta"].shape[0] > 10
-    for k in recs[0]:
-        assert recs[0][k].dtype == recs[1][k].dtype and (recs[0][k] == recs[1][k]).all(), k
+        for rnd in range(2):  # two drains: the second starts in the middle of the outbox ring
+            for _ in range(25):
+                actor.step()
+            torch.cuda.synchronize()
+            if packed:
+                buf, n, moves = actor.drain_packed()
+                assert buf.is_cuda and buf.numel() == packed_layout(n, moves, actor.A, actor.W)[1]
+                recs.append(unpack_packed(buf.cpu().numpy(), n, moves, actor.A, actor.W))
+                assert actor.drain_packed() is None
+            else:
+                recs.append(actor.drain())
+    for padded, ragged in ((recs[0], recs[2]), (recs[1], recs[3])):
+        n = padded["meta"].shape[0]
+        assert n > 10 and ragged["meta"].shape[0] == n and (padded["meta"] == ragged["meta"]).all()
+        assert len(set(padded["meta"][:, 0].tolist())) > 1  # games of different lengths
+        for i in range(n):
+            a, b = unpack_record(padded, i), unpack_record(ragged, i)
+            for k in a:
+                assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), (i, k)
+        hbuf, hn, hmoves = pack_records(padded, actor.A, actor.W)
+        again = unpack_packed(hbuf, hn, hmoves, actor.A, actor.W)
+        for k in again:
+            assert again[k].dtype == ragged[k].dtype and np.array_equal(again[k], ragged[k]), k
