@@ -20,13 +20,17 @@ __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
 // inverse_scalar_transform of LDS rows of bf16 logits, one (row, head) pair per 32-lane half of the wave: lane l32
 // owns logits [8*l32, 8*l32 + 8) (one ds_read_b128), DPP reductions inside each 16-lane row, one cross-row exchange;
 // V <= 256.  Same maths as hz_tree.hip support_to_scalar.
+// (the cross-row step through readlane + select, not a ds_bpermute round trip: row0 op row1 for lanes 0-31, row2 op row3
+// for lanes 32-63)
 __device__ __forceinline__ float half32_max(float v) {
   v = hz_row16_max(v);
-  return fmaxf(v, __shfl_xor(v, 16));
+  const float lo = fmaxf(hz_readlane_f(v, 0), hz_readlane_f(v, 16)), hi = fmaxf(hz_readlane_f(v, 32), hz_readlane_f(v, 48));
+  return (threadIdx.x & 32) ? hi : lo;
 }
 __device__ __forceinline__ float half32_sum(float v) {
   v = hz_row16_sum(v);
-  return v + __shfl_xor(v, 16);
+  const float lo = hz_readlane_f(v, 0) + hz_readlane_f(v, 16), hi = hz_readlane_f(v, 32) + hz_readlane_f(v, 48);
+  return (threadIdx.x & 32) ? hi : lo;
 }
 __device__ __forceinline__ float row32_support_to_scalar(const uint16_t* row, int V, int support_min, int l32) {
   uint32_t w[4];
@@ -57,9 +61,11 @@ __device__ __forceinline__ float row32_support_to_scalar(const uint16_t* row, in
   }
   se = half32_sum(se);
   sw = half32_sum(sw);
-  const float v = sw / se;
+  // (a network output, tolerance 1e-3: the hardware reciprocal and square root -- 1 ulp -- instead of the correctly
+  // rounded sequences the tree arithmetic needs)
+  const float v = sw * __builtin_amdgcn_rcpf(se);
   const float eps = 0.001f;
-  const float t = (sqrtf(1.0f + 4.0f * eps * (fabsf(v) + 1.0f + eps)) - 1.0f) / (2.0f * eps);
+  const float t = (__builtin_amdgcn_sqrtf(1.0f + 4.0f * eps * (fabsf(v) + 1.0f + eps)) - 1.0f) * (1.0f / (2.0f * eps));
   float out = t * t - 1.0f;
   if (v < 0.0f) out = -out;
   if (out != out) out = 0.0f;
@@ -117,7 +123,12 @@ __device__ __forceinline__ void mlp_body(
   constexpr int NTHR = 64 * NW;
   constexpr bool PRESTAGED = STAGE == STAGE_REGS;
   constexpr int MT = 16 * RT;
-  const int tid = threadIdx.x, lane = tid & 63;
+  // (opaque to the optimiser: inside a caller's loop -- the simulations of the persistent search kernel -- everything
+  // derived from the thread index would otherwise be hoisted out of that loop, kept alive across the other phases and,
+  // at 128 registers per lane, spilled to scratch: a memory round trip per use instead of a few ALU instructions)
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: job fields stay in SGPRs, branches are scalar
   const int rs = H.row_stride;
   const int r0 = lane & 15, kq = (lane >> 4) * 8, c4 = 4 * (lane >> 4);

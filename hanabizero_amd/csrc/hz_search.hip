@@ -35,17 +35,15 @@ struct SearchArgs {
 // What the phases hand to each other inside a workgroup: the descent ends by requesting its leaf's parent hidden state
 // (pool[entry][tree], one 16-B load per lane) into registers and leaves the action in act_s; the inference writes those
 // registers into its row of the image only after it has started its weight stream (the load's latency hides under it),
-// and leaves reward / value / policy logits in rew_s / val_s / pol_s for the backup.  The pointers
-// handed to the shared bodies are biased by -row0 so that their indexing by the global tree number lands in these arrays.
+// and leaves the head logits in the image, where the tree's wave turns them into reward / value / policy logits in its
+// registers.  The pointers handed to the shared bodies are biased by -row0 so that their indexing by the global tree
+// number lands in these arrays.
 struct SearchLds {
   uint16_t* image;  // [16][row_stride]
   float4* prec_s;   // [16][S+1]  the last descent's records, per tree
   int32_t* path_s;  // [16][S+1]  the last descent's path, per tree
   float* lds_q;     // [16][S]    q cache, per tree, for the whole search
   int32_t* act_s;   // [16]
-  float* rew_s;     // [16]
-  float* val_s;     // [16]
-  float* pol_s;     // [16][A]
   uint64_t* exp_s;  // [32] hz_exp2f_tab
 };
 
@@ -86,28 +84,35 @@ __device__ __forceinline__ RowFrag search_backup_descent(const TreeView& tv, con
                                                          bool more, TreeLocal& tl, float4& root_row) {
   const TraverseOut to = search_traverse_out(H, a, L, row0);
   NetOut no;
-  no.rewards = L.rew_s - row0; no.values = L.val_s - row0; no.logits = L.pol_s - (size_t)row0 * tv.A;
+  no.rewards = nullptr; no.values = nullptr; no.logits = nullptr;
   no.reward_logits = nullptr; no.value_logits = nullptr; no.policy_logits = nullptr;
   no.reward_stride = 0; no.value_stride = 0; no.policy_stride = 0;
   no.support_size = 0; no.support_min = 0; no.dtype = 0; no.out_rewards = nullptr; no.out_values = nullptr;
-  // the leaf's heads, straight from the row image the inference left behind (the arithmetic of the stand-alone kernel's
-  // final stage): lanes 0-31 turn the reward logits into a scalar, lanes 32-63 the value logits; lane a takes policy logit a
+  TP_ON(more ? 1 : 0);  // (diagnostic builds: the stamps of the last simulation that has a descent stay)
+  TP(14);
+  // the leaf's heads, straight from the row image the inference left behind into registers (the arithmetic of the
+  // stand-alone kernel's final stage): lanes 0-31 turn the reward logits into a scalar, lanes 32-63 the value logits;
+  // lane a takes policy logit a
   {
     const uint16_t* row = L.image + (size_t)srow * H.row_stride;
+#ifdef HZ_SEARCH_X_NOHEADS  // experiment (tools/search_profile.py): what the two scalar transforms cost; results are garbage
+    const float x = bf2f(row[((lane >> 5) ? H.off_value : H.off_reward) + 100]);
+#else
     const float x = row32_support_to_scalar(row + ((lane >> 5) ? H.off_value : H.off_reward), H.support_size,
                                             H.support_min, lane & 31);
-    if (lane == 0) L.rew_s[srow] = x;
-    if (lane == 32) L.val_s[srow] = x;
+#endif
+    float pl = 0.0f;
     if (lane < tv.A) {
-      float pl = bf2f(row[H.off_policy + lane]);
+      pl = bf2f(row[H.off_policy + lane]);
       if (pl != pl) pl = 0.0f;  // core/mcts.py:48-49
-      L.pol_s[srow * tv.A + lane] = pl;
     }
+    tl.leaf_reward = hz_readlane_f(x, 0);
+    tl.leaf_value = hz_readlane_f(x, 32);
+    tl.leaf_logit = pl;
   }
   float mn, mx;
   int rv, a0;
   float4 first;
-  TP_ON(1);
   TP(0);
   tl.publish = !more;  // the last backup's root sums and min / max are the ones the read-outs see
   backprop_body<false, true>(tv, tree, lane, srow, L.lds_q, sim + 1, no, mn, mx, rv, first, a0, &tl);
@@ -115,7 +120,9 @@ __device__ __forceinline__ RowFrag search_backup_descent(const TreeView& tv, con
   f.v[0] = f.v[1] = make_uint4(0u, 0u, 0u, 0u);
   if (lane == a0) root_row = first;  // the one record of the root's row this backup changed
   if (more) {
+#ifndef HZ_SEARCH_X_NOFENCE  // experiment: what draining the backup's record stores before the descent costs
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+#endif
     int entry;
     TP(5);
     tl.publish = sim + 2 == a.sims;  // the last descent
@@ -130,8 +137,8 @@ template <int RT>
 __device__ __forceinline__ void search_inference(const hz_mlp_header_t& H, const SearchArgs& a, const SearchLds& L, int sim,
                                                  int n_rows, int row0, const RowFrag* rows) {
   mlp_body<RT, 16, 2, STAGE_REGS, false>(H, a.jobs, a.wstream, a.bias, a.act_tab, a.pool, a.row_stride, nullptr, a.plane_stride,
-                                 L.act_s - row0, a.pool + (size_t)(sim + 1) * a.plane_stride, L.rew_s - row0,
-                                 L.val_s - row0, L.pol_s - (size_t)row0 * H.num_actions, n_rows, L.image, row0, rows);
+                                 L.act_s - row0, a.pool + (size_t)(sim + 1) * a.plane_stride, nullptr, nullptr, nullptr,
+                                 n_rows, L.image, row0, rows);
 }
 
 // Diagnostic build only (-DHZ_SEARCH_PROFILE, tools/search_profile.py): per-phase s_memtime sums of workgroup 100.
@@ -162,9 +169,6 @@ __global__ __launch_bounds__(1024, 1) void k_search(TreeView tv, hz_mlp_header_t
   L.path_s = reinterpret_cast<int32_t*>(L.prec_s + MT * (tv.S + 1));
   L.lds_q = reinterpret_cast<float*>(L.path_s + MT * (tv.S + 1));
   L.act_s = reinterpret_cast<int32_t*>(L.lds_q + MT * tv.S);
-  L.rew_s = reinterpret_cast<float*>(L.act_s + MT);
-  L.val_s = L.rew_s + MT;
-  L.pol_s = L.val_s + MT;
   if (threadIdx.x < 32) L.exp_s[threadIdx.x] = hz_exp2f_tab[threadIdx.x];
   TreeLocal tl[RT];
   bool mine[RT];
@@ -202,10 +206,12 @@ __global__ __launch_bounds__(1024, 1) void k_search(TreeView tv, hz_mlp_header_t
     unsigned long long t3 = SP_NOW();
     __syncthreads();  // leaf outputs visible; the row image is free again
     unsigned long long t4 = SP_NOW();
+    int lane_t = lane;  // (opaque: lane-derived values of the tree phase are recomputed per simulation, not spilled)
+    asm volatile("" : "+v"(lane_t));
 #pragma unroll
     for (int s = 0; s < RT; ++s)
       if (mine[s])
-        rows[s] = search_backup_descent(tv, H, a, L, row0, row0 + 16 * s + wave, lane, 16 * s + wave, sim, sim + 1 < a.sims,
+        rows[s] = search_backup_descent(tv, H, a, L, row0, row0 + 16 * s + wave, lane_t, 16 * s + wave, sim, sim + 1 < a.sims,
                                         tl[s], root_row[s]);
     p_tree += t1 - t0; p_wait1 += t2 - t1; p_mlp += t3 - t2; p_wait2 += t4 - t3;
     t0 = t4;
@@ -267,7 +273,7 @@ extern "C" int hz_search_run(hz_tree_t* t, int num_simulations, const hz_mlp_hea
   }
   auto lds_for = [&](int mt) {
     return (size_t)mt * H->row_stride * sizeof(uint16_t) + (size_t)mt * (t->S + 1) * (16 + 4) + (size_t)mt * t->S * sizeof(float) +
-           (size_t)(mt * 3 + mt * t->A + 2) * sizeof(float) + 32 * 8 + 256;  // (+256: slack behind the last array)
+           (size_t)(mt + 2) * sizeof(float) + 32 * 8 + 256;  // (+256: slack behind the last array)
   };
   if (rows_wg == 32 && lds_for(32) > 160 * 1024 && g_search_rows_per_workgroup == 0) rows_wg = 16;
   const size_t lds_bytes = lds_for(rows_wg);

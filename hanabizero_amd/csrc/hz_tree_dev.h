@@ -122,6 +122,8 @@ struct TreeLocal {
                     // the last descent's and the last backup's are ever read (the read-outs after the search)
   float pbc_reg, sqrt_reg;  // per-lane tables of the descent (pb_c's log factor, sqrt(n + 1)), loaded / computed once
   const uint64_t* exp_tab;  // hz_exp2f_tab in LDS
+  float leaf_reward, leaf_value;  // the leaf's outputs for the coming backup (uniform), and lane a's policy logit
+  float leaf_logit;
 };
 
 template <bool LOCAL = false>
@@ -344,7 +346,9 @@ __device__ __forceinline__ void backprop_body(const TreeView& tv, int tree, int 
   // expand the leaf: priors of the new entry's children
   float logit = 0.0f;
   if (on) {
-    if (FUSED) {
+    if (LOCAL) {
+      logit = tl->leaf_logit;
+    } else if (FUSED) {
       logit = load_as_f32(no.policy_logits, (long long)tree * no.policy_stride + lane, no.dtype);
       if (logit != logit) logit = 0.0f;  // core/mcts.py:48-49
     } else {
@@ -362,7 +366,10 @@ __device__ __forceinline__ void backprop_body(const TreeView& tv, int tree, int 
 
   const int npairs = (LOCAL ? tl->path_len : tv.path_len[tree]) - 1;  // edges on the path; the node below edge k is at depth k+1
   float G, leaf_reward;                      // bootstrap_value (cnode.cpp:318) and the leaf's reward
-  if (FUSED) {
+  if (LOCAL) {
+    G = tl->leaf_value;
+    leaf_reward = tl->leaf_reward;
+  } else if (FUSED) {
     const int es = (no.dtype == HZ_F32) ? 4 : 2;
     const uint8_t* vrow = (const uint8_t*)no.value_logits + (size_t)tree * (size_t)no.value_stride * es;
     const uint8_t* rrow = (const uint8_t*)no.reward_logits + (size_t)tree * (size_t)no.reward_stride * es;

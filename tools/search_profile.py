@@ -60,6 +60,7 @@ def main():
     lib.hz_tree_profile_read(tp.ctypes.data_as(C.c_void_p))
     tp = tp.astype(np.int64)
     names = ["start", "expand done", "leaf value/reward", "backup loop", "min/max", "fence"] + ["level %d" % d for d in range(1, 8)] + ["end"]
+    print("    heads' read-out        +%6d" % (tp[0] - tp[14]))
     prev = tp[0]
     for i, nme in enumerate(names):
         if tp[i] == 0 or tp[i] < tp[0]:
