@@ -131,7 +131,9 @@ __device__ __forceinline__ float hz_expf(float x, const uint64_t* tab = hz_exp2f
   uint64_t t = tab[ki & 31];
   t += ki << (52 - 5);
   const double s = __longlong_as_double((long long)t);
-  z = __builtin_fma(C0, r, C1);
+  double c1 = C1;  // (pinned to scalar registers here: hoisted out of a caller's loop as a vector-register constant it
+  asm volatile("" : "+s"(c1));  //  ends up spilled to scratch, a memory round trip in the middle of the expansion)
+  z = __builtin_fma(C0, r, c1);
   const double r2 = r * r;
   double y = __builtin_fma(C2, r, 1.0);
   y = __builtin_fma(z, r2, y);

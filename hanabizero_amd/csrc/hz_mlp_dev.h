@@ -131,7 +131,6 @@ __device__ __forceinline__ void mlp_body(
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: job fields stay in SGPRs, branches are scalar
   const int rs = H.row_stride;
-  const int r0 = lane & 15, kq = (lane >> 4) * 8, c4 = 4 * (lane >> 4);
   (void)NTHR;
 
   unsigned long long p_loop = 0, p_epi = 0, p_bar = 0, p_pre = 0;
@@ -206,7 +205,7 @@ __device__ __forceinline__ void mlp_body(
   int act[RT];  // (read after the barrier: in STAGE_REGS mode the caller's waves have only just written them)
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
-    const int row = row0 + 16 * rt + r0;
+    const int row = row0 + 16 * rt + (lane & 15);
     int a = row < n_rows ? actions[row] : 0;
     act[rt] = (a < 0 || a >= H.num_actions) ? 0 : a;
   }
@@ -215,6 +214,12 @@ __device__ __forceinline__ void mlp_body(
   (void)p_staged;
   long long gstep = 0;  // k-steps of this wave's stream consumed so far
   for (int j = 0; j < H.n_jobs; ++j) {
+    // this lane's place in the MFMA fragments, derived afresh per job from an opaque copy of the lane index: kept across
+    // the jobs the derived LDS addresses are spilled at 128 registers per lane, and their reloads (scratch = vector
+    // memory) would drain the weight ring in front of every k-loop
+    int lane_j = lane;
+    asm volatile("" : "+v"(lane_j));
+    const int r0 = lane_j & 15, kq = (lane_j >> 4) * 8, c4 = 4 * (lane_j >> 4);
     const int jsel = j >> 3, jb = (j & 7) * 8;
     const int jr = jsel == 0 ? jv[0] : (jsel == 1 ? jv[1] : (jsel == 2 ? jv[2] : jv[3]));
     hz_mlp_job_t J;
