@@ -162,7 +162,11 @@ __device__ __forceinline__ void mlp_body(
   // uniform base + per-lane 16-B offset: the k-loop advances the base on the scalar unit, not with 64-bit VALU adds
   const bf16x8* wbase = reinterpret_cast<const bf16x8*>(wstream + H.wave_stream_off[wave]);
   const long long kss = H.kstep_stride / 8;  // in 16-B fragments-per-lane units
+#ifdef HZ_MLP_X_NT  // experiment: non-temporal (streaming) weight loads
+#define wp(k, t) __builtin_nontemporal_load(&wbase[(long long)(k) * kss + (t) * 64 + lane])
+#else
 #define wp(k, t) wbase[(long long)(k) * kss + (t) * 64 + lane]
+#endif
   bf16x8 wf[HZ_RING][NT];
 #pragma unroll
   for (int d = 0; d < HZ_RING - HZ_BURST; ++d)
