@@ -227,7 +227,7 @@ def main():
     ap.add_argument("--share-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--no-fused-mlp", action="store_true", help="hipBLASLt GEMM chain instead of the fused MFMA kernel")
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
-    ap.add_argument("--flush-every", type=int, default=40, help="drain + gather finished games every this many steps (the outbox ring holds 4 x envs games: ~58 steps of Hanabi-Full) and once at the end of the timed loop")
+    ap.add_argument("--flush-every", type=int, default=None, help="drain + gather finished games every this many steps and once at the end of the timed loop (default 40 for Hanabi-Full -- the outbox ring holds 4 x envs games: ~58 steps of random-init play -- and 15 for Hanabi-Small, whose games are shorter)")
     ap.add_argument("--actors-per-gpu", type=int, default=1,
                     help="split this GPU's envs over this many concurrent actors (own hipGraph + stream each)")
     ap.add_argument("--branch-graph", action="store_true", help="with --actors-per-gpu > 1: one hipGraph with a branch per actor")
@@ -262,6 +262,8 @@ def main():
     from hanabizero_amd.selfplay import SelfPlayActor, packed_layout
 
     game, N, S, stack = WORKLOADS[args.workload]
+    if args.flush_every is None:
+        args.flush_every = 15 if game == "Hanabi-Small" else 40
     cfg = make_config(game, simulations=S, stack=stack, p_mcts_num=N)
     dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype]
     engine = build_engine(cfg, dtype, device, fused=False if args.no_fused_mlp else None)
