@@ -185,7 +185,7 @@ def test_select_action_kernel_edge_cases():
 
 
 @pytest.mark.parametrize("game,N,sims", [("Hanabi-Small", 100, 12), ("Hanabi-Full", 50, 50), ("Hanabi-Full", 1000, 20),
-                                         ("Hanabi-Full-5p", 70, 30)])
+                                         ("Hanabi-Full-5p", 70, 30), ("Hanabi-Full", 4170, 8)])
 def test_persistent_search_kernel_equals_launch_per_phase(game, N, sims):
     """hz_search_run (all simulations in one persistent kernel, a workgroup per 16 trees) against the launch-per-phase
     search (hz_tree_traverse -> hz_mlp_recurrent -> hz_tree_backprop_traverse ...): bit-identical trees, hidden-state
@@ -200,8 +200,10 @@ def test_persistent_search_kernel_equals_launch_per_phase(game, N, sims):
     noise = torch.rand(N, A, device="cuda", generator=g)
     noise = noise / noise.sum(1, keepdim=True)
     res = []
-    for persistent in (False, 16, 32):  # launch per phase; one / two trees per wavefront of the persistent kernel
-        check(lib.hz_search_set_rows_per_workgroup(int(persistent)), "hz_search_set_rows_per_workgroup")
+    # launch per phase; one / two trees per wavefront of the persistent kernel; the library's own choice (two once the
+    # trees outnumber 16 per compute unit: the last case)
+    for persistent in (False, 16, 32, "auto"):
+        check(lib.hz_search_set_rows_per_workgroup(0 if persistent == "auto" else int(persistent)), "hz_search_set_rows_per_workgroup")
         roots = cytree.Roots(N, A, sims, tie_seed=5, tree_id_base=17)
         roots.prepare(cfg.root_exploration_fraction, noise, torch.zeros(N, device="cuda"), logits0, actor.legal)
         pool = torch.zeros(sims, N, eng.H, dtype=eng.dtype, device="cuda")
