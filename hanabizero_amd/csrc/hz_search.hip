@@ -23,9 +23,9 @@ struct SearchArgs {
   int32_t* ix;             // [N] scratch: leaf parent entry of the current simulation (= pool plane)
   int32_t* iy;             // [N]
   int32_t* la;             // [N] last action
-  float* rew;              // [N] scratch: leaf reward / value / policy logits of the current simulation
+  float* rew;              // [N], [N], [N][A]: reserved (the leaf outputs never leave the chip)
   float* val;
-  float* pol;              // [N][A]
+  float* pol;
   int sims;                // simulations to run (S - 1, as the reference)
 };
 

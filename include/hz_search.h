@@ -28,7 +28,8 @@ extern "C" {
  * pool             [>= num_simulations + 1][N][hidden] bf16 (DEVICE), plane 0 = the roots' hidden states; plane k+1
  *                  receives the hidden states simulation k produces; plane_stride / row_stride in elements
  * ix, iy, la       [N] i32 scratch (DEVICE): on return the values of the last simulation
- * rewards, values  [N] f32 scratch; policy [N][num_actions] f32 scratch: leaf outputs of the last simulation */
+ * rewards, values  [N] f32, policy [N][num_actions] f32 (DEVICE): reserved -- the leaf outputs stay on chip (row image ->
+ *                  registers of the tree's wave) and these arrays are not written; they must still be valid pointers */
 int hz_search_run(hz_tree_t* t, int num_simulations, const hz_mlp_header_t* H, const hz_mlp_job_t* jobs,
                   const void* wstream, const float* biases, const float* action_table, void* pool,
                   int64_t plane_stride, int64_t row_stride, int32_t* ix, int32_t* iy, int32_t* la, float* rewards,
