@@ -511,6 +511,30 @@ class _FusedChain:
             row = cut[p0:p0 + waves] + [None] * (waves - len(cut[p0:p0 + waves]))
             self._jobs.append(dict(entries=row, barrier=barrier and p0 == 0, store_hidden=False))
 
+    def add_stage(self, lanes, barrier=True):
+        """Independent chains side by side between two workgroup barriers: `lanes` = [[(w, b, K, src, dst, relu, res), ...],
+        ...]; lane i owns the waves [i * waves / len(lanes), (i + 1) * waves / len(lanes)) and runs its layers one after
+        the other on them while the other lanes stream their own: no wave idles through a barrier because the layer at
+        hand is narrow.  No layer of a stage may read what another layer of the same stage writes (there is no barrier
+        inside a stage); layers may have different K."""
+        cw, waves = self.cw, self.waves
+        cap = waves // len(lanes)
+        assert cap >= 1
+        rows = []
+        for i, lane in enumerate(lanes):
+            r = 0
+            for li, (w, b, K, src, dst, relu, res) in enumerate(lane):
+                chunks = [(c, min(cw, w.shape[0] - c)) for c in range(0, w.shape[0], cw)]
+                for j, (c, n) in enumerate(chunks):
+                    row = r + j // cap
+                    while len(rows) <= row:
+                        rows.append([None] * waves)
+                    rows[row][i * cap + j % cap] = dict(w=w[c:c + n], b=b[c:c + n], ks=K // 32, src=src, dst=dst + c,
+                                                        res=None if res is None else res + c, relu=relu, act=None)
+                r += (len(chunks) + cap - 1) // cap
+        for k, row in enumerate(rows):
+            self._jobs.append(dict(entries=row, barrier=barrier and k == 0, store_hidden=False, fixed=True))
+
     def _finish(self, width, in_width, hidden, state_off, hidden_off, off_r, off_v, off_p):
         from ._lib import MlpHeader, MlpJob
         engine, waves, tiles, cw, jobs = self.engine, self.waves, self.tiles, self.cw, self._jobs
@@ -526,13 +550,18 @@ class _FusedChain:
         load = [0] * waves
         for job in jobs:
             ents = [e for e in job["entries"] if e is not None]
-            order = sorted(range(waves), key=lambda w: (load[w], w))[:len(ents)]
-            row = [None] * waves
-            for w, e in zip(sorted(order), ents):
-                row[w] = e
-                load[w] += e["ks"]
             pass_ks = max(e["ks"] for e in ents)
-            assert all(e["ks"] == pass_ks for e in ents), "jobs of one pass share their K"
+            if job.get("fixed"):  # add_stage: the entries sit on the waves of their lane
+                row = list(job["entries"])
+                for w, e in enumerate(row):
+                    load[w] += e["ks"] if e is not None else 0
+            else:
+                order = sorted(range(waves), key=lambda w: (load[w], w))[:len(ents)]
+                row = [None] * waves
+                for w, e in zip(sorted(order), ents):
+                    row[w] = e
+                    load[w] += e["ks"]
+                assert all(e["ks"] == pass_ks for e in ents), "jobs of one pass share their K"
             for wave, e in enumerate(row):
                 flags = (MLP_BARRIER if job["barrier"] else 0) | (MLP_STORE_HIDDEN if job["store_hidden"] else 0)
                 if e is None:
@@ -622,35 +651,42 @@ class FusedRecurrent(_FusedChain):
         wh = torch.cat([_fold(rw[0], rw[1])[0], _fold(ac[0], ac[1])[0], _fold(va[0], va[1])[0]], 0)
         bh = torch.cat([_fold(rw[0], rw[1])[1], _fold(ac[0], ac[1])[1], _fold(va[0], va[1])[1]], 0)
         if full:   # NewDynamicNet + 3-layer heads (config/hanabi_control/model.py:93-125, 250-269)
-            # Row image, 3 H wide (every region is reused as soon as its contents are dead, so that 32 rows of it and
+            # Row image, 3 H + h wide (every region is reused as soon as its contents are dead, so that 32 rows of it and
             # the 32 trees' search state fit the 160 KiB of a workgroup -- hz_search.hip):
-            #   [0, H) X state | [H, 2H) Y1 | [2H, 3H) Y0 = the next hidden state;  the heads' first layer (3 h wide)
-            #   lands on X and the lower half of Y1, their second layers behind it (upper Y1, Y0), the third layers back
-            #   on the first layer's thirds (the actor's in place over its own residual), the policy logits on the
-            #   reward head's dead second layer.
-            assert 3 * h <= 2 * H
-            Y1, Y0 = H, 2 * H
+            #   [0, H) X state | [H, 2H) Y1 | [2H, 3H) Y0 = the next hidden state | [3H, 3H + h) E
+            # After the dynamics net the three head chains (reward R, actor A, value V: h1 -> h2 -> h3 (-> policy)) are
+            # independent, and a 256-column layer occupies only half the waves of a 16 x 2 workgroup: instead of one layer
+            # per barrier the chains are staggered so that between two barriers both halves stream --
+            #   pass   h1R | h1A                      Y0 -> Z = [0, 2h)        (all waves; stores the hidden state)
+            #   S1     h1V            || h2R, h2A     Y0 -> [2h, 3h);  Z thirds -> Tr = [3h, 4h), Ta = E
+            #   S2     h2V, h3R       || h3A          [2h, 3h) -> Tv = Y0's first h;  Tr -> [0, h);  Ta -> [h, 2h) in place (+ residual)
+            #   S3     h3V            || policy       Tv -> [2h, 3h);  [h, 2h) -> Tr
+            assert 3 * h <= 2 * H and 4 * h <= 2 * H and 2 * H + h <= 3 * H
+            Y1, Y0, E = H, 2 * H, 3 * H
             Z = X
+            wr1, br1 = _fold(rw[0], rw[1])
+            wa1, ba1 = _fold(ac[0], ac[1])
+            wv1, bv1 = _fold(va[0], va[1])
             add_dense(w1s, b1, H, X, Y0, relu=True, barrier=False, act_w=w1a)
             add_dense(w2, b2, H, Y0, Y1, relu=True)
             add_dense(w3, b3, H, Y1, Y0, relu=True, res_off=X)
-            add_dense(wh, bh, H, Y0, Z, relu=True, store_hidden=True)
-            Tr, Ta, Tv = Z + 3 * h, Z + 4 * h, Z + 5 * h
-            heads2 = [(_fold(rw[3], rw[4]), Z, Tr), (_fold(ac[3].fc1, ac[3].bn1), Z + h, Ta), (_fold(va[3], va[4]), Z + 2 * h, Tv)]
-            first = True
-            for (w, b), src, dst in heads2:
-                add_dense(w, b, h, src, dst, relu=True, barrier=first)
-                first = False
-            R3, U, V3 = Z, Z + h, Z + 2 * h                 # reward logits | actor hidden | value logits
+            add_dense(torch.cat([wr1, wa1], 0), torch.cat([br1, ba1], 0), H, Y0, Z, relu=True, store_hidden=True)
+            Tr, Ta, Tv = Z + 3 * h, E, Y0
+            wr2, br2 = _fold(rw[3], rw[4])
+            wa2, ba2 = _fold(ac[3].fc1, ac[3].bn1)
+            wv2, bv2 = _fold(va[3], va[4])
             wr3, br3 = _fold(rw[6])
             wa3, ba3 = _fold(ac[3].fc2, ac[3].bn2)
             wv3, bv3 = _fold(va[6])
-            add_dense(wr3, br3, h, Tr, R3, relu=False, barrier=True)
-            add_dense(wa3, ba3, h, Ta, U, relu=True, res_off=Z + h, barrier=False)  # (in place: a lane reads the residual
-            add_dense(wv3, bv3, h, Tv, V3, relu=False, barrier=False)               #  element it then overwrites)
             wp4, bp4 = _fold(ac[4])
-            add_dense(wp4, bp4, h, U, Tr, relu=False, barrier=True)
-            off_r, off_v, off_p, width = R3, V3, Tr, max(3 * H, Z + 6 * h)
+            R3, U, V3 = Z, Z + h, Z + 2 * h                 # reward logits | actor hidden | value logits
+            self.add_stage([[(wv1, bv1, H, Y0, Z + 2 * h, True, None)],
+                            [(wr2, br2, h, Z, Tr, True, None), (wa2, ba2, h, Z + h, Ta, True, None)]])
+            self.add_stage([[(wv2, bv2, h, Z + 2 * h, Tv, True, None), (wr3, br3, h, Tr, R3, False, None)],
+                            [(wa3, ba3, h, Ta, U, True, Z + h)]])  # (in place: a lane reads the residual element it then overwrites)
+            self.add_stage([[(wv3, bv3, h, Tv, V3, False, None)],
+                            [(wp4, bp4, h, U, Tr, False, None)]])
+            off_r, off_v, off_p, width = R3, V3, Tr, max(3 * H + h, Z + 6 * h)
         else:      # DynamicNet + 2-layer heads (model.py:61-91, 138-149)
             Z = Y1
             add_dense(w1s, b1, H, X, Y0, relu=True, res_off=X, barrier=False, act_w=w1a)
