@@ -107,7 +107,7 @@ extern "C" int hz_mlp_profile_read_passes(unsigned long long* host) {
 // The input rows of a workgroup: gathered here from state_src (STAGE_GATHER), or handed over by the caller's waves in
 // registers (STAGE_REGS: wave w holds rows w, 16 + w, ..; lane l its l-th 16-B chunk in row_frag[rt].v[l / 64]; NW == 16) and
 // written into the image here, after the weight ring has been started -- the rows' load latency hides under it.
-enum { STAGE_GATHER = 0, STAGE_REGS = 1 };
+enum { STAGE_GATHER = 0, STAGE_REGS = 1, STAGE_REGS_HALF = 2 };
 struct RowFrag {
   uint4 v[2];
 };
@@ -121,7 +121,7 @@ __device__ __forceinline__ void mlp_body(
     float* __restrict__ out_value, float* __restrict__ out_policy, int n_rows, uint16_t* lds, int row0,
     const RowFrag* row_frag) {
   constexpr int NTHR = 64 * NW;
-  constexpr bool PRESTAGED = STAGE == STAGE_REGS;
+  constexpr bool PRESTAGED = STAGE != STAGE_GATHER;
   constexpr int MT = 16 * RT;
   // (opaque to the optimiser: inside a caller's loop -- the simulations of the persistent search kernel -- everything
   // derived from the thread index would otherwise be hoisted out of that loop, kept alive across the other phases and,
@@ -204,6 +204,14 @@ __device__ __forceinline__ void mlp_body(
       for (int u = 0; u < 2; ++u)
         if (lane + 64 * u < chunks)
           *reinterpret_cast<uint4*>(lds + (size_t)(16 * rt + wave) * rs + H.state_off + (lane + 64 * u) * 8) = row_frag[rt].v[u];
+  }
+  if (STAGE == STAGE_REGS_HALF) {  // wave w holds row w in lanes 0-31 and row 16 + w in lanes 32-63: lane l of a half
+    static_assert(STAGE != STAGE_REGS_HALF || (NW == 16 && RT == 2), "two rows per wave");  // its chunks l and 32 + l
+    const int hl = lane & 31, hrow = 16 * (lane >> 5) + wave;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      if (hl + 32 * u < chunks)
+        *reinterpret_cast<uint4*>(lds + (size_t)hrow * rs + H.state_off + (hl + 32 * u) * 8) = row_frag[0].v[u];
   }
   __syncthreads();
   int act[RT];  // (read after the barrier: in STAGE_REGS mode the caller's waves have only just written them)

@@ -11,6 +11,7 @@
 #include "hz_mlp_dev.h"
 #include "hz_search.h"
 #include "hz_tree_dev.h"
+#include "hz_tree_half_dev.h"
 
 struct SearchArgs {
   const hz_mlp_job_t* jobs;
@@ -224,12 +225,113 @@ __global__ __launch_bounds__(1024, 1) void k_search(TreeView tv, hz_mlp_header_t
 #endif
 }
 
+// 32 trees per workgroup, the two trees of a wave side by side in its two 32-lane halves (hz_tree_half_dev.h; A <= 32,
+// hidden <= 512): the tree phase of a simulation costs one tree's instruction stream, not two.
+__global__ __launch_bounds__(1024, 1) void k_search_half(TreeView tv, hz_mlp_header_t H, SearchArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+  constexpr int MT = 32;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int row0 = blockIdx.x * MT;
+  SearchLds L;
+  L.image = lds;
+  L.exp_s = reinterpret_cast<uint64_t*>(lds + (size_t)MT * H.row_stride);
+  L.prec_s = reinterpret_cast<float4*>(L.exp_s + 32);
+  L.path_s = reinterpret_cast<int32_t*>(L.prec_s + MT * (tv.S + 1));
+  L.lds_q = reinterpret_cast<float*>(L.path_s + MT * (tv.S + 1));
+  L.act_s = reinterpret_cast<int32_t*>(L.lds_q + MT * tv.S);
+  if (threadIdx.x < 32) L.exp_s[threadIdx.x] = hz_exp2f_tab[threadIdx.x];
+  __syncthreads();
+  HalfLane q;
+  HalfTree t;
+  float pbc_reg, sqrt_reg;
+  float4 root_row = make_float4(0.f, 0.f, 0.f, 0.f);
+  RowFrag rows;
+  rows.v[0] = rows.v[1] = make_uint4(0u, 0u, 0u, 0u);
+  float mn = 0.0f, mx = 0.0f;
+  // (everything lane-derived is rebuilt from an opaque lane index wherever a phase starts: see k_search)
+#define HZ_HALF_SETUP(LANE)                                                              \
+  {                                                                                       \
+    q.l = (LANE) & 31; q.h = (LANE) >> 5; q.hbase = 32 * q.h;                            \
+    const int srow = 16 * q.h + wave;                                                     \
+    t.tree = row0 + srow;                                                                 \
+    t.mine = t.tree < tv.N;                                                               \
+    t.path = L.path_s + srow * (tv.S + 1);                                                \
+    t.prec = L.prec_s + srow * (tv.S + 1);                                                \
+    t.lq = L.lds_q + srow * tv.S;                                                         \
+  }
+  HZ_HALF_SETUP(lane)
+  pbc_reg = (tv.S < 64 && lane <= tv.S) ? tv.pbc_tab[lane] : 0.0f;  // the descent's per-lane tables, for the whole search
+  sqrt_reg = sqrtf((float)lane + 1.0f);
+  t.root_vsum = 0.0f; t.root_visit = 0; t.path_len = 1;
+  t.leaf_reward = t.leaf_value = t.leaf_logit = 0.0f;
+  const bool any_mine = row0 + wave < tv.N;  // (rows are filled in order: the lower half's tree exists if any does)
+  if (any_mine) {
+    if (t.mine) {
+      t.root_visit = tv.root_visit[t.tree];
+      t.root_vsum = tv.root_vsum[t.tree];
+      mn = tv.mm_min[t.tree];
+      mx = tv.mm_max[t.tree];
+      if (q.l < tv.A) root_row = tv.rec[(size_t)t.tree * tv.S * tv.A + q.l];
+    }
+    const int entry = traverse_half(tv, q, t, 0, mn, mx, root_row, pbc_reg, sqrt_reg, L.act_s + 16 * q.h + wave, a.ix, a.iy,
+                                    a.sims == 1);
+    if (t.mine) {
+      const uint4* src = reinterpret_cast<const uint4*>(a.pool + ((size_t)entry * tv.N + t.tree) * (size_t)H.hidden);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) rows.v[u] = (q.l + 32 * u) * 8 < H.hidden ? src[q.l + 32 * u] : make_uint4(0u, 0u, 0u, 0u);
+    }
+  }
+  for (int sim = 0; sim < a.sims; ++sim) {
+    mlp_body<2, 16, 2, STAGE_REGS_HALF, false>(H, a.jobs, a.wstream, a.bias, a.act_tab, a.pool, a.row_stride, nullptr,
+                                               a.plane_stride, L.act_s - row0, a.pool + (size_t)(sim + 1) * a.plane_stride,
+                                               nullptr, nullptr, nullptr, tv.N, L.image, row0, &rows);
+    __syncthreads();  // leaf outputs visible; the row image is free again
+    if (!any_mine) continue;
+    int lane_t = lane;
+    asm volatile("" : "+v"(lane_t));
+    HZ_HALF_SETUP(lane_t)
+    const bool more = sim + 1 < a.sims;
+    {  // the leaf's heads, from the row image into registers: each half's 32 lanes turn first its reward logits, then its
+      // value logits into scalars (uniform within the half); lane l takes policy logit l
+      const uint16_t* row = L.image + (size_t)(16 * q.h + wave) * H.row_stride;
+      t.leaf_reward = row32_support_to_scalar(row + H.off_reward, H.support_size, H.support_min, q.l);
+      t.leaf_value = row32_support_to_scalar(row + H.off_value, H.support_size, H.support_min, q.l);
+      float pl = 0.0f;
+      if (q.l < tv.A) {
+        pl = bf2f(row[H.off_policy + q.l]);
+        if (pl != pl) pl = 0.0f;  // core/mcts.py:48-49
+      }
+      t.leaf_logit = pl;
+    }
+    int rv, a0;
+    float4 first;
+    backprop_half(tv, q, t, sim + 1, L.exp_s, !more, mn, mx, rv, first, a0);
+    if (q.l == a0) root_row = first;
+    rows.v[0] = rows.v[1] = make_uint4(0u, 0u, 0u, 0u);
+    if (more) {
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      const int entry = traverse_half(tv, q, t, sim + 1, mn, mx, root_row, pbc_reg, sqrt_reg, L.act_s + 16 * q.h + wave, a.ix,
+                                      a.iy, sim + 2 == a.sims);
+      if (t.mine) {
+        const uint4* src = reinterpret_cast<const uint4*>(a.pool + ((size_t)entry * tv.N + t.tree) * (size_t)H.hidden);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) rows.v[u] = (q.l + 32 * u) * 8 < H.hidden ? src[q.l + 32 * u] : make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+  }
+#undef HZ_HALF_SETUP
+}
+
 // 0 = choose by the tree count (two trees per wave once one per wave would need more workgroups than the device has
 // compute units), 16 / 32 = force (tests, tools)
 static int g_search_rows_per_workgroup = 0;
+static int g_search_side_by_side = -1;  // two trees per wave: -1 = side by side in the wave's halves when possible, 0 = one after the other
 extern "C" int hz_search_set_rows_per_workgroup(int rows) {
-  HZ_REQUIRE(rows == 0 || rows == 16 || rows == 32, "hz_search_set_rows_per_workgroup: %d (0 = auto, 16 or 32)", rows);
-  g_search_rows_per_workgroup = rows;
+  HZ_REQUIRE(rows == 0 || rows == 16 || rows == 32 || rows == -32,
+             "hz_search_set_rows_per_workgroup: %d (0 = auto, 16, 32, or -32 = 32 with the trees of a wave one after the other)", rows);
+  g_search_side_by_side = rows == -32 ? 0 : -1;
+  g_search_rows_per_workgroup = rows == -32 ? 32 : rows;
   return 0;
 }
 
@@ -278,17 +380,21 @@ extern "C" int hz_search_run(hz_tree_t* t, int num_simulations, const hz_mlp_hea
   if (rows_wg == 32 && lds_for(32) > 160 * 1024 && g_search_rows_per_workgroup == 0) rows_wg = 16;
   const size_t lds_bytes = lds_for(rows_wg);
   HZ_REQUIRE(lds_bytes <= 160 * 1024, "hz_search_run: %zu B of LDS per workgroup exceed 160 KiB", lds_bytes);
-  static size_t configured[2] = {0, 0};
-  const void* fn = rows_wg == 32 ? (const void*)k_search<2> : (const void*)k_search<1>;
-  if (lds_bytes > configured[rows_wg == 32]) {
+  const bool halves = rows_wg == 32 && g_search_side_by_side != 0 && t->A <= 32 && H->hidden <= 512;
+  static size_t configured[3] = {0, 0, 0};
+  const int variant = rows_wg == 32 ? (halves ? 2 : 1) : 0;
+  const void* fn = variant == 2 ? (const void*)k_search_half : variant == 1 ? (const void*)k_search<2> : (const void*)k_search<1>;
+  if (lds_bytes > configured[variant]) {
     HZ_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    configured[rows_wg == 32] = lds_bytes;
+    configured[variant] = lds_bytes;
   }
   SearchArgs a;
   a.jobs = jobs; a.wstream = (const uint16_t*)wstream; a.bias = biases; a.act_tab = action_table;
   a.pool = (uint16_t*)pool; a.plane_stride = plane_stride; a.row_stride = row_stride;
   a.ix = ix; a.iy = iy; a.la = la; a.rew = rewards; a.val = values; a.pol = policy; a.sims = num_simulations;
-  if (rows_wg == 32)
+  if (variant == 2)
+    hipLaunchKernelGGL(k_search_half, dim3((t->N + 31) / 32), dim3(1024), lds_bytes, (hipStream_t)stream, view(t), *H, a);
+  else if (variant == 1)
     hipLaunchKernelGGL(k_search<2>, dim3((t->N + 31) / 32), dim3(1024), lds_bytes, (hipStream_t)stream, view(t), *H, a);
   else
     hipLaunchKernelGGL(k_search<1>, dim3((t->N + 15) / 16), dim3(1024), lds_bytes, (hipStream_t)stream, view(t), *H, a);

@@ -36,7 +36,9 @@ int hz_search_run(hz_tree_t* t, int num_simulations, const hz_mlp_header_t* H, c
                   float* values, float* policy, void* stream);
 
 /* Trees per workgroup of the following hz_search_run calls of this process: 0 = chosen from the tree count (default),
- * 16 or 32 = forced (tests, measurements).  The results do not depend on it. */
+ * 16 or 32 = forced (tests, measurements); with 32 the two trees of a wavefront are searched side by side in its two
+ * 32-lane halves when num_actions <= 32 and hidden <= 512, -32 forces them one after the other.  The results do not depend
+ * on any of it. */
 int hz_search_set_rows_per_workgroup(int rows);
 
 #ifdef __cplusplus

@@ -200,9 +200,10 @@ def test_persistent_search_kernel_equals_launch_per_phase(game, N, sims):
     noise = torch.rand(N, A, device="cuda", generator=g)
     noise = noise / noise.sum(1, keepdim=True)
     res = []
-    # launch per phase; one / two trees per wavefront of the persistent kernel; the library's own choice (two once the
-    # trees outnumber 16 per compute unit: the last case)
-    for persistent in (False, 16, 32, "auto"):
+    # launch per phase; one tree per wavefront of the persistent kernel; two, side by side in the wave's halves (A <= 32)
+    # or one after the other (-32; what A = 48 gets either way); the library's own choice (two once the trees outnumber
+    # 16 per compute unit: the last case)
+    for persistent in (False, 16, 32, -32, "auto"):
         check(lib.hz_search_set_rows_per_workgroup(0 if persistent == "auto" else int(persistent)), "hz_search_set_rows_per_workgroup")
         roots = cytree.Roots(N, A, sims, tie_seed=5, tree_id_base=17)
         roots.prepare(cfg.root_exploration_fraction, noise, torch.zeros(N, device="cuda"), logits0, actor.legal)

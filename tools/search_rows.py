@@ -21,7 +21,7 @@ def main():
     device = torch.device("cuda", 0)
     cfg = make_config(game, simulations=S, stack=stack, p_mcts_num=N)
     engine = bench.build_engine(cfg, torch.bfloat16, device, fused=None)
-    for rows in (16, 32):
+    for rows in (16, -32, 32):  # one tree per wave; two, one after the other; two, side by side in the halves
         check(lib.hz_search_set_rows_per_workgroup(rows), "rows")
         actor = SelfPlayActor(cfg, engine, N, seed=0, device=device, use_graph=True)
         actor._capture()
