@@ -240,11 +240,15 @@ __global__ __launch_bounds__(1024, 1) void k_search_half(TreeView tv, hz_mlp_hea
   L.path_s = reinterpret_cast<int32_t*>(L.prec_s + MT * (tv.S + 1));
   L.lds_q = reinterpret_cast<float*>(L.path_s + MT * (tv.S + 1));
   L.act_s = reinterpret_cast<int32_t*>(L.lds_q + MT * tv.S);
+  float* tab_s = reinterpret_cast<float*>(L.act_s + MT);  // the descent's tables: pb_c's log factor and sqrt(n + 1), n < 64
   if (threadIdx.x < 32) L.exp_s[threadIdx.x] = hz_exp2f_tab[threadIdx.x];
+  if (threadIdx.x < 64) {
+    tab_s[threadIdx.x] = (tv.S < 64 && (int)threadIdx.x <= tv.S) ? tv.pbc_tab[threadIdx.x] : 0.0f;
+    tab_s[64 + threadIdx.x] = sqrtf((float)threadIdx.x + 1.0f);
+  }
   __syncthreads();
   HalfLane q;
   HalfTree t;
-  float pbc_reg, sqrt_reg;
   float4 root_row = make_float4(0.f, 0.f, 0.f, 0.f);
   RowFrag rows;
   rows.v[0] = rows.v[1] = make_uint4(0u, 0u, 0u, 0u);
@@ -261,8 +265,6 @@ __global__ __launch_bounds__(1024, 1) void k_search_half(TreeView tv, hz_mlp_hea
     t.lq = L.lds_q + srow * tv.S;                                                         \
   }
   HZ_HALF_SETUP(lane)
-  pbc_reg = (tv.S < 64 && lane <= tv.S) ? tv.pbc_tab[lane] : 0.0f;  // the descent's per-lane tables, for the whole search
-  sqrt_reg = sqrtf((float)lane + 1.0f);
   t.root_vsum = 0.0f; t.root_visit = 0; t.path_len = 1;
   t.leaf_reward = t.leaf_value = t.leaf_logit = 0.0f;
   const bool any_mine = row0 + wave < tv.N;  // (rows are filled in order: the lower half's tree exists if any does)
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(1024, 1) void k_search_half(TreeView tv, hz_mlp_hea
       mx = tv.mm_max[t.tree];
       if (q.l < tv.A) root_row = tv.rec[(size_t)t.tree * tv.S * tv.A + q.l];
     }
-    const int entry = traverse_half(tv, q, t, 0, mn, mx, root_row, pbc_reg, sqrt_reg, L.act_s + 16 * q.h + wave, a.ix, a.iy,
+    const int entry = traverse_half(tv, q, t, 0, mn, mx, root_row, tab_s, L.act_s + 16 * q.h + wave, a.ix, a.iy,
                                     a.sims == 1);
     if (t.mine) {
       const uint4* src = reinterpret_cast<const uint4*>(a.pool + ((size_t)entry * tv.N + t.tree) * (size_t)H.hidden);
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(1024, 1) void k_search_half(TreeView tv, hz_mlp_hea
     rows.v[0] = rows.v[1] = make_uint4(0u, 0u, 0u, 0u);
     if (more) {
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-      const int entry = traverse_half(tv, q, t, sim + 1, mn, mx, root_row, pbc_reg, sqrt_reg, L.act_s + 16 * q.h + wave, a.ix,
+      const int entry = traverse_half(tv, q, t, sim + 1, mn, mx, root_row, tab_s, L.act_s + 16 * q.h + wave, a.ix,
                                       a.iy, sim + 2 == a.sims);
       if (t.mine) {
         const uint4* src = reinterpret_cast<const uint4*>(a.pool + ((size_t)entry * tv.N + t.tree) * (size_t)H.hidden);
@@ -375,7 +377,7 @@ extern "C" int hz_search_run(hz_tree_t* t, int num_simulations, const hz_mlp_hea
   }
   auto lds_for = [&](int mt) {
     return (size_t)mt * H->row_stride * sizeof(uint16_t) + (size_t)mt * (t->S + 1) * (16 + 4) + (size_t)mt * t->S * sizeof(float) +
-           (size_t)(mt + 2) * sizeof(float) + 32 * 8 + 256;  // (+256: slack behind the last array)
+           (size_t)(mt + 2) * sizeof(float) + 32 * 8 + 128 * sizeof(float) + 256;  // (+256: slack behind the last array)
   };
   if (rows_wg == 32 && lds_for(32) > 160 * 1024 && g_search_rows_per_workgroup == 0) rows_wg = 16;
   const size_t lds_bytes = lds_for(rows_wg);

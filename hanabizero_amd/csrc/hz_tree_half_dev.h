@@ -90,7 +90,7 @@ struct HalfTree {
 // traverse_body<true> for two trees.  `publish` (uniform): store the bookkeeping scalars the read-outs use.
 // Returns this half's leaf parent entry; its action goes to *la_slot (LDS, per half).
 __device__ __forceinline__ int traverse_half(const TreeView& tv, const HalfLane& q, HalfTree& t, int sim, float mn, float mx,
-                                             float4 root_row, float pbc_reg, float sqrt_reg, int32_t* la_slot, int32_t* ix,
+                                             float4 root_row, const float* tab /* LDS: [64] pb_c log factors, [64] sqrt(n + 1) */, int32_t* la_slot, int32_t* ix,
                                              int32_t* iy, bool publish) {
   const int A = tv.A, S = tv.S;
   const bool on = q.l < A;
@@ -136,8 +136,8 @@ __device__ __forceinline__ int traverse_half(const TreeView& tv, const HalfLane&
     is_root = false;
     parent_q = mean_q;
     const bool tab_in_regs = S < 64;
-    float pb_c = tab_in_regs ? hh_lookup_f(pbc_reg, pvc) : tv.pbc_tab[pvc];
-    const float sq = tab_in_regs ? hh_lookup_f(sqrt_reg, pvc) : sqrtf((float)pvc + 1.0f);
+    float pb_c = tab_in_regs ? tab[pvc] : tv.pbc_tab[pvc];
+    const float sq = tab_in_regs ? tab[64 + pvc] : sqrtf((float)pvc + 1.0f);
     pb_c = pb_c * (sq / (float)(visit + 1));
     const float prior_score = pb_c * prior;
     float vs = (visit == 0) ? mean_q : qsa;
