@@ -24,7 +24,7 @@ def ref_select_action(visit_counts, legal, u):
     return a, ent, visit_counts
 
 
-def make(game, N, sims, stack, dtype, use_graph, seed=3):
+def make(game, N, sims, stack, dtype, use_graph, seed=3, peaked=False):
     from hanabizero_amd.config import make_config
     from hanabizero_amd.model import InferenceEngine
     from hanabizero_amd.selfplay import SelfPlayActor
@@ -32,6 +32,13 @@ def make(game, N, sims, stack, dtype, use_graph, seed=3):
     cfg = make_config(game, simulations=sims, stack=stack, p_mcts_num=N)
     net = cfg.get_uniform_network()
     net.load_state_dict({k: torch.from_numpy(v) for k, v in fill_state_dict(net.state_dict()).items()})
+    if peaked:  # a policy head that all but always proposes one action and constant values / rewards: every simulation
+        with torch.no_grad():  # extends one chain (deep paths)
+            net._prediction_actor[-1].weight.zero_()   # (the same logits at every node)
+            net._prediction_actor[-1].bias[5] += 40.0  # (play card 0: legal in every position)
+            for head in (net._prediction_value, net._dynamics_reward):
+                head[-1].weight.zero_()
+                head[-1].bias.zero_()
     net.eval()
     eng = InferenceEngine(net, cfg.value_support.max, dtype=dtype, device="cuda")
     return cfg, eng, SelfPlayActor(cfg, eng, N, seed=seed, use_graph=use_graph)
@@ -184,16 +191,17 @@ def test_select_action_kernel_edge_cases():
     assert act.tolist() == [10, 0, -1, 1, 0]
 
 
-@pytest.mark.parametrize("game,N,sims", [("Hanabi-Small", 100, 12), ("Hanabi-Full", 50, 50), ("Hanabi-Full", 1000, 20),
-                                         ("Hanabi-Full-5p", 70, 30), ("Hanabi-Full", 4170, 8)])
-def test_persistent_search_kernel_equals_launch_per_phase(game, N, sims):
+@pytest.mark.parametrize("game,N,sims,peaked", [("Hanabi-Small", 100, 12, False), ("Hanabi-Full", 50, 50, False),
+                                                ("Hanabi-Full", 1000, 20, False), ("Hanabi-Full-5p", 70, 30, False),
+                                                ("Hanabi-Full", 4170, 8, False), ("Hanabi-Full", 45, 50, True)])
+def test_persistent_search_kernel_equals_launch_per_phase(game, N, sims, peaked):
     """hz_search_run (all simulations in one persistent kernel, a workgroup per 16 trees) against the launch-per-phase
     search (hz_tree_traverse -> hz_mlp_recurrent -> hz_tree_backprop_traverse ...): bit-identical trees, hidden-state
     pools and leaf outputs; the launch-per-phase path itself is pinned to the oracle by the tests above."""
     from hanabizero_amd import cytree
     from hanabizero_amd._lib import check, lib
     from hanabizero_amd.mcts import MCTS
-    cfg, eng, actor = make(game, N, sims, 2, torch.bfloat16, use_graph=False)
+    cfg, eng, actor = make(game, N, sims, 2, torch.bfloat16, use_graph=False, peaked=peaked)
     A = cfg.action_space_size
     g = torch.Generator(device="cuda").manual_seed(N)
     value0, logits0, hidden0 = actor.root_inference()
@@ -206,7 +214,7 @@ def test_persistent_search_kernel_equals_launch_per_phase(game, N, sims):
     for persistent in (False, 16, 32, -32, "auto"):
         check(lib.hz_search_set_rows_per_workgroup(0 if persistent == "auto" else int(persistent)), "hz_search_set_rows_per_workgroup")
         roots = cytree.Roots(N, A, sims, tie_seed=5, tree_id_base=17)
-        roots.prepare(cfg.root_exploration_fraction, noise, torch.zeros(N, device="cuda"), logits0, actor.legal)
+        roots.prepare(0.0 if peaked else cfg.root_exploration_fraction, noise, torch.zeros(N, device="cuda"), logits0, actor.legal)
         pool = torch.zeros(sims, N, eng.H, dtype=eng.dtype, device="cuda")
         MCTS(cfg, persistent=bool(persistent)).run_multi(roots, eng, hidden0, pool=pool)
         torch.cuda.synchronize()
@@ -219,6 +227,8 @@ def test_persistent_search_kernel_equals_launch_per_phase(game, N, sims):
         assert torch.equal(a[3][0], b[3][0]) and torch.equal(a[3][1], b[3][1])
         assert torch.equal(a[5], b[5])
     assert int(a[0].sum()) == N * (sims - 1)
+    if peaked:  # paths longer than the 32 lanes a tree has in the side-by-side kernel: its backup runs in two chunks
+        assert int(a[4].max()) > 34, int(a[4].max())
 
 
 def test_packed_drain_equals_drain():
