@@ -148,11 +148,39 @@ class GameHistory:  # core/game.py:49-214
 
     # -- replay ingest: packed GPU record -> reference-shaped history --------------------------------------
     @classmethod
+    def from_arrays(cls, action_space, config, actions, rewards, child_visits, root_values, legal_actions, frames):
+        """A finished history from whole arrays: what init() + T x (store_search_stats, append) + game_over() leave behind
+        (selfplay_worker.py:216-228, 300-308), without the move-by-move Python.  frames [T+1, D] (0/1; kept in the dtype
+        given -- uint8 from the packed records, where the reference holds int64 lists), legal_actions [T+1, A] float64,
+        child_visits [T, A] float64 (already normalised), root_values [T] float64, actions / rewards [T] int64."""
+        g = cls(action_space, max_length=config.history_length, config=config)
+        g.target_values, g.target_rewards, g.target_policies = [], [], []
+        stack = config.stacked_observations
+        g.obs_history = np.concatenate((np.repeat(frames[:1], stack - 1, axis=0), frames), axis=0) if stack > 1 else np.asarray(frames)
+        g.actions, g.rewards = actions, rewards
+        g.child_visits, g.root_values = child_visits, root_values
+        g.legal_actions = legal_actions
+        return g
+
+    @classmethod
     def from_packed(cls, rec, action_space, config):
         """rec: dict produced by hanabizero_amd.selfplay.unpack_record (numpy arrays of ONE finished game):
         len, action [T], reward [T], visits [T, A] (masked counts), value [T], legal [T+1, A], obs_bits [T+1, W] u32.
         Equivalent to the history the reference actor builds move by move and then closes with game_over()
-        (selfplay_worker.py:216-228, 300-308); rewards are the raw env rewards (put() reshapes them later)."""
+        (`from_packed_stepwise` below does exactly that; tests/test_game.py compares the two); rewards are the raw env
+        rewards (put() reshapes them later)."""
+        T = int(rec["len"])
+        D = config.obs_shape // config.stacked_observations
+        frames = np.unpackbits(np.ascontiguousarray(rec["obs_bits"][:T + 1]).view(np.uint8), axis=1, bitorder="little")[:, :D]
+        counts = rec["visits"][:T].astype(np.int64)
+        return cls.from_arrays(action_space, config, rec["action"][:T].astype(np.int64), rec["reward"][:T].astype(np.int64),
+                               counts / counts.sum(1, keepdims=True), rec["value"][:T].astype(np.float64),
+                               rec["legal"][:T + 1].astype(np.float64), frames)
+
+    @classmethod
+    def from_packed_stepwise(cls, rec, action_space, config):
+        """The same history built the way the reference actor builds it, one move at a time (the specification of
+        from_packed; used by the tests)."""
         g = cls(action_space, max_length=config.history_length, config=config)
         T = int(rec["len"])
         D = config.obs_shape // config.stacked_observations
@@ -170,9 +198,14 @@ class GameHistory:  # core/game.py:49-214
 
 def reshape_turn_rewards(game_history):
     """DataWorker.put (selfplay_worker.py:32-37): r'[t] = r[t] + r[t-1] with the ORIGINAL r[t-1], in place."""
-    prev_r = game_history.rewards[0]
-    for step_id in range(1, len(game_history.rewards)):
-        cur_r = game_history.rewards[step_id] + prev_r
-        prev_r = game_history.rewards[step_id]
-        game_history.rewards[step_id] = cur_r
+    r = game_history.rewards
+    if isinstance(r, np.ndarray):
+        if len(r) > 1:
+            r[1:] = r[1:] + r[:-1].copy()
+        return game_history
+    prev_r = r[0]
+    for step_id in range(1, len(r)):
+        cur_r = r[step_id] + prev_r
+        prev_r = r[step_id]
+        r[step_id] = cur_r
     return game_history

@@ -50,14 +50,34 @@ class ReplayBuffer:
 
     def ingest_packed(self, buf, n, moves, action_space=None):
         """All games of one packed byte buffer (SelfPlayActor.drain_packed / dist.gather_packed) -> GameHistory objects
-        (GameHistory.from_packed), turn rewards reshaped as DataWorker.put does (selfplay_worker.py:32-37), stored at the
-        maximum priority (--use_max_priority, train.sh).  Returns the number of games."""
+        (the histories GameHistory.from_packed builds), turn rewards reshaped as DataWorker.put does
+        (selfplay_worker.py:32-37), stored at the maximum priority (--use_max_priority, train.sh).  Whole-buffer numpy:
+        one bit-unpack, one normalisation of the visit counts, one priority append and one look-up extension per buffer;
+        the per-game work is slicing.  Returns the number of games."""
         cfg = self.config
-        W = (cfg.obs_shape // cfg.stacked_observations + 31) // 32
-        rec = unpack_packed(buf, n, moves, cfg.action_space_size, W)
+        A, D = cfg.action_space_size, cfg.obs_shape // cfg.stacked_observations
+        rec = unpack_packed(buf, n, moves, A, (D + 31) // 32)
+        lens = rec["meta"][:, 0].astype(np.int64)
+        start = rec["start"]
+        frames = np.unpackbits(np.ascontiguousarray(rec["obs"]).view(np.uint8), axis=1, bitorder="little")[:, :D]
+        counts = rec["visits"].astype(np.int64)
+        visits = counts / counts.sum(1, keepdims=True)
+        values = rec["value"].astype(np.float64)
+        legal = rec["legal"].astype(np.float64)
+        actions = rec["action"].astype(np.int64)
+        raw = rec["reward"].astype(np.int64)
+        rewards = raw.copy()                      # DataWorker.put: r'[t] = r[t] + r[t-1] inside a game
+        rewards[1:] += raw[:-1]
+        rewards[start] = raw[start]
+        max_prio = self.priorities.max() if self.buffer else 1
+        first = self.base_idx + len(self.buffer)
         for i in range(n):
-            g = reshape_turn_rewards(GameHistory.from_packed(unpack_record(rec, i), action_space, cfg))
-            self.save_game(g, True, 0, None)
+            s, T = int(start[i]), int(lens[i])
+            self.buffer.append(GameHistory.from_arrays(action_space, cfg, actions[s:s + T], rewards[s:s + T], visits[s:s + T],
+                                                       values[s:s + T], legal[s + i:s + i + T + 1], frames[s + i:s + i + T + 1]))
+        self._eps_collected += n
+        self.priorities = np.concatenate((self.priorities, np.full(int(lens.sum()), float(max_prio))))
+        self.game_look_up += [(first + i, pos) for i in range(n) for pos in range(int(lens[i]))]
         return n
 
     # -- sampling ------------------------------------------------------------------------------------------------

@@ -47,3 +47,49 @@ def test_from_packed_round_trip():
     assert (g.actions == rec["action"]).all() and (g.rewards == rec["reward"]).all()
     assert (np.array(g.obs(1)) == frames[0:2]).all() and len(g.obs(T, extra_len=3, padding=True)) == 5
     assert g.legal_actions.shape == (T + 1, A)
+
+
+def _same_history(a, b):
+    for k in ("obs_history", "actions", "rewards", "child_visits", "root_values", "legal_actions"):
+        x, y = np.asarray(getattr(a, k)), np.asarray(getattr(b, k))
+        assert x.shape == y.shape and np.array_equal(x, y), k
+    assert np.asarray(a.child_visits).dtype == np.float64 and np.asarray(a.root_values).dtype == np.float64
+    assert len(a) == len(b)
+
+
+def test_from_packed_equals_the_move_by_move_build_and_ingest_equals_save_game():
+    """The vectorised replay ingest (GameHistory.from_packed / from_arrays, ReplayBuffer.ingest_packed) leaves exactly
+    what the reference's move-by-move construction (init, store_search_stats + append per move, game_over), put()'s reward
+    reshape and save_game leave (core/game.py:170-200, selfplay_worker.py:32-37, replay_buffer.py:108-132)."""
+    from hanabizero_amd.replay import ReplayBuffer
+    from hanabizero_amd.selfplay import pack_records, unpack_packed, unpack_record
+    cfg = make_config("Hanabi-Small", stack=3)
+    A, D = cfg.action_space_size, cfg.obs_dim
+    W = (D + 31) // 32
+    rng = np.random.RandomState(4)
+    n, T = 37, 12
+    lens = rng.randint(1, T + 1, n)
+    rec = dict(action=rng.randint(0, A, (n, T)).astype(np.int8), reward=rng.randint(-2, 3, (n, T)).astype(np.int8),
+               value=rng.randn(n, T).astype(np.float32), visits=rng.randint(0, 9, (n, T, A)).astype(np.int16),
+               legal=rng.randint(0, 2, (n, T + 1, A)).astype(np.uint8),
+               obs=rng.randint(-2**31, 2**31 - 1, (n, T + 1, W)).astype(np.int32),
+               meta=np.stack([lens, rng.randint(0, 11, n), np.arange(n), np.zeros(n, np.int64)], 1).astype(np.int32))
+    rec["visits"][:, :, 0] += 1
+    buf, n_, moves = pack_records(rec, A, W)
+    view = unpack_packed(buf, n_, moves, A, W)
+    want = ReplayBuffer(cfg)
+    want.save_game(GameHistory.from_packed_stepwise(unpack_record(view, 0), None, cfg), True, 0, None)  # (an older game)
+    got = ReplayBuffer(cfg)
+    got.save_game(GameHistory.from_packed_stepwise(unpack_record(view, 0), None, cfg), True, 0, None)
+    for i in range(n):
+        r = unpack_record(view, i)
+        slow = GameHistory.from_packed_stepwise(r, None, cfg)
+        _same_history(GameHistory.from_packed(r, None, cfg), slow)
+        want.save_game(reshape_turn_rewards(slow), True, 0, None)
+    assert got.ingest_packed(buf, n_, moves) == n
+    assert got.size() == want.size() and got.episodes_collected() == want.episodes_collected()
+    assert np.array_equal(got.priorities, want.priorities) and got.game_look_up == want.game_look_up
+    for a, b in zip(got.buffer, want.buffer):
+        _same_history(a, b)
+    g, pos, idx, w, mt = got.prepare_batch_context(8, beta=0.4)
+    assert len(g) == 8 and all(0 <= p < len(x) for x, p in zip(g, pos))
