@@ -54,7 +54,13 @@ def scalar_loss(prediction, target):
 
 
 # ---- optimiser and schedule (core/train.py:32-51, 327-328) -------------------------------------------------------
-def make_optimizer(model, config):
+def make_optimizer(model, config, capturable=False):
+    """capturable: the fused implementation with the learning rate in a device tensor, so that a step can be captured
+    into a hipGraph (GraphedUpdate) and adjust_lr still takes effect."""
+    if capturable:
+        dev = next(model.parameters()).device
+        return torch.optim.SGD(model.parameters(), lr=torch.tensor(float(config.lr_init), device=dev), momentum=config.momentum,
+                               weight_decay=config.weight_decay, fused=True)
     return torch.optim.SGD(model.parameters(), lr=config.lr_init, momentum=config.momentum,
                            weight_decay=config.weight_decay)
 
@@ -67,7 +73,10 @@ def adjust_lr(config, optimizer, step_count):
         lr = config.lr_init * config.lr_decay_rate ** ((step_count - config.lr_warm_step) // config.lr_decay_steps)
         lr = lr if lr >= 0.0001 else 0.0001
     for group in optimizer.param_groups:
-        group["lr"] = lr
+        if isinstance(group["lr"], torch.Tensor):
+            group["lr"].fill_(lr)  # (in place: a captured step reads the tensor)
+        else:
+            group["lr"] = lr
     return lr
 
 
@@ -204,3 +213,88 @@ def update_weights(model, batch, optimizer, config, amp=torch.bfloat16):
     loss_data = (f(total_loss), f(weighted_loss), f(parts["loss"].mean()), 0, f(parts["policy_loss"].mean()),
                  f(parts["reward_loss"].mean()), f(parts["value_loss"].mean()), 0.0)
     return loss_data, new_priority.detach().cpu().numpy()
+
+
+class GraphedUpdate:
+    """update_weights with the whole step -- forward through the unrolled model, backward, gradient clipping, SGD -- captured
+    once into a hipGraph and replayed per batch: eager PyTorch spends the step launching ~1.5 k small kernels.
+    Same arithmetic as update_weights (it captures compute_losses and the same optimiser calls); the optimiser must come
+    from make_optimizer(model, config, capturable=True).  Batches must have the captured batch size.
+
+        step = GraphedUpdate(model, optimizer, config, batch_size)
+        loss_data, new_priority = step(batch)        # same returns as update_weights"""
+
+    def __init__(self, model, optimizer, config, batch_size, amp=torch.bfloat16):
+        self.model, self.optimizer, self.config, self.amp = model, optimizer, config, amp
+        dev = next(model.parameters()).device
+        B, U, A, stack = int(batch_size), config.num_unroll_steps, config.action_space_size, config.stacked_observations
+        D = config.obs_shape // stack
+        z = lambda *shape, dtype=torch.float32: torch.zeros(shape, dtype=dtype, device=dev)
+        self.obs, self.action = z(B, stack, D), z(B, U, dtype=torch.long)
+        self.target_reward, self.target_value, self.target_policy = z(B, U), z(B, U + 1), z(B, U + 1, A)
+        self.target_policy[:] = 1.0 / A
+        self.weights = z(B) + 1.0
+        self.out = z(7)
+        self.priority = z(B)
+        self._graph = None
+
+    def _body(self):
+        cfg = self.config
+        weighted_loss, parts = compute_losses(self.model, cfg, self.obs, self.action, self.target_reward, self.target_value,
+                                              self.target_policy, self.weights, amp=self.amp)
+        total_loss = weighted_loss
+        gradient_scale = 1.0 / cfg.num_unroll_steps
+        total_loss.register_hook(lambda grad: grad * gradient_scale)
+        self.optimizer.zero_grad(set_to_none=False)
+        total_loss.backward()
+        torch.nn.utils.clip_grad_norm_(self.model.parameters(), cfg.max_grad_norm, foreach=True)
+        self.optimizer.step()
+        r = cfg.priority_reward_ratio
+        self.priority.copy_((1 - r) * (parts["value_priority"] + cfg.prioritized_replay_eps) + r * parts["reward_priority"])
+        self.out.copy_(torch.stack([total_loss.detach(), weighted_loss.detach(), parts["loss"].detach().mean(),
+                                    parts["policy_loss"].detach().mean(), parts["reward_loss"].detach().mean(),
+                                    parts["value_loss"].detach().mean(), total_loss.detach() * 0]))
+
+    def _capture(self):
+        self.model.train()
+        # warm-up on a side stream (allocations, autotuning, momentum buffers) with the state put back afterwards
+        saved = [p.detach().clone() for p in self.model.parameters()]
+        saved_buf = [b.detach().clone() for b in self.model.buffers()]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                self._body()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            for p, q in zip(self.model.parameters(), saved):
+                p.copy_(q)
+            for b, q in zip(self.model.buffers(), saved_buf):
+                b.copy_(q)
+            for st in self.optimizer.state.values():
+                if st.get("momentum_buffer") is not None:
+                    st["momentum_buffer"].zero_()  # (a zero buffer gives the first real step what a missing one gives it)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            self._body()
+        self._graph = g
+        # the capture itself does not execute: nothing to undo
+
+    def __call__(self, batch):
+        (obs_batch_ori, action_batch, mask_batch, indices, weights, make_time), (target_reward, target_value, target_policy) = batch
+        cfg = self.config
+        if self._graph is None:
+            self._capture()
+        dev = self.obs.device
+        self.obs.copy_(_t(obs_batch_ori, dev)[:, 0:cfg.stacked_observations, :], non_blocking=True)
+        self.action.copy_(_t(action_batch, dev, torch.long), non_blocking=True)
+        self.target_reward.copy_(_t(target_reward, dev)[:, :cfg.num_unroll_steps], non_blocking=True)
+        self.target_value.copy_(_t(target_value, dev), non_blocking=True)
+        self.target_policy.copy_(_t(target_policy, dev), non_blocking=True)
+        self.weights.copy_(_t(weights, dev), non_blocking=True)
+        self._graph.replay()
+        o = self.out.cpu().numpy()  # the one host round trip of a step
+        loss_data = (float(o[0]), float(o[1]), float(o[2]), 0, float(o[3]), float(o[4]), float(o[5]), 0.0)
+        return loss_data, self.priority.cpu().numpy()
+

@@ -180,6 +180,34 @@ def test_bf16_learner_step_on_gpu_and_weights_reach_the_engine():
     assert torch.isfinite(h.float()).all() and p.shape == (64, cfg.action_space_size)
 
 
+@pytest.mark.gpu
+def test_graphed_learner_step_equals_eager_steps():
+    """GraphedUpdate (the whole learner step as one hipGraph replay, fused SGD with the learning rate in a device tensor)
+    walks the same trajectory as update_weights: same losses, same priorities, same weights after several steps with a
+    changing learning rate, within bf16-autocast noise between the fused and the foreach optimiser kernels."""
+    import copy
+    from hanabizero_amd.learner import GraphedUpdate, adjust_lr, make_optimizer, update_weights
+    cfg = _cfg("Hanabi-Full", stack=4)
+    cfg.lr_init, cfg.lr_warm_step = 0.05, 4
+    torch.manual_seed(0)
+    net_a = cfg.get_uniform_network().cuda()
+    net_b = copy.deepcopy(net_a)
+    opt_a = make_optimizer(net_a, cfg)
+    opt_b = make_optimizer(net_b, cfg, capturable=True)
+    step_b = GraphedUpdate(net_b, opt_b, cfg, 32)
+    batches = [_batch(cfg, 32, s) for s in range(3)]
+    for it in range(8):
+        adjust_lr(cfg, opt_a, it + 1)
+        adjust_lr(cfg, opt_b, it + 1)
+        la, pa = update_weights(net_a, batches[it % 3], opt_a, cfg, amp=torch.bfloat16)
+        lb, pb = step_b(batches[it % 3])
+        assert np.allclose(la[:7], lb[:7], rtol=2e-2, atol=2e-3), (it, la, lb)
+        assert np.allclose(pa, pb, rtol=5e-2, atol=5e-3)
+    for (k, a), b in zip(net_a.state_dict().items(), net_b.state_dict().values()):
+        assert torch.allclose(a.float(), b.float(), rtol=2e-2, atol=2e-3), k
+    assert float(opt_b.param_groups[0]["lr"]) == pytest.approx(0.05)
+
+
 def test_replay_buffer_bookkeeping():
     from hanabizero_amd.replay import ReplayBuffer
     cfg = _cfg()

@@ -20,7 +20,7 @@ import bench  # noqa: E402
 from hanabizero_amd.config import make_config  # noqa: E402
 from hanabizero_amd.dist import gather_packed  # noqa: E402
 from hanabizero_amd.evaluate import test as run_test  # noqa: E402
-from hanabizero_amd.learner import make_batch, make_optimizer, update_weights  # noqa: E402
+from hanabizero_amd.learner import GraphedUpdate, make_batch, make_optimizer, update_weights  # noqa: E402
 from hanabizero_amd.reanalyze import prepare_policy_re  # noqa: E402
 from hanabizero_amd.replay import ReplayBuffer  # noqa: E402
 from hanabizero_amd.selfplay import SelfPlayActor  # noqa: E402
@@ -78,6 +78,11 @@ def main():
     out["make_batch_256"] = {"ms": 1e3 * (time.perf_counter() - t0), "note": "host assembly + one target-model inference"}
     dt = timed(lambda: update_weights(learner, batch, opt, cfg, amp=torch.bfloat16), 10)
     out["update_weights_256"] = {"ms": 1e3 * dt, "steps_per_s": 1 / dt, "samples_per_s": cfg.batch_size / dt}
+    learner2 = cfg.get_uniform_network().to(device)
+    graphed = GraphedUpdate(learner2, make_optimizer(learner2, cfg, capturable=True), cfg, cfg.batch_size)
+    dt = timed(lambda: graphed(batch), 20)
+    out["graphed_update_256"] = {"ms": 1e3 * dt, "steps_per_s": 1 / dt, "samples_per_s": cfg.batch_size / dt,
+                                 "note": "the same step as one hipGraph replay (learner.GraphedUpdate), incl. the H2D copy of the batch"}
     del actor
 
     # f-4: evaluation
