@@ -366,15 +366,11 @@ __global__ __launch_bounds__(256) void k_actor_pack(PackTable pt, const int32_t*
 
 // one wave per env: trajectory heads and the model's input window
 template <typename U>
-__global__ __launch_bounds__(256) void k_actor_begin_move(hz_actor_bufs_t b, const uint8_t* __restrict__ done,
-                                                          const int32_t* __restrict__ packed,
-                                                          const uint8_t* __restrict__ legal,
-                                                          const uint8_t* __restrict__ newest, long long newest_row_bytes,
-                                                          uint8_t* __restrict__ stack_buf, long long stack_row_bytes,
-                                                          int stack, long long obs_bytes) {
-  const int lane = threadIdx.x & 63;
-  const int env = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (env >= b.num_envs) return;
+__device__ __forceinline__ void actor_begin_move_wave(const hz_actor_bufs_t& b, int env, int lane, const uint8_t* __restrict__ done,
+                                                      const int32_t* __restrict__ packed, const uint8_t* __restrict__ legal,
+                                                      const uint8_t* __restrict__ newest, long long newest_row_bytes,
+                                                      uint8_t* __restrict__ stack_buf, long long stack_row_bytes, int stack,
+                                                      long long obs_bytes) {
   const int A = b.num_actions, T = b.max_moves, W = b.packed_words;
   const bool d = done[env] != 0;
   const int t0 = d ? 0 : actor_t(b, env) + 1;
@@ -395,6 +391,19 @@ __global__ __launch_bounds__(256) void k_actor_begin_move(hz_actor_bufs_t b, con
     U* dst = row + (size_t)k * n;
     for (long long i = lane; i < n; i += 64) dst[i] = src[i];
   }
+}
+
+template <typename U>
+__global__ __launch_bounds__(256) void k_actor_begin_move(hz_actor_bufs_t b, const uint8_t* __restrict__ done,
+                                                          const int32_t* __restrict__ packed,
+                                                          const uint8_t* __restrict__ legal,
+                                                          const uint8_t* __restrict__ newest, long long newest_row_bytes,
+                                                          uint8_t* __restrict__ stack_buf, long long stack_row_bytes,
+                                                          int stack, long long obs_bytes) {
+  const int lane = threadIdx.x & 63;
+  const int env = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (env >= b.num_envs) return;
+  actor_begin_move_wave<U>(b, env, lane, done, packed, legal, newest, newest_row_bytes, stack_buf, stack_row_bytes, stack, obs_bytes);
 }
 
 #define HZ_ACTOR_CHECK(b, who)                                                                                      \
@@ -558,14 +567,10 @@ __device__ double gamma_draw(CounterRng& g, double alpha) {  // Marsaglia & Tsan
   return out;
 }
 
-// one wave per env, lane = action
-__global__ __launch_bounds__(256) void k_actor_draw(uint64_t seed, long long env_id_base, long long* __restrict__ move_count,
-                                                    int N, int A, double alpha, float* __restrict__ noise,
-                                                    double* __restrict__ uniform) {
-  __shared__ double g_s[4][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int env = blockIdx.x * 4 + wave;
-  if (env >= N) return;
+// one wave per env, lane = action; g_w: 64 doubles of LDS for this wave
+__device__ __forceinline__ void actor_draw_wave(uint64_t seed, long long env_id_base, long long* __restrict__ move_count, int env,
+                                                int lane, int A, double alpha, float* __restrict__ noise,
+                                                double* __restrict__ uniform, double* g_w) {
   const long long k = move_count[env];
   const uint64_t base = mix64(mix64(seed ^ 0x68616e616269ull) + (uint64_t)(env_id_base + env)) + (uint64_t)k * 0xD1B54A32D192ED03ull;
   CounterRng g;
@@ -573,10 +578,10 @@ __global__ __launch_bounds__(256) void k_actor_draw(uint64_t seed, long long env
   g.k = 0;
   double x = 0.0;
   if (lane < A) x = gamma_draw(g, alpha);
-  g_s[wave][lane] = x;
+  g_w[lane] = x;
   __builtin_amdgcn_wave_barrier();
   double sum = 0.0;
-  for (int a = 0; a < A; ++a) sum += g_s[wave][a];  // same-wave LDS traffic is ordered; action order, like numpy
+  for (int a = 0; a < A; ++a) sum += g_w[a];  // same-wave LDS traffic is ordered; action order, like numpy
   if (lane < A) noise[(size_t)env * A + lane] = sum > 0.0 ? (float)(x / sum) : 1.0f / (float)A;
   if (lane == 0) {
     CounterRng gu;
@@ -588,6 +593,38 @@ __global__ __launch_bounds__(256) void k_actor_draw(uint64_t seed, long long env
   }
 }
 
+__global__ __launch_bounds__(256) void k_actor_draw(uint64_t seed, long long env_id_base, long long* __restrict__ move_count,
+                                                    int N, int A, double alpha, float* __restrict__ noise,
+                                                    double* __restrict__ uniform) {
+  __shared__ double g_s[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int env = blockIdx.x * 4 + wave;
+  if (env >= N) return;
+  actor_draw_wave(seed, env_id_base, move_count, env, lane, A, alpha, noise, uniform, g_s[wave]);
+}
+
+// hz_actor_begin_move and the NEXT move's hz_actor_draw in one launch: waves 0-3 of a workgroup move the windows of four
+// envs while waves 4-7 draw for the same four (the two are independent and each is bound by one wave's latency).
+template <typename U>
+__global__ __launch_bounds__(512) void k_actor_begin_move_draw(hz_actor_bufs_t b, const uint8_t* __restrict__ done,
+                                                               const int32_t* __restrict__ packed,
+                                                               const uint8_t* __restrict__ legal,
+                                                               const uint8_t* __restrict__ newest, long long newest_row_bytes,
+                                                               uint8_t* __restrict__ stack_buf, long long stack_row_bytes,
+                                                               int stack, long long obs_bytes, uint64_t seed,
+                                                               long long* __restrict__ move_count, double alpha,
+                                                               float* __restrict__ noise, double* __restrict__ uniform) {
+  __shared__ double g_s[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int env = blockIdx.x * 4 + (wave & 3);
+  if (env >= b.num_envs) return;
+  if (wave < 4)
+    actor_begin_move_wave<U>(b, env, lane, done, packed, legal, newest, newest_row_bytes, stack_buf, stack_row_bytes, stack,
+                             obs_bytes);
+  else
+    actor_draw_wave(seed, (long long)b.env_id_base, move_count, env, lane, b.num_actions, alpha, noise, uniform, g_s[wave & 3]);
+}
+
 extern "C" int hz_actor_draw(uint64_t seed, int64_t env_id_base, int64_t* move_count, int num_envs, int num_actions,
                              double alpha, float* noise, double* uniform, void* stream) {
   HZ_REQUIRE(num_envs > 0 && num_actions > 0 && num_actions <= 64, "hz_actor_draw: bad sizes N=%d A=%d", num_envs,
@@ -596,6 +633,33 @@ extern "C" int hz_actor_draw(uint64_t seed, int64_t env_id_base, int64_t* move_c
   HZ_REQUIRE(alpha > 0.0, "hz_actor_draw: alpha must be > 0");
   hipLaunchKernelGGL(k_actor_draw, dim3((num_envs + 3) / 4), dim3(256), 0, (hipStream_t)stream, seed,
                      (long long)env_id_base, (long long*)move_count, num_envs, num_actions, alpha, noise, uniform);
+  HZ_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int hz_actor_begin_move_draw(const hz_actor_bufs_t* bufs, const uint8_t* done, const int32_t* packed,
+                                        const uint8_t* legal, const void* newest, int64_t newest_row_bytes, void* stack_buf,
+                                        int64_t stack_row_bytes, int stack, int64_t obs_bytes, uint64_t seed,
+                                        int64_t* move_count, double alpha, float* noise, double* uniform, void* stream) {
+  HZ_ACTOR_CHECK(bufs, "hz_actor_begin_move_draw");
+  HZ_REQUIRE(done && packed && legal && newest && stack_buf && move_count && noise && uniform,
+             "hz_actor_begin_move_draw: NULL argument");
+  HZ_REQUIRE(stack >= 1 && obs_bytes > 0 && stack_row_bytes >= (int64_t)stack * obs_bytes && newest_row_bytes >= obs_bytes,
+             "hz_actor_begin_move_draw: bad window geometry (stack=%d obs_bytes=%lld)", stack, (long long)obs_bytes);
+  HZ_REQUIRE(alpha > 0.0, "hz_actor_begin_move_draw: alpha must be > 0");
+  const dim3 grid((bufs->num_envs + 3) / 4), block(512);
+  const uintptr_t al = (uintptr_t)newest | (uintptr_t)stack_buf | (uintptr_t)newest_row_bytes | (uintptr_t)stack_row_bytes |
+                       (uintptr_t)obs_bytes;
+#define HZ_BEGIN_MOVE_DRAW(U)                                                                                       \
+  hipLaunchKernelGGL(k_actor_begin_move_draw<U>, grid, block, 0, (hipStream_t)stream, *bufs, done, packed, legal,   \
+                     (const uint8_t*)newest, (long long)newest_row_bytes, (uint8_t*)stack_buf,                      \
+                     (long long)stack_row_bytes, stack, (long long)obs_bytes, seed, (long long*)move_count, alpha,  \
+                     noise, uniform)
+  if ((al & 15) == 0) HZ_BEGIN_MOVE_DRAW(uint4);
+  else if ((al & 3) == 0) HZ_BEGIN_MOVE_DRAW(uint32_t);
+  else if ((al & 1) == 0) HZ_BEGIN_MOVE_DRAW(uint16_t);
+  else HZ_BEGIN_MOVE_DRAW(uint8_t);
+#undef HZ_BEGIN_MOVE_DRAW
   HZ_HIP(hipGetLastError());
   return 0;
 }

@@ -116,6 +116,7 @@ class SelfPlayActor:
                               illegal_steps=self.illegal_steps.data_ptr())
         self.total_moves = 0
         self._drained = 0
+        self._drawn = False  # the coming move's noise / uniforms are already in self.noise / self.uniform
         self._graph = None
         self.use_graph = use_graph
         self.noise_seed = int(seed) & 0xFFFFFFFFFFFFFFFF
@@ -145,8 +146,11 @@ class SelfPlayActor:
                                    padded=self.Dp != self.D)
 
     def _step_body(self, draw=True):
+        """draw=True: the lock-step draws its own root noise / sampling uniforms -- the first one up front, every later
+        one at the end of the step before (in the launch that moves the observation windows); draw=False: the caller has
+        called _draw() for this move (tests)."""
         cfg, N = self.cfg, self.N
-        if draw:
+        if draw and not self._drawn:
             self._draw()
         value0, logits0, hidden0 = self.root_inference(state_out=self.pool[0])
         self.roots.prepare(cfg.root_exploration_fraction, self.noise, self.zeros_n, logits0, self.legal)
@@ -169,9 +173,18 @@ class SelfPlayActor:
         self.env.observe(out=self.newest, packed=self.tmp_packed, legal=self.legal)
         # trajectory heads + stack window: shift for running games, refill for new ones (selfplay_worker.py:237, 326-327)
         es = self.newest.element_size()
-        check(lib.hz_actor_begin_move(b, done.data_ptr(), self.tmp_packed.data_ptr(), self.legal.data_ptr(),
-                                      self.newest.data_ptr(), self.newest.stride(0) * es, self.stack_buf.data_ptr(),
-                                      self.stack_buf.stride(0) * es, self.stack, self.Dp * es, st), "hz_actor_begin_move")
+        if draw:  # ... and the next move's draws in the same launch
+            check(lib.hz_actor_begin_move_draw(b, done.data_ptr(), self.tmp_packed.data_ptr(), self.legal.data_ptr(),
+                                               self.newest.data_ptr(), self.newest.stride(0) * es, self.stack_buf.data_ptr(),
+                                               self.stack_buf.stride(0) * es, self.stack, self.Dp * es, self.noise_seed,
+                                               self.move_count.data_ptr(), float(cfg.root_dirichlet_alpha),
+                                               self.noise.data_ptr(), self.uniform.data_ptr(), st), "hz_actor_begin_move_draw")
+            self._drawn = True
+        else:
+            check(lib.hz_actor_begin_move(b, done.data_ptr(), self.tmp_packed.data_ptr(), self.legal.data_ptr(),
+                                          self.newest.data_ptr(), self.newest.stride(0) * es, self.stack_buf.data_ptr(),
+                                          self.stack_buf.stride(0) * es, self.stack, self.Dp * es, st), "hz_actor_begin_move")
+            self._drawn = False
 
     def _capture(self):
         self.roots.set_params(self.cfg.pb_c_base, self.cfg.pb_c_init, self.cfg.discount, self.cfg.value_delta_max)

@@ -111,6 +111,14 @@ int hz_actor_begin_move(const hz_actor_bufs_t* bufs, const uint8_t* done, const 
                         const void* newest, int64_t newest_row_bytes, void* stack_buf, int64_t stack_row_bytes, int stack,
                         int64_t obs_bytes, void* stream);
 
+/* hz_actor_begin_move followed by hz_actor_draw for the NEXT move (env_id_base = bufs->env_id_base) in one launch: the two
+ * are independent, each is bound by the latency of one wavefront per env, and run side by side they cost the longer of
+ * the two.  Same results as the two calls. */
+int hz_actor_begin_move_draw(const hz_actor_bufs_t* bufs, const uint8_t* done, const int32_t* packed, const uint8_t* legal,
+                             const void* newest, int64_t newest_row_bytes, void* stack_buf, int64_t stack_row_bytes, int stack,
+                             int64_t obs_bytes, uint64_t seed, int64_t* move_count, double alpha, float* noise,
+                             double* uniform, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
