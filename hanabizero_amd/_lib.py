@@ -27,6 +27,11 @@ class MlpHeader(C.Structure):  # include/hz_mlp.h hz_mlp_header_t
                 ("kstep_stride", C.c_int64), ("wave_stream_off", C.c_int64 * 16)]
 
 
+class RowsJob(C.Structure):  # include/hz_rows.h hz_rows_job_t
+    _fields_ = [("slot", C.c_void_p), ("list", C.c_void_p), ("count", C.c_void_p), ("num_arrays", C.c_int32),
+                ("max_rows", C.c_int32), ("src", C.c_void_p * 8), ("dst", C.c_void_p * 8), ("row_bytes", C.c_int64 * 8)]
+
+
 class ActorBufs(C.Structure):  # include/hz_selfplay.h hz_actor_bufs_t
     _fields_ = [(n, C.c_int32) for n in ("num_envs", "num_actions", "packed_words", "max_moves", "outbox_games",
                                          "env_id_base")] + \
@@ -70,6 +75,7 @@ def _load():
         "hz_env_destroy": [V],
         "hz_env_dims": [V, C.POINTER(I), C.POINTER(I), C.POINTER(I), C.POINTER(I)],
         "hz_env_reset": [V, V, V],
+        "hz_env_reset_rows": [V, V, C.POINTER(RowsJob), V],
         "hz_env_step": [V, V, V, V, V, V, V, V],
         "hz_env_observe": [V, I, V, I, I64, V, V, V],
         "hz_env_probe": [V, V, V],
@@ -80,6 +86,7 @@ def _load():
         "hz_actor_record_search": [C.POINTER(ActorBufs), V, V, V, V, F, I, V, V, V],
         "hz_actor_record_step": [C.POINTER(ActorBufs), V, V, V, V, V, V, V],
         "hz_actor_flush": [C.POINTER(ActorBufs), V],
+        "hz_actor_flush_job": [C.POINTER(ActorBufs), C.POINTER(RowsJob)],
         "hz_actor_pack": [C.POINTER(ActorBufs), I64, I, I64, V, V, I64, V],
         "hz_actor_begin_move": [C.POINTER(ActorBufs), V, V, V, V, I64, V, I64, I, I64, V],
         "hz_actor_begin_move_draw": [C.POINTER(ActorBufs), V, V, V, V, I64, V, I64, I, I64, U64, V, C.c_double, V, V, V],

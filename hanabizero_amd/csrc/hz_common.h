@@ -140,3 +140,17 @@ __device__ __forceinline__ float hz_expf(float x, const uint64_t* tab = hz_exp2f
   y = y * s;
   return (float)y;
 }
+
+// ---- one row of bytes moved by a whole workgroup, at the widest unit source, destination and length allow
+__device__ __forceinline__ void copy_row_block(const uint8_t* a, uint8_t* b, long long n, int tid, int nthreads) {
+  if ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)n) & 15) == 0) {
+    for (long long off = (long long)tid * 16; off < n; off += (long long)nthreads * 16)
+      *reinterpret_cast<uint4*>(b + off) = *reinterpret_cast<const uint4*>(a + off);
+  } else if ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)n) & 3) == 0) {
+    for (long long off = (long long)tid * 4; off < n; off += (long long)nthreads * 4)
+      *reinterpret_cast<uint32_t*>(b + off) = *reinterpret_cast<const uint32_t*>(a + off);
+  } else {
+    for (long long off = tid; off < n; off += nthreads) b[off] = a[off];
+  }
+
+}

@@ -414,12 +414,8 @@ __global__ __launch_bounds__(RULES_THREADS) void k_env_rules(EnvCfg g, uint32_t*
 // reference's order), and all mt19937 words of the 2 * players * hand_size draws are regenerated by the lanes in
 // parallel (every input of the recurrence is an OLD word as long as fewer than 227 are drawn: see mt_batch_begin).
 // Same state bits and the same generator state as the lane-per-env path (tests/test_hip_env.py).
-__global__ __launch_bounds__(256) void k_env_reset_wave(EnvCfg g, uint32_t* __restrict__ state, uint32_t* __restrict__ mt,
-                                                        const uint8_t* __restrict__ mask) {
-  __shared__ uint32_t st_s[4][32];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int env = blockIdx.x * 4 + wave;
+__device__ __forceinline__ void env_reset_wave_body(const EnvCfg& g, uint32_t* __restrict__ state, uint32_t* __restrict__ mt,
+                                                    const uint8_t* __restrict__ mask, int env, int lane, uint32_t* st) {
   if (env >= g.N) return;
   if (mask != nullptr && mask[env] == 0) return;
   const int ncards = g.C * g.R, deals = g.P * g.H, n = 2 * deals;
@@ -438,7 +434,6 @@ __global__ __launch_bounds__(256) void k_env_reset_wave(EnvCfg g, uint32_t* __re
   out ^= (out << 15) & 0xefc60000u;
   out ^= (out >> 18);
 
-  uint32_t* st = st_s[wave];
   if (lane < 32) st[lane] = 0u;
   int cnt = lane < ncards ? g.inst[lane % g.R] : 0;  // HanabiDeck ctor (hanabi_state.cc:53-64): lane = color * R + rank
   int total = 0;
@@ -511,6 +506,39 @@ __global__ __launch_bounds__(256) void k_env_reset_wave(EnvCfg g, uint32_t* __re
     MT(624) = (uint32_t)(idx > 624 ? idx - 624 : idx);
   }
 #undef MT
+}
+
+__global__ __launch_bounds__(256) void k_env_reset_wave(EnvCfg g, uint32_t* __restrict__ state, uint32_t* __restrict__ mt,
+                                                        const uint8_t* __restrict__ mask) {
+  __shared__ uint32_t st_s[4][32];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  env_reset_wave_body(g, state, mt, mask, blockIdx.x * 4 + wave, lane, st_s[wave]);
+}
+
+// the reset plus an independent row scatter (include/hz_rows.h) in one launch: workgroups [0, reset_blocks) reset, the rest
+// walk the job's row list, `per_array` workgroups per array (one whole workgroup per row)
+__global__ __launch_bounds__(256) void k_env_reset_rows(EnvCfg g, uint32_t* __restrict__ state, uint32_t* __restrict__ mt,
+                                                        const uint8_t* __restrict__ mask, hz_rows_job_t job, int reset_blocks,
+                                                        int per_array) {
+  __shared__ uint32_t st_s[4][32];
+  if ((int)blockIdx.x < reset_blocks) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    env_reset_wave_body(g, state, mt, mask, blockIdx.x * 4 + wave, lane, st_s[wave]);
+    return;
+  }
+  const int b = (int)blockIdx.x - reset_blocks;
+  const int k = b / per_array;
+  const long long rb = job.row_bytes[k];
+  const int n = *job.count;
+  for (int j = b % per_array; j < n; j += per_array) {
+    const int row = job.list[j];
+    const int sl = job.slot[row];
+    if (sl < 0) continue;
+    copy_row_block((const uint8_t*)job.src[k] + (size_t)row * (size_t)rb, (uint8_t*)job.dst[k] + (size_t)sl * (size_t)rb, rb,
+                   threadIdx.x, blockDim.x);
+  }
 }
 
 // ---- observation kernel: one wave per env ----------------------------------------------------------------
@@ -750,6 +778,20 @@ extern "C" int hz_env_reset(hz_env_t* e, const uint8_t* mask, void* stream) {
   // one wave per env (envs not in the mask leave at once); k_env_rules mode 0 is the lane-per-env form of the same reset
   hipLaunchKernelGGL(k_env_reset_wave, dim3((e->cfg.N + 3) / 4), dim3(256), 0, (hipStream_t)stream, e->cfg, e->state,
                      e->mt, mask);
+  HZ_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int hz_env_reset_rows(hz_env_t* e, const uint8_t* mask, const hz_rows_job_t* rows, void* stream) {
+  HZ_REQUIRE(e != nullptr && rows != nullptr, "hz_env_reset_rows: NULL argument");
+  HZ_REQUIRE(rows->num_arrays >= 1 && rows->num_arrays <= 8 && rows->max_rows >= 1 && rows->slot && rows->list && rows->count,
+             "hz_env_reset_rows: malformed rows job (%d arrays, %d rows)", rows->num_arrays, rows->max_rows);
+  for (int k = 0; k < rows->num_arrays; ++k)
+    HZ_REQUIRE(rows->src[k] && rows->dst[k] && rows->row_bytes[k] > 0, "hz_env_reset_rows: array %d of the rows job is empty", k);
+  const int reset_blocks = (e->cfg.N + 3) / 4;
+  const int per_array = rows->max_rows < 256 ? rows->max_rows : 256;
+  hipLaunchKernelGGL(k_env_reset_rows, dim3(reset_blocks + per_array * rows->num_arrays), dim3(256), 0, (hipStream_t)stream,
+                     e->cfg, e->state, e->mt, mask, *rows, reset_blocks, per_array);
   HZ_HIP(hipGetLastError());
   return 0;
 }

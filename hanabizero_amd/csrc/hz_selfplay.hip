@@ -282,18 +282,6 @@ __device__ __forceinline__ void copy_row(const uint8_t* a, uint8_t* b, long long
   }
 }
 
-__device__ __forceinline__ void copy_row_block(const uint8_t* a, uint8_t* b, long long n, int tid, int nthreads) {
-  if ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)n) & 15) == 0) {
-    for (long long off = (long long)tid * 16; off < n; off += (long long)nthreads * 16)
-      *reinterpret_cast<uint4*>(b + off) = *reinterpret_cast<const uint4*>(a + off);
-  } else if ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)n) & 3) == 0) {
-    for (long long off = (long long)tid * 4; off < n; off += (long long)nthreads * 4)
-      *reinterpret_cast<uint32_t*>(b + off) = *reinterpret_cast<const uint32_t*>(a + off);
-  } else {
-    for (long long off = tid; off < n; off += nthreads) b[off] = a[off];
-  }
-}
-
 // blockIdx.y = array; the workgroups of one array walk the list of finished envs, one whole workgroup per row
 __global__ __launch_bounds__(256) void k_actor_flush(FlushTable ft, const int32_t* __restrict__ slot,
                                                      const int32_t* __restrict__ finished,
@@ -461,6 +449,26 @@ extern "C" int hz_actor_flush(const hz_actor_bufs_t* bufs, void* stream) {
   hipLaunchKernelGGL(k_actor_flush, dim3(gx, 7), dim3(256), 0, (hipStream_t)stream, ft, bufs->slot, bufs->finished,
                      bufs->num_finished);
   HZ_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int hz_actor_flush_job(const hz_actor_bufs_t* bufs, hz_rows_job_t* job) {
+  HZ_ACTOR_CHECK(bufs, "hz_actor_flush_job");
+  HZ_REQUIRE(job != nullptr, "hz_actor_flush_job: NULL job");
+  HZ_REQUIRE(bufs->out_action && bufs->out_reward && bufs->out_value && bufs->out_visits && bufs->out_legal &&
+                 bufs->out_obs && bufs->out_meta, "hz_actor_flush_job: NULL outbox array");
+  const long long A = bufs->num_actions, W = bufs->packed_words, T = bufs->max_moves;
+  const void* src[7] = {bufs->action, bufs->reward, bufs->value, bufs->visits, bufs->legal, bufs->obs, bufs->meta};
+  void* dst[7] = {bufs->out_action, bufs->out_reward, bufs->out_value, bufs->out_visits, bufs->out_legal, bufs->out_obs,
+                  bufs->out_meta};
+  const long long rb[7] = {T, T, 4 * T, 2 * T * A, (T + 1) * A, 4 * (T + 1) * W, 16};
+  job->slot = bufs->slot; job->list = bufs->finished; job->count = bufs->num_finished;
+  job->num_arrays = 7; job->max_rows = bufs->num_envs;
+  for (int k = 0; k < 8; ++k) {
+    job->src[k] = k < 7 ? src[k] : nullptr;
+    job->dst[k] = k < 7 ? dst[k] : nullptr;
+    job->row_bytes[k] = k < 7 ? rb[k] : 0;
+  }
   return 0;
 }
 

@@ -67,10 +67,15 @@ class HanabiVecEnv:
     def hbm_bytes(self):
         return int(lib.hz_env_hbm_bytes(self._h))
 
-    def reset(self, mask=None):
-        """mask: None (all) or uint8/bool CUDA tensor [N]."""
+    def reset(self, mask=None, rows=None):
+        """mask: None (all) or uint8/bool CUDA tensor [N].  rows: optional _lib.RowsJob (include/hz_rows.h), an independent
+        row scatter the same launch carries along (hz_env_reset_rows)."""
         m = None if mask is None else self._mask(mask)
-        check(lib.hz_env_reset(self._h, None if m is None else m.data_ptr(), _stream()), "hz_env_reset")
+        if rows is not None:
+            import ctypes as C
+            check(lib.hz_env_reset_rows(self._h, None if m is None else m.data_ptr(), C.byref(rows), _stream()), "hz_env_reset_rows")
+        else:
+            check(lib.hz_env_reset(self._h, None if m is None else m.data_ptr(), _stream()), "hz_env_reset")
 
     def _mask(self, mask):
         m = mask if isinstance(mask, torch.Tensor) else torch.as_tensor(np.asarray(mask), device=self.device)

@@ -29,7 +29,7 @@ import numpy as np
 import torch
 
 from . import cytree
-from ._lib import ActorBufs, check, lib
+from ._lib import ActorBufs, RowsJob, check, lib
 from .hanabi_env import HanabiVecEnv
 from .mcts import MCTS
 
@@ -114,6 +114,8 @@ class SelfPlayActor:
                               out_count=self.out_count.data_ptr(), slot=self.slot.data_ptr(),
                               finished=self.finished.data_ptr(), num_finished=self.num_finished.data_ptr(),
                               illegal_steps=self.illegal_steps.data_ptr())
+        self.flush_job = RowsJob()  # hz_actor_flush as data: the masked reset of every lock-step carries it (hz_env_reset_rows)
+        check(lib.hz_actor_flush_job(C.byref(self.bufs), C.byref(self.flush_job)), "hz_actor_flush_job")
         self.total_moves = 0
         self._drained = 0
         self._drawn = False  # the coming move's noise / uniforms are already in self.noise / self.uniform
@@ -166,10 +168,10 @@ class SelfPlayActor:
         self.env.observe_packed(self.tmp_packed, self.tmp_legal)
         check(lib.hz_actor_record_step(b, reward.data_ptr(), done.data_ptr(), score.data_ptr(), status.data_ptr(),
                                        self.tmp_packed.data_ptr(), self.tmp_legal.data_ptr(), st), "hz_actor_record_step")
-        check(lib.hz_actor_flush(b, st), "hz_actor_flush")  # finished games -> outbox ring
-        # reset finished envs (selfplay_worker.py:230-240) and take everybody's current observation
+        # finished games -> outbox ring (hz_actor_flush), in the launch that resets the finished envs
+        # (selfplay_worker.py:230-240); then everybody's current observation
         # (tried: flush and the draws as parallel graph branches -- the cross-queue dependencies cost what the overlap saves)
-        self.env.reset(done)
+        self.env.reset(done, rows=self.flush_job)
         self.env.observe(out=self.newest, packed=self.tmp_packed, legal=self.legal)
         # trajectory heads + stack window: shift for running games, refill for new ones (selfplay_worker.py:237, 326-327)
         es = self.newest.element_size()

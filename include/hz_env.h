@@ -25,6 +25,8 @@
 
 #include <stdint.h>
 
+#include "hz_rows.h"
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -46,6 +48,10 @@ int hz_env_dims(const hz_env_t* e, int* num_moves, int* obs_len, int* own_hand_l
 
 /* mask [N] u8 (device) or NULL = all envs.  RNG state carries over, as rl_env.py:249 reuses self.game. */
 int hz_env_reset(hz_env_t* e, const uint8_t* mask, void* stream);
+/* hz_env_reset plus an independent row scatter (hz_rows.h; e.g. hz_actor_flush_job: the finished games' trajectories into
+ * the outbox ring) executed by additional workgroups of the same launch: the reset is bound by the latency of the few
+ * wavefronts that have a game to deal, the scatter rides along for free.  Same results as the two separate calls. */
+int hz_env_reset_rows(hz_env_t* e, const uint8_t* mask, const hz_rows_job_t* rows, void* stream);
 
 /* actions [N] i32 move uids; outputs reward [N] i32 (score delta, may be negative at the loss of the last life),
  * done [N] u8, score [N] i32, status [N] i32.  Envs with mask[i]==0 are untouched (their outputs too). */

@@ -6,6 +6,8 @@
 
 #include <stdint.h>
 
+#include "hz_rows.h"
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -89,6 +91,10 @@ int hz_actor_record_step(const hz_actor_bufs_t* bufs, const int32_t* reward, con
 /* hz_rows_scatter of all six trajectory arrays and the meta rows by bufs->slot, one launch over bufs->finished
  * (one workgroup per row and array). */
 int hz_actor_flush(const hz_actor_bufs_t* bufs, void* stream);
+
+/* The scatter hz_actor_flush performs, as data (host side, no launch): pass it to hz_env_reset_rows to have the masked reset
+ * that follows the flush in a lock-step carry it. */
+int hz_actor_flush_job(const hz_actor_bufs_t* bufs, hz_rows_job_t* job);
 
 /* Outbox ring rows [first, first + n) (mod capacity) as ONE packed byte buffer, the games back to back (ragged; `moves` =
  * the sum of their lengths, which out_count[1] accumulates): sections
