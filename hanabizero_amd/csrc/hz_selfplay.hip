@@ -202,21 +202,21 @@ __global__ __launch_bounds__(256) void k_actor_record_search(hz_actor_bufs_t b, 
   }
 }
 
-__global__ __launch_bounds__(256) void k_actor_record_step(hz_actor_bufs_t b, const int32_t* __restrict__ reward,
-                                                           const int32_t* __restrict__ score,
-                                                           const int32_t* __restrict__ status,
-                                                           const int32_t* __restrict__ packed,
-                                                           const uint8_t* __restrict__ legal_next) {
-  const int env = blockIdx.x * blockDim.x + threadIdx.x;
+// four threads per env (part = 0..3): the row copies are split among them, part 0 also writes the scalars
+__device__ __forceinline__ void actor_record_step_env(const hz_actor_bufs_t& b, int env, int part,
+                                                      const int32_t* __restrict__ reward, const int32_t* __restrict__ score,
+                                                      const int32_t* __restrict__ status, const int32_t* __restrict__ packed,
+                                                      const uint8_t* __restrict__ legal_next) {
   if (env >= b.num_envs) return;
   const int A = b.num_actions, T = b.max_moves, W = b.packed_words;
   const int t = actor_t(b, env);
+  int32_t* orow = b.obs + ((size_t)env * (T + 1) + t + 1) * W;
+  for (int w = part; w < W; w += 4) orow[w] = packed[(size_t)env * W + w];
+  uint8_t* lrow = b.legal + ((size_t)env * (T + 1) + t + 1) * A;
+  for (int a = part; a < A; a += 4) lrow[a] = legal_next[(size_t)env * A + a];
+  if (part != 0) return;
   b.reward[(size_t)env * T + t] = (int8_t)reward[env];
   if (status[env] != 0) atomicAdd(reinterpret_cast<unsigned long long*>(b.illegal_steps), 1ull);
-  int32_t* orow = b.obs + ((size_t)env * (T + 1) + t + 1) * W;
-  for (int w = 0; w < W; ++w) orow[w] = packed[(size_t)env * W + w];
-  uint8_t* lrow = b.legal + ((size_t)env * (T + 1) + t + 1) * A;
-  for (int a = 0; a < A; ++a) lrow[a] = legal_next[(size_t)env * A + a];
   int32_t* m = b.meta + (size_t)env * 4;
   m[0] = t + 1;
   m[1] = score[env];
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void k_actor_record_step(hz_actor_bufs_t b, co
 }
 
 // outbox slots of the games that just ended, in env order: one workgroup, ballot prefix counts
-__global__ __launch_bounds__(1024) void k_actor_slots(hz_actor_bufs_t b, const uint8_t* __restrict__ done) {
+__device__ __forceinline__ void actor_slots_block(const hz_actor_bufs_t& b, const uint8_t* __restrict__ done) {
   __shared__ int wave_total[16];
   __shared__ long long base_s;
   __shared__ int moves_s;
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(1024) void k_actor_slots(hz_actor_bufs_t b, const u
     if (env < b.num_envs) b.slot[env] = d ? (int32_t)((base + off + before) % (long long)b.outbox_games) : -1;
     if (d) {
       b.finished[(int)(base - base_s) + off + before] = env;
-      atomicAdd(&moves_s, b.meta[(size_t)env * 4]);  // its length (k_actor_record_step has just written the meta row)
+      atomicAdd(&moves_s, actor_t(b, env) + 1);  // its length (what actor_record_step_env writes into the meta row)
     }
     base += tot;
     __syncthreads();
@@ -262,6 +262,18 @@ __global__ __launch_bounds__(1024) void k_actor_slots(hz_actor_bufs_t b, const u
     b.out_count[1] += moves_s;
     *b.num_finished = (int)(base - base_s);
   }
+}
+
+// hz_actor_record_step in one launch: workgroups [0, gridDim.x - 1) record 256 envs each (four threads per env), the last
+// one computes the outbox slots (it needs `done` and the trajectory lengths only, nothing the other workgroups write)
+__global__ __launch_bounds__(1024) void k_actor_record_step_slots(hz_actor_bufs_t b, const int32_t* __restrict__ reward,
+                                                                  const uint8_t* __restrict__ done,
+                                                                  const int32_t* __restrict__ score,
+                                                                  const int32_t* __restrict__ status,
+                                                                  const int32_t* __restrict__ packed,
+                                                                  const uint8_t* __restrict__ legal_next) {
+  if (blockIdx.x + 1 == gridDim.x) actor_slots_block(b, done);
+  else actor_record_step_env(b, blockIdx.x * 256 + (threadIdx.x >> 2), threadIdx.x & 3, reward, score, status, packed, legal_next);
 }
 
 struct FlushTable {
@@ -423,9 +435,8 @@ extern "C" int hz_actor_record_step(const hz_actor_bufs_t* bufs, const int32_t* 
                                     const uint8_t* legal_next, void* stream) {
   HZ_ACTOR_CHECK(bufs, "hz_actor_record_step");
   HZ_REQUIRE(reward && done && score && status && packed && legal_next, "hz_actor_record_step: NULL argument");
-  hipLaunchKernelGGL(k_actor_record_step, dim3((bufs->num_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, *bufs,
-                     reward, score, status, packed, legal_next);
-  hipLaunchKernelGGL(k_actor_slots, dim3(1), dim3(1024), 0, (hipStream_t)stream, *bufs, done);
+  hipLaunchKernelGGL(k_actor_record_step_slots, dim3((bufs->num_envs + 255) / 256 + 1), dim3(1024), 0, (hipStream_t)stream,
+                     *bufs, reward, done, score, status, packed, legal_next);
   HZ_HIP(hipGetLastError());
   return 0;
 }
