@@ -27,11 +27,6 @@ class MlpHeader(C.Structure):  # include/hz_mlp.h hz_mlp_header_t
                 ("kstep_stride", C.c_int64), ("wave_stream_off", C.c_int64 * 16)]
 
 
-class SearchMove(C.Structure):  # include/hz_search.h hz_search_move_t
-    _fields_ = [("noise_fraction", C.c_float), ("noises", C.c_void_p), ("policy_logits", C.c_void_p), ("legal", C.c_void_p),
-                ("out_counts", C.c_void_p), ("out_values", C.c_void_p)]
-
-
 class RowsJob(C.Structure):  # include/hz_rows.h hz_rows_job_t
     _fields_ = [("slot", C.c_void_p), ("list", C.c_void_p), ("count", C.c_void_p), ("num_arrays", C.c_int32),
                 ("max_rows", C.c_int32), ("src", C.c_void_p * 8), ("dst", C.c_void_p * 8), ("row_bytes", C.c_int64 * 8)]
@@ -99,7 +94,6 @@ def _load():
         "hz_mlp_recurrent": [C.POINTER(MlpHeader), V, V, V, V, V, I64, V, I64, V, V, V, V, V, I, I, V],
         # include/hz_search.h
         "hz_search_run": [V, I, C.POINTER(MlpHeader), V, V, V, V, V, I64, I64, V, V, V, V, V, V, V],
-        "hz_search_run_move": [V, I, C.POINTER(MlpHeader), V, V, V, V, V, I64, I64, V, V, V, V, V, V, C.POINTER(SearchMove), V],
         "hz_search_set_rows_per_workgroup": [I],
         # include/hz_netglue.h
         "hz_add_relu": [V, I64, V, I64, I, I, I, V],

@@ -28,13 +28,6 @@ struct SearchArgs {
   float* val;
   float* pol;
   int sims;                // simulations to run (S - 1, as the reference)
-  // optional (hz_search_run_move): the root expansion in front of the search and the root read-outs behind it
-  float prep_frac;
-  const float* prep_noises;  // [N][A] or nullptr (no noise)
-  const float* prep_logits;  // [N][A] or nullptr: the trees are already prepared
-  const uint8_t* prep_legal; // [N][A]
-  int32_t* out_counts;       // [N][A] or nullptr
-  float* out_values;         // [N]
 };
 
 // (The phases must be inlined into the kernel: through a real call the compiler loses the address space of every
@@ -78,23 +71,12 @@ __device__ __forceinline__ RowFrag search_first_descent(const TreeView& tv, cons
                                                         float4& root_row) {
   const TraverseOut to = search_traverse_out(H, a, L, row0);
   int entry;
+  tl.root_visit = tv.root_visit[tree];
+  tl.root_vsum = tv.root_vsum[tree];
   tl.publish = a.sims == 1;
   root_row = make_float4(0.f, 0.f, 0.f, 0.f);
-  float mn0, mx0;
-  if (a.prep_logits != nullptr) {  // CRoots::prepare here instead of in a launch of its own
-    root_row = prepare_tree(tv, tree, lane, a.prep_frac, a.prep_noises, a.prep_logits, a.prep_legal);
-    tl.root_visit = 0;
-    tl.root_vsum = 0.0f;
-    mn0 = HZ_FLOAT_MAX;
-    mx0 = HZ_FLOAT_MIN;
-  } else {
-    if (lane < tv.A) root_row = tv.rec[(size_t)tree * tv.S * tv.A + lane];  // from now on kept in registers, patched per backup
-    tl.root_visit = tv.root_visit[tree];
-    tl.root_vsum = tv.root_vsum[tree];
-    mn0 = tv.mm_min[tree];
-    mx0 = tv.mm_max[tree];
-  }
-  traverse_body<true>(tv, tree, lane, 0, mn0, mx0, tl.root_visit, to, true, root_row, &entry, &tl);
+  if (lane < tv.A) root_row = tv.rec[(size_t)tree * tv.S * tv.A + lane];  // from now on kept in registers, patched per backup
+  traverse_body<true>(tv, tree, lane, 0, tv.mm_min[tree], tv.mm_max[tree], tl.root_visit, to, true, root_row, &entry, &tl);
   return search_request_row(tv, H, a, entry, tree, lane);
 }
 
@@ -189,13 +171,6 @@ __global__ __launch_bounds__(1024, 1) void k_search(TreeView tv, hz_mlp_header_t
   L.lds_q = reinterpret_cast<float*>(L.path_s + MT * (tv.S + 1));
   L.act_s = reinterpret_cast<int32_t*>(L.lds_q + MT * tv.S);
   if (threadIdx.x < 32) L.exp_s[threadIdx.x] = hz_exp2f_tab[threadIdx.x];
-  // the read-out pointers wait in LDS for the end of the search (as kernel arguments they would sit in -- or be spilled
-  // from -- scalar registers through every simulation)
-  unsigned long long* io_s = reinterpret_cast<unsigned long long*>(L.act_s + MT + 2);
-  if (threadIdx.x == 0) {
-    io_s[0] = (unsigned long long)a.out_counts;
-    io_s[1] = (unsigned long long)a.out_values;
-  }
   TreeLocal tl[RT];
   bool mine[RT];
   RowFrag rows[RT];
@@ -242,17 +217,6 @@ __global__ __launch_bounds__(1024, 1) void k_search(TreeView tv, hz_mlp_header_t
     p_tree += t1 - t0; p_wait1 += t2 - t1; p_mlp += t3 - t2; p_wait2 += t4 - t3;
     t0 = t4;
   }
-  int32_t* out_counts = reinterpret_cast<int32_t*>(io_s[0]);
-  float* out_values = reinterpret_cast<float*>(io_s[1]);
-  if (out_counts != nullptr) {  // get_distributions + get_values (cnode.cpp:266-292) from the registers the search ends with
-#pragma unroll
-    for (int s = 0; s < RT; ++s)
-      if (mine[s]) {
-        const int tree = row0 + 16 * s + wave;
-        if (lane < tv.A) out_counts[(size_t)tree * tv.A + lane] = (int)(__float_as_uint(root_row[s].w) >> 16);
-        if (lane == 0) out_values[tree] = tl[s].root_visit == 0 ? 0.0f : tl[s].root_vsum / (float)tl[s].root_visit;
-      }
-  }
 #ifdef HZ_SEARCH_PROFILE
   if (blockIdx.x == 100 / RT && lane == 0) {
     unsigned long long* o = hz_search_prof + wave * 4;
@@ -282,11 +246,6 @@ __global__ __launch_bounds__(1024, 1) void k_search_half(TreeView tv, hz_mlp_hea
     tab_s[threadIdx.x] = (tv.S < 64 && (int)threadIdx.x <= tv.S) ? tv.pbc_tab[threadIdx.x] : 0.0f;
     tab_s[64 + threadIdx.x] = sqrtf((float)threadIdx.x + 1.0f);
   }
-  unsigned long long* io_s = reinterpret_cast<unsigned long long*>(tab_s + 128);  // (see k_search)
-  if (threadIdx.x == 0) {
-    io_s[0] = (unsigned long long)a.out_counts;
-    io_s[1] = (unsigned long long)a.out_values;
-  }
   __syncthreads();
   HalfLane q;
   HalfTree t;
@@ -310,29 +269,7 @@ __global__ __launch_bounds__(1024, 1) void k_search_half(TreeView tv, hz_mlp_hea
   t.leaf_reward = t.leaf_value = t.leaf_logit = 0.0f;
   const bool any_mine = row0 + wave < tv.N;  // (rows are filled in order: the lower half's tree exists if any does)
   if (any_mine) {
-    if (a.prep_logits != nullptr) {  // CRoots::prepare here: the wave's two trees in turn (one-tree code, lane = action),
-      float4 r[2];                   // then the upper tree's row moves to the upper half's lanes
-#pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-        const int tr = row0 + 16 * hh + wave;  // (uniform)
-        r[hh] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (tr < tv.N) r[hh] = prepare_tree(tv, tr, lane, a.prep_frac, a.prep_noises, a.prep_logits, a.prep_legal);
-      }
-      // (every lane executes the permutes: written inside the ?: they would run for the upper half only, and a
-      // ds_bpermute reads nothing from lanes that are switched off)
-      const int from = 4 * q.l;
-      const float ux = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(r[1].x)));
-      const float uy = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(r[1].y)));
-      const float uz = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(r[1].z)));
-      const float uw = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(r[1].w)));
-      root_row.x = q.h ? ux : r[0].x;
-      root_row.y = q.h ? uy : r[0].y;
-      root_row.z = q.h ? uz : r[0].z;
-      root_row.w = q.h ? uw : r[0].w;
-      if (!t.mine || q.l >= tv.A) root_row = make_float4(0.f, 0.f, 0.f, 0.f);
-      mn = HZ_FLOAT_MAX;
-      mx = HZ_FLOAT_MIN;
-    } else if (t.mine) {
+    if (t.mine) {
       t.root_visit = tv.root_visit[t.tree];
       t.root_vsum = tv.root_vsum[t.tree];
       mn = tv.mm_min[t.tree];
@@ -385,12 +322,6 @@ __global__ __launch_bounds__(1024, 1) void k_search_half(TreeView tv, hz_mlp_hea
       }
     }
   }
-  int32_t* out_counts = reinterpret_cast<int32_t*>(io_s[0]);
-  float* out_values = reinterpret_cast<float*>(io_s[1]);
-  if (out_counts != nullptr && any_mine && t.mine) {
-    if (q.l < tv.A) out_counts[(size_t)t.tree * tv.A + q.l] = (int)(__float_as_uint(root_row.w) >> 16);
-    if (q.l == 0) out_values[t.tree] = t.root_visit == 0 ? 0.0f : t.root_vsum / (float)t.root_visit;
-  }
 #undef HZ_HALF_SETUP
 }
 
@@ -406,19 +337,12 @@ extern "C" int hz_search_set_rows_per_workgroup(int rows) {
   return 0;
 }
 
-static int search_launch(hz_tree_t* t, int num_simulations, const hz_mlp_header_t* H, const hz_mlp_job_t* jobs,
-                         const void* wstream, const float* biases, const float* action_table, void* pool,
-                         int64_t plane_stride, int64_t row_stride, int32_t* ix, int32_t* iy, int32_t* la, float* rewards,
-                         float* values, float* policy, const hz_search_move_t* mv, void* stream) {
+extern "C" int hz_search_run(hz_tree_t* t, int num_simulations, const hz_mlp_header_t* H, const hz_mlp_job_t* jobs,
+                             const void* wstream, const float* biases, const float* action_table, void* pool,
+                             int64_t plane_stride, int64_t row_stride, int32_t* ix, int32_t* iy, int32_t* la,
+                             float* rewards, float* values, float* policy, void* stream) {
   HZ_REQUIRE(t && H && jobs && wstream && biases && action_table && pool && ix && iy && la && rewards && values && policy,
              "hz_search_run: NULL argument");
-  const bool prepares = mv != nullptr && mv->policy_logits != nullptr;
-  if (prepares) {
-    HZ_REQUIRE(mv->legal != nullptr, "hz_search_run_move: legal must accompany policy_logits");
-    t->next_entry = 1;  // (the kernel expands the roots itself)
-  }
-  if (mv != nullptr) HZ_REQUIRE((mv->out_counts == nullptr) == (mv->out_values == nullptr),
-                                "hz_search_run_move: out_counts and out_values come together");
   HZ_REQUIRE(t->params_set, "hz_search_run: call hz_tree_set_params first");
   HZ_REQUIRE(num_simulations >= 1 && num_simulations < t->S,
              "hz_search_run: num_simulations=%d outside [1, tree capacity %d)", num_simulations, t->S);
@@ -470,12 +394,6 @@ static int search_launch(hz_tree_t* t, int num_simulations, const hz_mlp_header_
   a.jobs = jobs; a.wstream = (const uint16_t*)wstream; a.bias = biases; a.act_tab = action_table;
   a.pool = (uint16_t*)pool; a.plane_stride = plane_stride; a.row_stride = row_stride;
   a.ix = ix; a.iy = iy; a.la = la; a.rew = rewards; a.val = values; a.pol = policy; a.sims = num_simulations;
-  a.prep_frac = mv ? mv->noise_fraction : 0.0f;
-  a.prep_noises = mv ? mv->noises : nullptr;
-  a.prep_logits = mv ? mv->policy_logits : nullptr;
-  a.prep_legal = mv ? mv->legal : nullptr;
-  a.out_counts = mv ? mv->out_counts : nullptr;
-  a.out_values = mv ? mv->out_values : nullptr;
   if (variant == 2)
     hipLaunchKernelGGL(k_search_half, dim3((t->N + 31) / 32), dim3(1024), lds_bytes, (hipStream_t)stream, view(t), *H, a);
   else if (variant == 1)
@@ -486,21 +404,3 @@ static int search_launch(hz_tree_t* t, int num_simulations, const hz_mlp_header_
   t->next_entry = num_simulations + 1;
   return 0;
 }
-
-extern "C" int hz_search_run(hz_tree_t* t, int num_simulations, const hz_mlp_header_t* H, const hz_mlp_job_t* jobs,
-                             const void* wstream, const float* biases, const float* action_table, void* pool,
-                             int64_t plane_stride, int64_t row_stride, int32_t* ix, int32_t* iy, int32_t* la,
-                             float* rewards, float* values, float* policy, void* stream) {
-  return search_launch(t, num_simulations, H, jobs, wstream, biases, action_table, pool, plane_stride, row_stride, ix, iy, la,
-                       rewards, values, policy, nullptr, stream);
-}
-
-extern "C" int hz_search_run_move(hz_tree_t* t, int num_simulations, const hz_mlp_header_t* H, const hz_mlp_job_t* jobs,
-                                  const void* wstream, const float* biases, const float* action_table, void* pool,
-                                  int64_t plane_stride, int64_t row_stride, int32_t* ix, int32_t* iy, int32_t* la,
-                                  float* rewards, float* values, float* policy, const hz_search_move_t* move, void* stream) {
-  HZ_REQUIRE(move != nullptr, "hz_search_run_move: NULL move");
-  return search_launch(t, num_simulations, H, jobs, wstream, biases, action_table, pool, plane_stride, row_stride, ix, iy, la,
-                       rewards, values, policy, move, stream);
-}
-

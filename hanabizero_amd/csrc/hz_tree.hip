@@ -44,7 +44,42 @@ __global__ __launch_bounds__(256) void k_prepare(TreeView tv, float frac, const 
   const int lane = threadIdx.x & 63;
   const int tree = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (tree >= tv.N) return;
-  prepare_tree(tv, tree, lane, frac, noises, logits, legal);
+  const int A = tv.A, S = tv.S;
+  const bool on = lane < A;
+  const float logit = on ? logits[(size_t)tree * A + lane] : 0.0f;
+  const int lg = on ? (int)legal[(size_t)tree * A + lane] : 0;
+  const uint64_t legal_mask = __ballot(on && lg != 0);  // expand skips legal == 0 (cnode.cpp:71)
+  float prior = expand_prior(logit, legal_mask, lane, A);
+  if (noises != nullptr) {
+    const float nz = on ? noises[(size_t)tree * A + lane] : 0.0f;
+    // legal_noise: sum in action order over legal == 1 (cnode.cpp:120-129)
+    float legal_noise = 0.0f;
+    uint64_t mm = __ballot(on && lg == 1);
+    while (mm) {
+      const int a = __ffsll((unsigned long long)mm) - 1;
+      mm &= mm - 1;
+      legal_noise += hz_readlane_f(nz, a);
+    }
+    if (lg <= 0) {
+      prior = 0.0f;  // cnode.cpp:131-135
+    } else {
+      const float noise = nz / legal_noise;          // cnode.cpp:136
+      prior = prior * (1 - frac) + noise * frac;     // cnode.cpp:140 (three roundings, no FMA)
+    }
+  }
+  if (on) {
+    float4 r;
+    r.x = prior; r.y = 0.0f; r.z = 0.0f; r.w = __uint_as_float(pack_vc(0, -1));
+    tv.rec[((size_t)tree * S + 0) * A + lane] = r;
+  }
+  for (int e = lane; e < S; e += 64) tv.best_action[(size_t)tree * S + e] = -1;
+  if (lane == 0) {
+    tv.root_visit[tree] = 0;
+    tv.root_vsum[tree] = 0.0f;
+    tv.mm_min[tree] = HZ_FLOAT_MAX;  // CMinMaxStats ctor (cminimax.cpp:5-9)
+    tv.mm_max[tree] = HZ_FLOAT_MIN;
+    tv.path_len[tree] = 0;
+  }
   (void)rewards;  // the root's own reward is never read by the search (cnode.cpp:303,330 skip the root)
 }
 

@@ -235,30 +235,6 @@ class Roots:
         self._sim += int(num_simulations)
         return ix, iy, la
 
-    def search_move_tensors(self, fused, pool, num_simulations, rew, val, pol, fraction, noises, logits, legal, counts, values):
-        """prepare (noises None: prepare_no_noise) + every simulation + the root read-outs (visit counts [N, A] i32, root
-        values [N] f32) as ONE kernel launch (hz_search_run_move): what prepare(...), search_tensors(...) and
-        root_stats_tensors(...) do in three.  All tensors on the device, fp32 / uint8 / int32 as in those calls."""
-        import ctypes as C
-        from ._lib import SearchMove
-        assert fused.waves == 16 and fused.tiles == 2 and pool.dim() == 3 and pool.shape[1] == self.root_num
-        N, A = self.root_num, self.action_num
-        assert logits.shape == (N, A) and logits.dtype == torch.float32 and logits.is_contiguous()
-        assert legal.shape == (N, A) and legal.dtype == torch.uint8 and legal.is_contiguous()
-        assert noises is None or (noises.shape == (N, A) and noises.dtype == torch.float32 and noises.is_contiguous())
-        assert counts.shape == (N, A) and counts.dtype == torch.int32 and values.shape == (N,) and values.dtype == torch.float32
-        mv = SearchMove(noise_fraction=float(fraction), noises=None if noises is None else noises.data_ptr(),
-                        policy_logits=logits.data_ptr(), legal=legal.data_ptr(), out_counts=counts.data_ptr(),
-                        out_values=values.data_ptr())
-        ix, iy, la = self._ix, self._iy, self._la
-        check(lib.hz_search_run_move(self._h, int(num_simulations), C.byref(fused.header), fused.jobs.data_ptr(),
-                                     fused.weights.data_ptr(), fused.biases.data_ptr(), fused.act_table.data_ptr(),
-                                     pool.data_ptr(), pool.stride(0), pool.stride(1), ix.data_ptr(), iy.data_ptr(),
-                                     la.data_ptr(), rew.data_ptr(), val.data_ptr(), pol.data_ptr(), C.byref(mv), _stream()),
-              "hz_search_run_move")
-        self._sim = int(num_simulations)
-        return counts, values
-
     def root_stats_tensors(self, counts=None, values=None):
         """(visit counts [N, A] i32, root values [N] f32) in one launch; optional caller-owned outputs."""
         if counts is None:

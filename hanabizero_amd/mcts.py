@@ -18,7 +18,6 @@ class MCTS(object):
     def __init__(self, config, persistent=True):
         self.config = config
         self.persistent = persistent  # fused engines: the whole simulation loop as one persistent kernel
-        self._scratch = None
 
     def run_multi(self, roots, model, hidden_state_roots, pool=None):
         """roots: hanabizero_amd.cytree.Roots (already prepared).  model: an InferenceEngine (fast path) or a
@@ -65,33 +64,6 @@ class MCTS(object):
                 roots.traverse_tensors(pool, net_in, onehot_cols=oh)
                 r_log, v_log, p_log = model.recurrent_heads(net_in, pool[index_simulation + 1])
                 roots.backprop_nets_tensors(index_simulation + 1, r_log, v_log, model.V, -model.support, p_log)
-
-    def run_move(self, roots, model, hidden_state_roots, pool, root_exploration_fraction, noises, policy_logits, legal,
-                 counts, values):
-        """roots.prepare(...) (noises None: prepare_no_noise) + run_multi(...) + the root read-outs (visit counts into
-        `counts` [N, A] i32, root values into `values` [N] f32): ONE kernel launch when the engine has the fused bf16
-        kernel (hz_search_run_move), the three calls otherwise.  Tensors on the device."""
-        S, num = self.config.num_simulations, roots.num
-        fused16 = model.fused_shape(16, 2) if (self.persistent and getattr(model, "fused", None) is not None) else None
-        if fused16 is not None and fused16.lds_bytes(16) + 16 * (24 * (S + 1) + 4 * roots.action_num + 16) + 512 <= 160 * 1024:
-            with torch.no_grad():
-                roots.set_params(self.config.pb_c_base, self.config.pb_c_init, self.config.discount, self.config.value_delta_max)
-                if hidden_state_roots.data_ptr() != pool[0].data_ptr():
-                    pool[0].copy_(hidden_state_roots)
-                if self._scratch is None or self._scratch[0].shape[0] != num or self._scratch[0].device != pool.device:
-                    self._scratch = (torch.empty(num, dtype=torch.float32, device=pool.device),
-                                     torch.empty(num, dtype=torch.float32, device=pool.device),
-                                     torch.empty((num, roots.action_num), dtype=torch.float32, device=pool.device))
-                rew, val, pol = self._scratch
-                roots.search_move_tensors(fused16, pool, S - 1, rew, val, pol, root_exploration_fraction, noises,
-                                          policy_logits.to(torch.float32).contiguous(), legal, counts, values)
-            return counts, values
-        if noises is None:
-            roots.prepare_no_noise(torch.zeros(num, device=pool.device), policy_logits, legal)
-        else:
-            roots.prepare(root_exploration_fraction, noises, torch.zeros(num, device=pool.device), policy_logits, legal)
-        self.run_multi(roots, model, hidden_state_roots, pool=pool)
-        return roots.root_stats_tensors(counts, values)
 
     def _run_multi_compat(self, roots, model, hidden_state_roots):
         """The reference loop verbatim in structure (lists / numpy through the drop-in cytree API): lets an unmodified

@@ -155,9 +155,9 @@ class SelfPlayActor:
         if draw and not self._drawn:
             self._draw()
         value0, logits0, hidden0 = self.root_inference(state_out=self.pool[0])
-        # roots.prepare + all simulations + the root read-outs: one launch on the fused bf16 engine (hz_search_run_move)
-        self.mcts.run_move(self.roots, self.engine, hidden0, self.pool, cfg.root_exploration_fraction, self.noise, logits0,
-                           self.legal, self.counts, self.values)
+        self.roots.prepare(cfg.root_exploration_fraction, self.noise, self.zeros_n, logits0, self.legal)
+        self.mcts.run_multi(self.roots, self.engine, hidden0, pool=self.pool)
+        self.roots.root_stats_tensors(self.counts, self.values)
         b, st = C.byref(self.bufs), _stream()
         check(lib.hz_actor_record_search(b, self.counts.data_ptr(), self.values.data_ptr(), self.legal.data_ptr(),
                                          self.uniform.data_ptr(), float(cfg.visit_softmax_temperature_fn(0, 0)),

@@ -35,23 +35,6 @@ int hz_search_run(hz_tree_t* t, int num_simulations, const hz_mlp_header_t* H, c
                   int64_t plane_stride, int64_t row_stride, int32_t* ix, int32_t* iy, int32_t* la, float* rewards,
                   float* values, float* policy, void* stream);
 
-/* The same search with the launches either side of it folded in: when policy_logits is not NULL the kernel first expands
- * the roots -- hz_tree_prepare (noises == NULL: hz_tree_prepare without noise; CRoots::prepare / prepare_no_noise,
- * cnode.cpp:247-259) -- and when out_counts is not NULL it ends by writing what hz_tree_get_root_stats returns
- * (get_distributions + get_values, cnode.cpp:266-292).  Same bits as the three calls. */
-typedef struct {
-  float noise_fraction;        /* root_exploration_fraction */
-  const float* noises;         /* [N][A] f32 or NULL */
-  const float* policy_logits;  /* [N][A] f32 root logits, or NULL: the tree is already prepared */
-  const uint8_t* legal;        /* [N][A] u8 */
-  int32_t* out_counts;         /* [N][A] i32 root child visit counts, or NULL */
-  float* out_values;           /* [N] f32 root values (with out_counts) */
-} hz_search_move_t;
-int hz_search_run_move(hz_tree_t* t, int num_simulations, const hz_mlp_header_t* H, const hz_mlp_job_t* jobs,
-                       const void* wstream, const float* biases, const float* action_table, void* pool,
-                       int64_t plane_stride, int64_t row_stride, int32_t* ix, int32_t* iy, int32_t* la, float* rewards,
-                       float* values, float* policy, const hz_search_move_t* move, void* stream);
-
 /* Trees per workgroup of the following hz_search_run calls of this process: 0 = chosen from the tree count (default),
  * 16 or 32 = forced (tests, measurements); with 32 the two trees of a wavefront are searched side by side in its two
  * 32-lane halves when num_actions <= 32 and hidden <= 512, -32 forces them one after the other.  The results do not depend

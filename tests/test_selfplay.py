@@ -261,42 +261,3 @@ def test_packed_drain_equals_drain():
         again = unpack_packed(hbuf, hn, hmoves, actor.A, actor.W)
         for k in again:
             assert again[k].dtype == ragged[k].dtype and np.array_equal(again[k], ragged[k]), k
-
-
-@pytest.mark.parametrize("game,N,noise", [("Hanabi-Full", 300, True), ("Hanabi-Small", 90, False), ("Hanabi-Full", 4200, True)])
-def test_search_move_equals_prepare_search_readouts(game, N, noise):
-    """hz_search_run_move (root expansion + all simulations + root read-outs in ONE launch) against the three calls it
-    folds -- Roots.prepare / prepare_no_noise, the persistent search, hz_tree_get_root_stats -- for every kernel variant."""
-    from hanabizero_amd import cytree
-    from hanabizero_amd._lib import check, lib
-    from hanabizero_amd.mcts import MCTS
-    sims = 14
-    cfg, eng, actor = make(game, N, sims, 2, torch.bfloat16, use_graph=False)
-    A = cfg.action_space_size
-    g = torch.Generator(device="cuda").manual_seed(N)
-    value0, logits0, hidden0 = actor.root_inference()
-    nz = torch.rand(N, A, device="cuda", generator=g)
-    nz = (nz / nz.sum(1, keepdim=True)) if noise else None
-    zeros = torch.zeros(N, device="cuda")
-    for rows in (16, 32, -32, 0):
-        check(lib.hz_search_set_rows_per_workgroup(rows), "rows")
-        a = cytree.Roots(N, A, sims, tie_seed=5, tree_id_base=17)
-        if noise:
-            a.prepare(cfg.root_exploration_fraction, nz, zeros, logits0, actor.legal)
-        else:
-            a.prepare_no_noise(zeros, logits0, actor.legal)
-        pool_a = torch.zeros(sims, N, eng.H, dtype=eng.dtype, device="cuda")
-        MCTS(cfg).run_multi(a, eng, hidden0, pool=pool_a)
-        ca, va = a.root_stats_tensors()
-        b = cytree.Roots(N, A, sims, tie_seed=5, tree_id_base=17)
-        pool_b = torch.zeros(sims, N, eng.H, dtype=eng.dtype, device="cuda")
-        cb = torch.full((N, A), -1, dtype=torch.int32, device="cuda")
-        vb = torch.full((N,), -1.0, dtype=torch.float32, device="cuda")
-        MCTS(cfg).run_move(b, eng, hidden0, pool_b, cfg.root_exploration_fraction, nz, logits0, actor.legal, cb, vb)
-        torch.cuda.synchronize()
-        assert torch.equal(ca, cb) and torch.equal(va, vb) and torch.equal(pool_a, pool_b)
-        assert torch.equal(a.trajectories_tensor(), b.trajectories_tensor()) and torch.equal(a.values_tensor(), b.values_tensor())
-        assert torch.equal(a.distributions_tensor(), b.distributions_tensor()) and torch.equal(a.path_len_tensor(), b.path_len_tensor())
-        assert all(torch.equal(x, y) for x, y in zip(a.minmax_tensors(), b.minmax_tensors()))
-    check(lib.hz_search_set_rows_per_workgroup(0), "rows")
-
