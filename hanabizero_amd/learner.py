@@ -93,26 +93,30 @@ def make_batch(games, positions, config, value_fn, weights=None, rng=None):
     rng = rng or np.random
     U, td, stack, A, g = config.num_unroll_steps, config.td_steps, config.stacked_observations, config.action_space_size, config.discount
     B = len(games)
-    obs_lst, action_lst, mask_lst, value_obs, value_mask = [], [], [], [], []
-    for game, pos in zip(games, positions):
+    D = config.obs_shape // stack
+    # (outputs are written in place: the per-sample lists + np.stack of the straightforward version cost more than
+    # everything else in this function)
+    obs_batch = np.empty((B, stack + U, D), np.float32)
+    value_obs = np.zeros((B * (U + 1), config.obs_shape), np.float32)  # zero_obs past the end of a game
+    value_mask = np.zeros(B * (U + 1), np.float64)
+    action_lst, mask_lst = [], []
+    k = 0
+    for b, (game, pos) in enumerate(zip(games, positions)):
         acts = [int(a) for a in game.actions[pos:pos + U]]
         mask = [1.0] * len(acts) + [0.0] * (U - len(acts))
         acts += [int(rng.randint(0, A)) for _ in range(U - len(acts))]
-        obs_lst.append(np.asarray(game.obs(pos, extra_len=U, padding=True), dtype=np.float32))
+        obs_batch[b] = game.obs(pos, extra_len=U, padding=True)
         action_lst.append(acts)
         mask_lst.append(mask)
         traj_len = len(game)
-        game_obs = game.obs(pos + td, U)  # :204-222 bootstrap observations, zero_obs past the end
+        game_obs = np.asarray(game.obs(pos + td, U))  # :204-222 bootstrap observations
         for cur in range(pos, pos + U + 1):
-            boot = cur + td
-            if boot < traj_len:
-                value_mask.append(1.0)
+            if cur + td < traj_len:
+                value_mask[k] = 1.0
                 beg = cur - pos
-                value_obs.append(np.asarray(game_obs[beg:beg + stack], dtype=np.float32).reshape(-1))
-            else:
-                value_mask.append(0.0)
-                value_obs.append(np.zeros(config.obs_shape, np.float32))
-    values = np.asarray(value_fn(np.stack(value_obs)), dtype=np.float64).reshape(-1) * (g ** td) * np.asarray(value_mask)
+                value_obs[k].reshape(stack, D)[:] = game_obs[beg:beg + stack]
+            k += 1
+    values = np.asarray(value_fn(value_obs), dtype=np.float64).reshape(-1) * (g ** td) * value_mask
     target_value = np.zeros((B, U + 1), np.float32)
     target_reward = np.zeros((B, U + 1), np.float32)
     target_policy = np.zeros((B, U + 1, A), np.float32)
@@ -128,7 +132,7 @@ def make_batch(games, positions, config, value_fn, weights=None, rng=None):
                 target_policy[b, j] = game.child_visits[cur]
             k += 1
     w = np.ones(B, np.float32) if weights is None else np.asarray(weights, np.float32)
-    inputs = (np.stack(obs_lst), np.asarray(action_lst, np.int64), np.asarray(mask_lst, np.float32), np.arange(B), w, np.zeros(B))
+    inputs = (obs_batch, np.asarray(action_lst, np.int64), np.asarray(mask_lst, np.float32), np.arange(B), w, np.zeros(B))
     return inputs, (target_reward[:, :U + 1], target_value, target_policy)
 
 
