@@ -261,3 +261,34 @@ def test_packed_drain_equals_drain():
         again = unpack_packed(hbuf, hn, hmoves, actor.A, actor.W)
         for k in again:
             assert again[k].dtype == ragged[k].dtype and np.array_equal(again[k], ragged[k]), k
+
+
+def test_fused_launches_equal_their_separate_calls():
+    """The lock-step with its fused launches (hz_actor_begin_move_draw; hz_env_reset_rows carrying the flush) against the same
+    moves made with the separate entry points (hz_actor_draw + hz_actor_begin_move; hz_actor_flush + hz_env_reset): the
+    same finished games, bit for bit, and the same live state."""
+    from hanabizero_amd._lib import check, lib
+    import ctypes as C
+    recs, states = [], []
+    for fused in (True, False):
+        cfg, eng, actor = make("Hanabi-Small", 96, 10, 2, torch.bfloat16, use_graph=False, seed=21)
+        if not fused:
+            def reset_then(mask, rows=None, _env=actor.env, _actor=actor):  # flush and reset as two launches
+                check(lib.hz_actor_flush(C.byref(_actor.bufs), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "flush")
+                type(_env).reset(_env, mask)
+            actor.env.reset = reset_then
+        for _ in range(28):
+            if fused:
+                actor._step_body(draw=True)
+            else:
+                actor._draw()
+                actor._step_body(draw=False)
+        torch.cuda.synchronize()
+        recs.append(actor.drain())
+        states.append((actor.stack_buf.clone(), actor.legal.clone(), actor.traj_len.clone(), actor.env.state_tensor().clone()
+                       if hasattr(actor.env, "state_tensor") else None))
+    assert recs[0]["meta"].shape[0] > 20
+    for k in recs[0]:
+        assert np.array_equal(recs[0][k], recs[1][k]), k
+    for a, b in zip(states[0], states[1]):
+        assert (a is None and b is None) or torch.equal(a, b)
