@@ -280,7 +280,10 @@ __device__ __forceinline__ void mlp_body(
     const uint16_t* src = lds + (size_t)r0 * rs + J.src_off + kq;
     // activation fragments, BQD - 1 k-steps ahead of their use (RT = 2 has the registers for one step ahead only; its
     // four MFMAs per k-step cover the LDS round trip)
-    constexpr int BQD = RT == 1 ? 4 : 2;
+#ifndef HZ_BQD2
+#define HZ_BQD2 2  // (3: measured no faster, more spills)
+#endif
+    constexpr int BQD = RT == 1 ? 4 : HZ_BQD2;
     bf16x8 bq[BQD][RT];
 #pragma unroll
     for (int d = 0; d < BQD - 1; ++d)
