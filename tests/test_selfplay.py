@@ -292,3 +292,46 @@ def test_fused_launches_equal_their_separate_calls():
         assert np.array_equal(recs[0][k], recs[1][k]), k
     for a, b in zip(states[0], states[1]):
         assert (a is None and b is None) or torch.equal(a, b)
+
+
+def test_new_entry_points_report_bad_arguments():
+    """hz_actor_pack / hz_actor_packed_bytes / hz_env_reset_rows / hz_actor_begin_move_draw / hz_search_set_rows_per_workgroup:
+    malformed calls come back as error codes with a message (the reference aborts or corrupts memory), nothing is launched."""
+    import ctypes as C
+    from hanabizero_amd._lib import HzError, RowsJob, check, lib
+    cfg, eng, actor = make("Hanabi-Small", 32, 10, 2, torch.bfloat16, use_graph=False)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    b = C.byref(actor.bufs)
+    out = torch.zeros(1 << 16, dtype=torch.uint8, device="cuda")
+    starts = torch.zeros(64, dtype=torch.int32, device="cuda")
+    assert lib.hz_actor_packed_bytes(-1, 5, actor.A, actor.W, None) == -1
+    assert lib.hz_actor_packed_bytes(3, 7, actor.A, actor.W, None) % 16 == 0
+    for args in ((0, 0, 5), (0, 5, 2), (0, 2, 10 ** 6), (-1, 2, 5)):  # n = 0; moves < n; moves > n * T; first < 0
+        with pytest.raises(HzError):
+            check(lib.hz_actor_pack(b, args[0], args[1], args[2], starts.data_ptr(), out.data_ptr(), out.numel(), st), "pack")
+    with pytest.raises(HzError):  # buffer too small
+        check(lib.hz_actor_pack(b, 0, 2, 9, starts.data_ptr(), out.data_ptr(), 64, st), "pack")
+    job = RowsJob()
+    check(lib.hz_actor_flush_job(b, C.byref(job)), "job")
+    assert job.num_arrays == 7 and job.max_rows == 32 and job.row_bytes[6] == 16
+    job.num_arrays = 9
+    with pytest.raises(HzError):
+        check(lib.hz_env_reset_rows(actor.env._h, None, C.byref(job), st), "reset_rows")
+    job.num_arrays = 7
+    job.row_bytes[2] = 0
+    with pytest.raises(HzError):
+        check(lib.hz_env_reset_rows(actor.env._h, None, C.byref(job), st), "reset_rows")
+    es = actor.newest.element_size()
+    with pytest.raises(HzError):  # alpha <= 0
+        check(lib.hz_actor_begin_move_draw(b, actor.env.done.data_ptr(), actor.tmp_packed.data_ptr(), actor.legal.data_ptr(),
+                                           actor.newest.data_ptr(), actor.newest.stride(0) * es, actor.stack_buf.data_ptr(),
+                                           actor.stack_buf.stride(0) * es, actor.stack, actor.Dp * es, 1,
+                                           actor.move_count.data_ptr(), 0.0, actor.noise.data_ptr(), actor.uniform.data_ptr(), st),
+              "begin_move_draw")
+    with pytest.raises(HzError):
+        check(lib.hz_search_set_rows_per_workgroup(48), "rows")
+    torch.cuda.synchronize()
+    for _ in range(3):  # and the actor is still in working order
+        actor.step()
+    torch.cuda.synchronize()
+    assert int(actor.illegal_steps) == 0
