@@ -101,6 +101,24 @@ extern "C" int hz_mlp_profile_read_passes(unsigned long long* host) {
 #define HZ_RING 4  // weight-fragment ring slots (k-steps); prefetch distance HZ_RING - 1.  Measured: 4 and 8 run at the
 #endif             // same rate (the memory pipe's own queue is the limit), 4 leaves registers for 16 waves per workgroup
 
+// Issue priority of this wave for the next few k-steps.  The sequencer serves the oldest wave of a SIMD first, so with a
+// fixed priority wave w < 4 of a workgroup (the oldest on its SIMD) streams its share of a layer in half the time the
+// youngest needs and then idles at the layer's barrier while the stragglers finish on a memory pipe they cannot fill alone
+// (tools/mlp_profile.py: k-loops 22 k cycles for waves 0-3, 48 k for waves 12-15 of 81 k).  Rotating the priority among
+// the four age groups every four k-steps gives each group every rank equally often: +1.2 % moves/s at 16 rows per workgroup
+// (A/B on one box, tools/ab_bench.sh; every 2 or 8 k-steps and fixed youngest-first are worse), -1.1 % with 32 rows, where it
+// is therefore off.  (s_setprio takes an immediate.)
+__device__ __forceinline__ void hz_rotate_prio(int group_plus_phase) {
+#ifndef HZ_MLP_X_NOPRIO
+  switch (group_plus_phase & 3) {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(3); break;
+  }
+#endif
+}
+
 // The body, called by every wave of the workgroup: NW waves, each producing NT 16-column tiles per job (NW x NT = 4 x 4
 // for the stand-alone kernel, 16 x 2 inside the persistent search kernel, whose 16 waves also own one tree each).
 // `lds`: the row image, MT * row_stride bf16.
@@ -334,24 +352,39 @@ __device__ __forceinline__ void mlp_body(
     PROF_ADD(p_pre, p_j1);
     const unsigned long long p_j2 = PROF_NOW();
     int s = 0;
+    const int prio_grp = wave >> 2;
+#ifndef HZ_PRIO_SHIFT
+#define HZ_PRIO_SHIFT 2  // the priorities rotate every 2^HZ_PRIO_SHIFT k-steps (experiment switch; -1: fixed, youngest first)
+#endif
+#ifdef HZ_PRIO_BIAS  // experiment: the youngest group always first, the other three rotate below it
+#define HZ_PRIO_EXPR(PH) (prio_grp == 3 ? 3 : (prio_grp + (PH)) % 3)
+#else
+#define HZ_PRIO_EXPR(PH) (prio_grp + (PH))
+#endif
+#define HZ_PRIO_AT(S, U)                                                                                  \
+  if (RT == 1 && HZ_PRIO_SHIFT >= 0 && ((U) & ((1 << (HZ_PRIO_SHIFT < 0 ? 0 : HZ_PRIO_SHIFT)) - 1)) == 0)   \
+    hz_rotate_prio(HZ_PRIO_EXPR((int)((gstep + (S)) >> (HZ_PRIO_SHIFT < 0 ? 0 : HZ_PRIO_SHIFT))));
+    if (RT == 1 && HZ_PRIO_SHIFT < 0) hz_rotate_prio(prio_grp);
     for (; s + 8 < J.ks; s += 8) {
-      HZ_MLP_STEP(s, 0)
-      HZ_MLP_STEP(s + 1, 1)
-      HZ_MLP_STEP(s + 2, 2)
-      HZ_MLP_STEP(s + 3, 3)
-      HZ_MLP_STEP(s + 4, 4)
-      HZ_MLP_STEP(s + 5, 5)
-      HZ_MLP_STEP(s + 6, 6)
-      HZ_MLP_STEP(s + 7, 7)
+      HZ_PRIO_AT(s, 0) HZ_MLP_STEP(s, 0)
+      HZ_PRIO_AT(s + 1, 1) HZ_MLP_STEP(s + 1, 1)
+      HZ_PRIO_AT(s + 2, 2) HZ_MLP_STEP(s + 2, 2)
+      HZ_PRIO_AT(s + 3, 3) HZ_MLP_STEP(s + 3, 3)
+      HZ_PRIO_AT(s + 4, 4) HZ_MLP_STEP(s + 4, 4)
+      HZ_PRIO_AT(s + 5, 5) HZ_MLP_STEP(s + 5, 5)
+      HZ_PRIO_AT(s + 6, 6) HZ_MLP_STEP(s + 6, 6)
+      HZ_PRIO_AT(s + 7, 7) HZ_MLP_STEP(s + 7, 7)
     }
-    HZ_MLP_STEP(s, 0)
-    HZ_MLP_STEP(s + 1, 1)
-    HZ_MLP_STEP(s + 2, 2)
-    HZ_MLP_STEP(s + 3, 3)
-    HZ_MLP_STEP(s + 4, 4)
-    HZ_MLP_STEP(s + 5, 5)
-    HZ_MLP_STEP(s + 6, 6)
-    HZ_MLP_STEP(s + 7, 7)
+    HZ_PRIO_AT(s, 0) HZ_MLP_STEP(s, 0)
+    HZ_PRIO_AT(s + 1, 1) HZ_MLP_STEP(s + 1, 1)
+    HZ_PRIO_AT(s + 2, 2) HZ_MLP_STEP(s + 2, 2)
+    HZ_PRIO_AT(s + 3, 3) HZ_MLP_STEP(s + 3, 3)
+    HZ_PRIO_AT(s + 4, 4) HZ_MLP_STEP(s + 4, 4)
+    HZ_PRIO_AT(s + 5, 5) HZ_MLP_STEP(s + 5, 5)
+    HZ_PRIO_AT(s + 6, 6) HZ_MLP_STEP(s + 6, 6)
+    HZ_PRIO_AT(s + 7, 7) HZ_MLP_STEP(s + 7, 7)
+#undef HZ_PRIO_AT
+#undef HZ_PRIO_EXPR
 #undef HZ_MLP_STEP
 #ifdef HZ_MLP_X_SPLITACC
 #pragma unroll
@@ -408,6 +441,9 @@ __device__ __forceinline__ void mlp_body(
   }
   const unsigned long long p_jobs_done = PROF_NOW();
   (void)p_jobs_done;
+#ifndef HZ_MLP_X_NOPRIO
+  if (RT == 1) __builtin_amdgcn_s_setprio(0);
+#endif
   if (FINAL) __syncthreads();  // (without the final stage the caller's own barrier follows)
   // heads -> scalars / policy logits: 32 lanes per (row, head) pair
 #ifndef HZ_MLP_X_NOFINAL
