@@ -159,11 +159,16 @@ __device__ __forceinline__ void mlp_body(
   // memory pipe busy meanwhile), then all row loads of this thread at once: two latencies in total, not two per trip.
   // this wave's job entries: 8 dwords per job, lane 8*(j % 8) + f of register j / 8 holds field f of job j.  One vector
   // load now instead of one scalar load (a dependent L2 round trip in front of every job) inside the job loop.
+#ifdef HZ_MLP_X_REVWAVE  // experiment: which wave streams which share of the weights, reversed (results unchanged)
+  const int vwave = NW - 1 - wave;
+#else
+  const int vwave = wave;
+#endif
   int jv[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int jl = 8 * i + (lane >> 3);
-    jv[i] = jl < H.n_jobs ? reinterpret_cast<const int*>(jobs)[((size_t)jl * NW + wave) * 8 + (lane & 7)] : 0;
+    jv[i] = jl < H.n_jobs ? reinterpret_cast<const int*>(jobs)[((size_t)jl * NW + vwave) * 8 + (lane & 7)] : 0;
   }
   const int chunks = H.in_width / 8;
   const int n_stage = MT * chunks;
@@ -178,7 +183,7 @@ __device__ __forceinline__ void mlp_body(
   __builtin_amdgcn_sched_barrier(0);
   // this wave's weight stream
   // uniform base + per-lane 16-B offset: the k-loop advances the base on the scalar unit, not with 64-bit VALU adds
-  const bf16x8* wbase = reinterpret_cast<const bf16x8*>(wstream + H.wave_stream_off[wave]);
+  const bf16x8* wbase = reinterpret_cast<const bf16x8*>(wstream + H.wave_stream_off[vwave]);
   const long long kss = H.kstep_stride / 8;  // in 16-B fragments-per-lane units
 #ifdef HZ_MLP_X_NT  // experiment: non-temporal (streaming) weight loads
 #define wp(k, t) __builtin_nontemporal_load(&wbase[(long long)(k) * kss + (t) * 64 + lane])

@@ -19,7 +19,7 @@ def main():
     os.makedirs(os.path.dirname(out), exist_ok=True)
     src = os.path.join(ROOT, "hanabizero_amd", "csrc")
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                           "-ffp-contract=off", "-w", "-DHZ_MLP_PROFILE", "-I" + src, "-I" + os.path.join(ROOT, "include"),
+                           "-ffp-contract=off", "-w", "-DHZ_MLP_PROFILE"] + [f for f in sys.argv[5:] if f.startswith("-D")] + [ "-I" + src, "-I" + os.path.join(ROOT, "include"),
                            "-o", out, os.path.join(src, "hz_mlp.hip"), os.path.join(src, "hz_tree.hip")])
     import bench
     from hanabizero_amd._lib import MlpHeader
