@@ -366,10 +366,15 @@ __device__ __forceinline__ void mlp_body(
 #else
 #define HZ_PRIO_EXPR(PH) (prio_grp + (PH))
 #endif
+#ifdef HZ_PRIO_RT2  // experiment: the rotation for the 32-row shape as well
+#define HZ_PRIO_ON true
+#else
+#define HZ_PRIO_ON (RT == 1)
+#endif
 #define HZ_PRIO_AT(S, U)                                                                                  \
-  if (RT == 1 && HZ_PRIO_SHIFT >= 0 && ((U) & ((1 << (HZ_PRIO_SHIFT < 0 ? 0 : HZ_PRIO_SHIFT)) - 1)) == 0)   \
+  if (HZ_PRIO_ON && HZ_PRIO_SHIFT >= 0 && ((U) & ((1 << (HZ_PRIO_SHIFT < 0 ? 0 : HZ_PRIO_SHIFT)) - 1)) == 0) \
     hz_rotate_prio(HZ_PRIO_EXPR((int)((gstep + (S)) >> (HZ_PRIO_SHIFT < 0 ? 0 : HZ_PRIO_SHIFT))));
-    if (RT == 1 && HZ_PRIO_SHIFT < 0) hz_rotate_prio(prio_grp);
+    if (HZ_PRIO_ON && HZ_PRIO_SHIFT < 0) hz_rotate_prio(prio_grp);
     for (; s + 8 < J.ks; s += 8) {
       HZ_PRIO_AT(s, 0) HZ_MLP_STEP(s, 0)
       HZ_PRIO_AT(s + 1, 1) HZ_MLP_STEP(s + 1, 1)
@@ -447,7 +452,7 @@ __device__ __forceinline__ void mlp_body(
   const unsigned long long p_jobs_done = PROF_NOW();
   (void)p_jobs_done;
 #ifndef HZ_MLP_X_NOPRIO
-  if (RT == 1) __builtin_amdgcn_s_setprio(0);
+  __builtin_amdgcn_s_setprio(0);
 #endif
   if (FINAL) __syncthreads();  // (without the final stage the caller's own barrier follows)
   // heads -> scalars / policy logits: 32 lanes per (row, head) pair
