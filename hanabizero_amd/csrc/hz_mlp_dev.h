@@ -119,6 +119,10 @@ __device__ __forceinline__ void hz_rotate_prio(int group_plus_phase) {
 #endif
 }
 
+__device__ __forceinline__ bf16x8 hz_bits_to_bf16x8(__attribute__((ext_vector_type(4))) unsigned int v) {
+  return *reinterpret_cast<bf16x8*>(&v);
+}
+
 // The body, called by every wave of the workgroup: NW waves, each producing NT 16-column tiles per job (NW x NT = 4 x 4
 // for the stand-alone kernel, 16 x 2 inside the persistent search kernel, whose 16 waves also own one tree each).
 // `lds`: the row image, MT * row_stride bf16.
@@ -185,7 +189,12 @@ __device__ __forceinline__ void mlp_body(
   // uniform base + per-lane 16-B offset: the k-loop advances the base on the scalar unit, not with 64-bit VALU adds
   const bf16x8* wbase = reinterpret_cast<const bf16x8*>(wstream + H.wave_stream_off[vwave]);
   const long long kss = H.kstep_stride / 8;  // in 16-B fragments-per-lane units
-#ifdef HZ_MLP_X_NT  // experiment: non-temporal (streaming) weight loads
+#if defined(HZ_MLP_X_BUFLOAD)  // experiment: buffer loads with an explicit cache policy (1 = sc0, 2 = nt, 16 = sc1)
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wstream, 0, 0x7fffffff, 0x00020000);
+  const int wvoff = (int)(H.wave_stream_off[vwave] * 2) + lane * 16;
+  typedef __attribute__((ext_vector_type(4))) unsigned int hz_u32x4;
+#define wp(k, t) hz_bits_to_bf16x8(__builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff + (t) * 1024, (int)((long long)(k) * kss * 16), HZ_MLP_X_BUFLOAD))
+#elif defined(HZ_MLP_X_NT)  // experiment: non-temporal (streaming) weight loads
 #define wp(k, t) __builtin_nontemporal_load(&wbase[(long long)(k) * kss + (t) * 64 + lane])
 #else
 #define wp(k, t) wbase[(long long)(k) * kss + (t) * 64 + lane]
