@@ -199,9 +199,19 @@ __device__ __forceinline__ void mlp_body(
 #else
 #define wp(k, t) wbase[(long long)(k) * kss + (t) * 64 + lane]
 #endif
+  // Prefetch distance in k-steps.  16-row shapes: HZ_RING - 1 (2 costs 1.7 % moves/s at 4096 envs).  32-row shape: 2 -- one
+  // ring slot stays spare, so the refill of a slot does not have to wait for the four MFMAs that have just read it
+  // (3: -2.1 % moves/s at 8192 envs, 1: -1.6 %; A/B on one box, tools/ab_bench.sh).
+#ifndef HZ_PF2
+#define HZ_PF2 2
+#endif
+#ifndef HZ_PF1
+#define HZ_PF1 (HZ_RING - 1)
+#endif
+#define HZ_PF (RT == 1 ? HZ_PF1 : HZ_PF2)
   bf16x8 wf[HZ_RING][NT];
 #pragma unroll
-  for (int d = 0; d < HZ_RING - HZ_BURST; ++d)
+  for (int d = 0; d < (HZ_BURST == 1 ? HZ_PF : HZ_RING - HZ_BURST); ++d)
 #pragma unroll
     for (int t = 0; t < NT; ++t) wf[d][t] = wp(d, t);
   __builtin_amdgcn_sched_barrier(0);
@@ -340,11 +350,16 @@ __device__ __forceinline__ void mlp_body(
 #endif
     __builtin_amdgcn_sched_barrier(0);
 
+#ifdef HZ_MLP_X_NOMFMA2  // experiment (results garbage): only the first row tile's MFMAs
+#define HZ_MFMA_RT 1
+#else
+#define HZ_MFMA_RT RT
+#endif
 #define HZ_MLP_STEP(S, U)                                                                                            \
   {                                                                                                                  \
     if (HZ_BURST == 1) {                                                                                             \
       _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                                 \
-          wf[((U) + HZ_RING - 1) % HZ_RING][t] = wp(gstep + (S) + HZ_RING - 1, t);                                  \
+          wf[((U) + HZ_PF) % HZ_RING][t] = wp(gstep + (S) + HZ_PF, t);                                              \
     } else if ((U) % 2 == 0) { /* two k-steps' fragments back to back: longer bursts per wave on the memory pipe */ \
       _Pragma("unroll") for (int t = 0; t < 2 * NT; ++t)                                                             \
           wf[((U) + HZ_RING - 2 + t / NT) % HZ_RING][t % NT] = wp(gstep + (S) + HZ_RING - 2 + t / NT, t % NT);          \
@@ -355,7 +370,7 @@ __device__ __forceinline__ void mlp_body(
               *reinterpret_cast<const bf16x8*>(src + (size_t)(16 * rt) * rs + 32 * ((S) + BQD - 1));                 \
     }                                                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                               \
-    _Pragma("unroll") for (int t = 0; t < NT; ++t) _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                  \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t) _Pragma("unroll") for (int rt = 0; rt < HZ_MFMA_RT; ++rt)           \
         HZ_ACC(U)[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[(U) % HZ_RING][t], bq[(U) % BQD][rt], HZ_ACC(U)[t][rt], 0, 0, 0); \
     __builtin_amdgcn_sched_barrier(0);                                                                               \
   }
