@@ -326,9 +326,13 @@ __device__ __forceinline__ void mlp_body(
 #define HZ_BQD2 2  // (3: measured no faster, more spills)
 #endif
     constexpr int BQD = RT == 1 ? 4 : HZ_BQD2;
+#ifndef HZ_BQPF1
+#define HZ_BQPF1 3  // how many k-steps ahead the 16-row shapes read their activation fragments (experiment switch)
+#endif
+    constexpr int BQPF = RT == 1 ? HZ_BQPF1 : BQD - 1;
     bf16x8 bq[BQD][RT];
 #pragma unroll
-    for (int d = 0; d < BQD - 1; ++d)
+    for (int d = 0; d < BQPF; ++d)
       if (d < J.ks) {
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) bq[d][rt] = *reinterpret_cast<const bf16x8*>(src + (size_t)(16 * rt) * rs + 32 * d);
@@ -366,8 +370,8 @@ __device__ __forceinline__ void mlp_body(
     }                                                                                                                \
     if (HZ_MLP_BREAD) { /* unconditional: the last trips read past the K range, into fragments nobody uses */       \
       _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                                              \
-          bq[((U) + BQD - 1) % BQD][rt] =                                                                            \
-              *reinterpret_cast<const bf16x8*>(src + (size_t)(16 * rt) * rs + 32 * ((S) + BQD - 1));                 \
+          bq[((U) + BQPF) % BQD][rt] =                                                                               \
+              *reinterpret_cast<const bf16x8*>(src + (size_t)(16 * rt) * rs + 32 * ((S) + BQPF));                    \
     }                                                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                               \
     _Pragma("unroll") for (int t = 0; t < NT; ++t) _Pragma("unroll") for (int rt = 0; rt < HZ_MFMA_RT; ++rt)           \
