@@ -359,8 +359,7 @@ __device__ __forceinline__ void mlp_body(
 #else
 #define HZ_MFMA_RT RT
 #endif
-#define HZ_MLP_STEP(S, U)                                                                                            \
-  {                                                                                                                  \
+#define HZ_MLP_LOADS(S, U)                                                                                           \
     if (HZ_BURST == 1) {                                                                                             \
       _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                                 \
           wf[((U) + HZ_PF) % HZ_RING][t] = wp(gstep + (S) + HZ_PF, t);                                              \
@@ -373,11 +372,16 @@ __device__ __forceinline__ void mlp_body(
           bq[((U) + BQPF) % BQD][rt] =                                                                               \
               *reinterpret_cast<const bf16x8*>(src + (size_t)(16 * rt) * rs + 32 * ((S) + BQPF));                    \
     }                                                                                                                \
-    __builtin_amdgcn_sched_barrier(0);                                                                               \
+    __builtin_amdgcn_sched_barrier(0);
+#define HZ_MLP_MFMAS(S, U)                                                                                           \
     _Pragma("unroll") for (int t = 0; t < NT; ++t) _Pragma("unroll") for (int rt = 0; rt < HZ_MFMA_RT; ++rt)           \
         HZ_ACC(U)[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[(U) % HZ_RING][t], bq[(U) % BQD][rt], HZ_ACC(U)[t][rt], 0, 0, 0); \
-    __builtin_amdgcn_sched_barrier(0);                                                                               \
-  }
+    __builtin_amdgcn_sched_barrier(0);
+#ifdef HZ_MLP_X_MFMAFIRST  // experiment: a k-step's MFMAs in front of its loads (the slot they refill was read a step earlier)
+#define HZ_MLP_STEP(S, U) { HZ_MLP_MFMAS(S, U) HZ_MLP_LOADS(S, U) }
+#else
+#define HZ_MLP_STEP(S, U) { HZ_MLP_LOADS(S, U) HZ_MLP_MFMAS(S, U) }
+#endif
 
     // all but the last 8 k-steps in a loop, the last 8 peeled: the 32 fragment loads they issue sit between the
     // bias / action-row loads above and their first use, so the compiler can wait with vmcnt(>=28) instead of draining
@@ -424,6 +428,8 @@ __device__ __forceinline__ void mlp_body(
 #undef HZ_PRIO_AT
 #undef HZ_PRIO_EXPR
 #undef HZ_MLP_STEP
+#undef HZ_MLP_LOADS
+#undef HZ_MLP_MFMAS
 #ifdef HZ_MLP_X_SPLITACC
 #pragma unroll
     for (int t = 0; t < NT; ++t)
