@@ -22,7 +22,7 @@ class MlpHeader(C.Structure):  # include/hz_mlp.h hz_mlp_header_t
     _fields_ = [("n_jobs", C.c_int32), ("row_stride", C.c_int32), ("hidden", C.c_int32), ("state_off", C.c_int32),
                 ("hidden_off", C.c_int32), ("off_reward", C.c_int32), ("off_value", C.c_int32), ("off_policy", C.c_int32),
                 ("support_size", C.c_int32), ("support_min", C.c_int32), ("num_actions", C.c_int32),
-                ("action_table_stride", C.c_int32), ("in_width", C.c_int32), ("reserved", C.c_int32),
+                ("action_table_stride", C.c_int32), ("in_width", C.c_int32), ("dtype", C.c_int32),
                 ("num_waves", C.c_int32), ("tiles_per_wave", C.c_int32),
                 ("kstep_stride", C.c_int64), ("wave_stream_off", C.c_int64 * 16)]
 
@@ -93,8 +93,7 @@ def _load():
         # include/hz_mlp.h
         "hz_mlp_recurrent": [C.POINTER(MlpHeader), V, V, V, V, V, I64, V, I64, V, V, V, V, V, I, I, V],
         # include/hz_search.h
-        "hz_search_run": [V, I, C.POINTER(MlpHeader), V, V, V, V, V, I64, I64, V, V, V, V, V, V, V],
-        "hz_search_set_rows_per_workgroup": [I],
+        "hz_search_run": [V, I, C.POINTER(MlpHeader), V, V, V, V, V, I64, I64, V, V, V, V, V, V, I, V],
         # include/hz_netglue.h
         "hz_add_relu": [V, I64, V, I64, I, I, I, V],
         "hz_test_expf": [V, V, I64, V],

@@ -2,10 +2,10 @@
 // heads + scalar transforms) as ONE MFMA kernel for gfx950.  See include/hz_mlp.h for what it replaces and why.
 //
 // Work split (body in hz_mlp_dev.h, shared with the persistent search kernel hz_search.hip): a workgroup of NW waves
-// (4, 8 or 16) owns MT rows (16 or 32) of the batch.  The rows' activations live in an LDS image (bf16, one image row per
+// (4, 8 or 16) owns MT rows (16 or 32) of the batch.  The rows' activations live in an LDS image (bf16 or fp16, one image row per
 // batch row) for the whole layer chain.  The chain is a table of jobs; in job j wave w produces 16 * NT output columns
 // (NT MFMA tiles: 4, or 2 with 16 waves) of one layer:
-//     D[n][row] += W[n][k] * X[k][row]      v_mfma_f32_16x16x32_bf16, A = weights, B = activations (ds_read_b128)
+//     D[n][row] += W[n][k] * X[k][row]      v_mfma_f32_16x16x32_{bf16,f16}, A = weights, B = activations (ds_read_b128)
 // so a lane ends up with 4 consecutive output columns of one batch row -> one ds_write_b64 per tile into the image.
 // Each wave's weights are ONE stream in execution order (1 KiB-contiguous dwordx4 fragment loads; the waves' streams are
 // interleaved k-step by k-step in memory), prefetched HZ_RING - 1 = 3 k-steps ahead in a register ring across job, layer
@@ -15,7 +15,7 @@
 #include "hz_mlp_dev.h"
 #include "hz_tree.h"
 
-template <int RT, int NW, int NT>
+template <class EL, int RT, int NW, int NT>
 __global__ __launch_bounds__(64 * NW, 1) void k_mlp_recurrent(
     hz_mlp_header_t H, const hz_mlp_job_t* __restrict__ jobs, const uint16_t* __restrict__ wstream,
     const float* __restrict__ bias, const float* __restrict__ act_tab, const uint16_t* __restrict__ state_src,
@@ -23,7 +23,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_recurrent(
     const int32_t* __restrict__ actions, uint16_t* __restrict__ hidden_out, float* __restrict__ out_reward,
     float* __restrict__ out_value, float* __restrict__ out_policy, int n_rows) {
   extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
-  mlp_body<RT, NW, NT>(H, jobs, wstream, bias, act_tab, state_src, state_row_stride, plane_index, plane_stride, actions,
+  mlp_body<EL, RT, NW, NT>(H, jobs, wstream, bias, act_tab, state_src, state_row_stride, plane_index, plane_stride, actions,
                        hidden_out, out_reward, out_value, out_policy, n_rows, lds, (int)blockIdx.x * 16 * RT, nullptr);
 }
 
@@ -38,6 +38,7 @@ extern "C" int hz_mlp_recurrent(const hz_mlp_header_t* H, const hz_mlp_job_t* jo
   HZ_REQUIRE(num_rows > 0, "hz_mlp_recurrent: num_rows must be > 0");
   HZ_REQUIRE(rows_per_wg == 16 || rows_per_wg == 32, "hz_mlp_recurrent: rows_per_wg must be 16 or 32");
   HZ_REQUIRE(H->n_jobs > 0 && H->n_jobs <= 32, "hz_mlp_recurrent: bad job count %d", H->n_jobs);
+  HZ_REQUIRE(H->dtype == HZ_BF16 || H->dtype == HZ_F16, "hz_mlp_recurrent: header dtype must be HZ_BF16 or HZ_F16 (got %d)", H->dtype);
   HZ_REQUIRE(H->support_size > 0 && H->support_size <= 256 && H->off_reward % 8 == 0 && H->off_value % 8 == 0,
              "hz_mlp_recurrent: support_size must be <= 256 and the logit columns 16-B aligned");
   HZ_REQUIRE(H->row_stride % 8 == 0 && H->hidden % 8 == 0 && row_stride % 8 == 0 && plane_stride % 8 == 0 &&
@@ -47,7 +48,7 @@ extern "C" int hz_mlp_recurrent(const hz_mlp_header_t* H, const hz_mlp_job_t* jo
                  ((uintptr_t)biases % 16) == 0 && ((uintptr_t)action_table % 16) == 0,
              "hz_mlp_recurrent: pointers must be 16-B aligned");
   HZ_REQUIRE((H->num_waves == 4 && H->tiles_per_wave == 4) || (H->num_waves == 16 && H->tiles_per_wave == 2) ||
-                 (H->num_waves == 8 && (H->tiles_per_wave == 4 || H->tiles_per_wave == 2)),
+                 (H->num_waves == 8 && H->tiles_per_wave == 4),
              "hz_mlp_recurrent: workgroup shape must be 4 waves x 4 tiles, 8 x 4 or 16 x 2 (got %d x %d)", H->num_waves,
              H->tiles_per_wave);
   for (int w = 0; w < H->num_waves; ++w)
@@ -58,24 +59,31 @@ extern "C" int hz_mlp_recurrent(const hz_mlp_header_t* H, const hz_mlp_job_t* jo
   const size_t lds_bytes = (size_t)rows_per_wg * H->row_stride * sizeof(uint16_t);
   HZ_REQUIRE(lds_bytes <= 160 * 1024, "hz_mlp_recurrent: %zu B of LDS per workgroup exceed 160 KiB", lds_bytes);
   const int grid = (num_rows + rows_per_wg - 1) / rows_per_wg;
-#define HZ_LAUNCH(RT, NW, NT)                                                                                        \
+  // (the dynamic-LDS limit is a per-device attribute of each kernel: remembered per device ordinal)
+  int dev = 0;
+  HZ_HIP(hipGetDevice(&dev));
+  HZ_REQUIRE(dev >= 0 && dev < 64, "hz_mlp_recurrent: device ordinal %d outside [0, 64)", dev);
+#define HZ_LAUNCH_EL(EL, RT, NW, NT)                                                                                 \
   do {                                                                                                               \
-    static size_t configured = 0;                                                                                    \
-    if (lds_bytes > configured) {                                                                                    \
-      HZ_HIP(hipFuncSetAttribute((const void*)k_mlp_recurrent<RT, NW, NT>,                                           \
+    static size_t configured[64];                                                                                    \
+    if (lds_bytes > configured[dev]) {                                                                               \
+      HZ_HIP(hipFuncSetAttribute((const void*)k_mlp_recurrent<EL, RT, NW, NT>,                                       \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                       \
-      configured = lds_bytes;                                                                                        \
+      configured[dev] = lds_bytes;                                                                                   \
     }                                                                                                                \
-    hipLaunchKernelGGL((k_mlp_recurrent<RT, NW, NT>), dim3(grid), dim3(64 * NW), lds_bytes, (hipStream_t)stream, *H,  \
-                       jobs, (const uint16_t*)wstream, biases, action_table, (const uint16_t*)state_src,             \
+    hipLaunchKernelGGL((k_mlp_recurrent<EL, RT, NW, NT>), dim3(grid), dim3(64 * NW), lds_bytes, (hipStream_t)stream,  \
+                       *H, jobs, (const uint16_t*)wstream, biases, action_table, (const uint16_t*)state_src,         \
                        (long long)row_stride, plane_index, (long long)plane_stride, actions, (uint16_t*)hidden_out,  \
                        out_reward, out_value, out_policy, num_rows);                                                 \
+  } while (0)
+#define HZ_LAUNCH(RT, NW, NT)                           \
+  do {                                                  \
+    if (H->dtype == HZ_F16) HZ_LAUNCH_EL(ElF16, RT, NW, NT); \
+    else HZ_LAUNCH_EL(ElBf16, RT, NW, NT);              \
   } while (0)
   if (H->num_waves == 4) {
     if (rows_per_wg == 16) HZ_LAUNCH(1, 4, 4);
     else HZ_LAUNCH(2, 4, 4);
-  } else if (H->num_waves == 8 && H->tiles_per_wave == 2) {
-    HZ_LAUNCH(1, 8, 2);  // (experiment shape)
   } else if (H->num_waves == 8) {
     if (rows_per_wg == 16) HZ_LAUNCH(1, 8, 4);
     else HZ_LAUNCH(2, 8, 4);
@@ -84,6 +92,7 @@ extern "C" int hz_mlp_recurrent(const hz_mlp_header_t* H, const hz_mlp_job_t* jo
     else HZ_LAUNCH(2, 16, 2);
   }
 #undef HZ_LAUNCH
+#undef HZ_LAUNCH_EL
   HZ_HIP(hipGetLastError());
   return 0;
 }

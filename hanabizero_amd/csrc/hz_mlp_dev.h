@@ -1,23 +1,54 @@
 // hz_mlp_dev.h -- device code of the fused recurrent-inference MLP (see hz_mlp.hip), shared by the stand-alone kernel
-// and the persistent search kernel (hz_search.hip).
+// and the persistent search kernel (hz_search.hip).  Everything is a template over the element format EL of weights and
+// activations: ElBf16 (v_mfma_f32_16x16x32_bf16) or ElF16 (v_mfma_f32_16x16x32_f16 -- the reference's own autocast
+// format, /root/reference/core/mcts.py:38-40); accumulation, bias, residual and ReLU are fp32 in both.
 #pragma once
 #include "hz_common.h"
 #include "hz_mlp.h"
+#include "hz_tree.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
-
-__device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
-// two fp32 -> packed bf16 pair: a plain cast compiles to v_cvt_pk_bf16_f32 on gfx950 (round-to-nearest-even, NaN kept)
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
-__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
-  const f32x2 f = {lo, hi};
-  const bf16x2 h = __builtin_convertvector(f, bf16x2);
-  return *reinterpret_cast<const uint32_t*>(&h);
-}
 
-// inverse_scalar_transform of LDS rows of bf16 logits, one (row, head) pair per 32-lane half of the wave: lane l32
+struct ElBf16 {
+  typedef bf16x8 v8;
+  static constexpr int code = HZ_BF16;
+  // the two elements of a packed pair -> fp32
+  static __device__ __forceinline__ float lo(uint32_t w) { return __uint_as_float(w << 16); }
+  static __device__ __forceinline__ float hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+  static __device__ __forceinline__ float one(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+  // two fp32 -> packed pair: a plain cast compiles to v_cvt_pk_bf16_f32 on gfx950 (round-to-nearest-even, NaN kept)
+  static __device__ __forceinline__ uint32_t pack(float a, float b) {
+    const f32x2 f = {a, b};
+    const bf16x2 h = __builtin_convertvector(f, bf16x2);
+    return *reinterpret_cast<const uint32_t*>(&h);
+  }
+  static __device__ __forceinline__ f32x4 mfma(v8 a, v8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+
+struct ElF16 {
+  typedef f16x8 v8;
+  static constexpr int code = HZ_F16;
+  static __device__ __forceinline__ float one(uint16_t h) { return (float)*reinterpret_cast<const _Float16*>(&h); }
+  static __device__ __forceinline__ float lo(uint32_t w) { return one((uint16_t)(w & 0xffffu)); }
+  static __device__ __forceinline__ float hi(uint32_t w) { return one((uint16_t)(w >> 16)); }
+  static __device__ __forceinline__ uint32_t pack(float a, float b) {  // v_cvt_pk_f16_f32: round-to-nearest-even
+    const f32x2 f = {a, b};
+    const f16x2 h = __builtin_convertvector(f, f16x2);
+    return *reinterpret_cast<const uint32_t*>(&h);
+  }
+  static __device__ __forceinline__ f32x4 mfma(v8 a, v8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+};
+
+// inverse_scalar_transform of LDS rows of EL logits, one (row, head) pair per 32-lane half of the wave: lane l32
 // owns logits [8*l32, 8*l32 + 8) (one ds_read_b128), DPP reductions inside each 16-lane row, one cross-row exchange;
 // V <= 256.  Same maths as hz_tree.hip support_to_scalar.
 // (the cross-row step through readlane + select, not a ds_bpermute round trip: row0 op row1 for lanes 0-31, row2 op row3
@@ -32,6 +63,7 @@ __device__ __forceinline__ float half32_sum(float v) {
   const float lo = hz_readlane_f(v, 0) + hz_readlane_f(v, 16), hi = hz_readlane_f(v, 32) + hz_readlane_f(v, 48);
   return (threadIdx.x & 32) ? hi : lo;
 }
+template <class EL>
 __device__ __forceinline__ float row32_support_to_scalar(const uint16_t* row, int V, int support_min, int l32) {
   uint32_t w[4];
   const int base = 8 * l32;
@@ -45,8 +77,8 @@ __device__ __forceinline__ float row32_support_to_scalar(const uint16_t* row, in
   float x[8];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    x[2 * k] = (base + 2 * k < V) ? __uint_as_float(w[k] << 16) : -INFINITY;
-    x[2 * k + 1] = (base + 2 * k + 1 < V) ? __uint_as_float(w[k] & 0xffff0000u) : -INFINITY;
+    x[2 * k] = (base + 2 * k < V) ? EL::lo(w[k]) : -INFINITY;
+    x[2 * k + 1] = (base + 2 * k + 1 < V) ? EL::hi(w[k]) : -INFINITY;
   }
   float m = -INFINITY;
 #pragma unroll
@@ -89,17 +121,9 @@ extern "C" int hz_mlp_profile_read_passes(unsigned long long* host) {
 #define PROF_ADD(var, t0) (void)(t0)
 #endif
 
-#ifdef HZ_MLP_X_NOBREAD  // experiment switch (tools/mlp_variants.py): no activation-fragment reads in the k-loop
-#define HZ_MLP_BREAD 0
-#else
-#define HZ_MLP_BREAD 1
-#endif
-#ifndef HZ_BURST
-#define HZ_BURST 1  // k-steps whose weight fragments are requested together (1 or 2)
-#endif
-#ifndef HZ_RING
-#define HZ_RING 4  // weight-fragment ring slots (k-steps); prefetch distance HZ_RING - 1.  Measured: 4 and 8 run at the
-#endif             // same rate (the memory pipe's own queue is the limit), 4 leaves registers for 16 waves per workgroup
+// Weight-fragment ring: HZ_RING slots of one k-step each.  Measured: 4 and 8 slots stream at the same
+// rate (the memory pipe's own queue is the limit), 4 leaves registers for 16 waves per workgroup.
+#define HZ_RING 4
 
 // Issue priority of this wave for the next few k-steps.  The sequencer serves the oldest wave of a SIMD first, so with a
 // fixed priority wave w < 4 of a workgroup (the oldest on its SIMD) streams its share of a layer in half the time the
@@ -109,23 +133,17 @@ extern "C" int hz_mlp_profile_read_passes(unsigned long long* host) {
 // (A/B on one box, tools/ab_bench.sh; every 2 or 8 k-steps and fixed youngest-first are worse), -1.1 % with 32 rows, where it
 // is therefore off.  (s_setprio takes an immediate.)
 __device__ __forceinline__ void hz_rotate_prio(int group_plus_phase) {
-#ifndef HZ_MLP_X_NOPRIO
   switch (group_plus_phase & 3) {
     case 0: __builtin_amdgcn_s_setprio(0); break;
     case 1: __builtin_amdgcn_s_setprio(1); break;
     case 2: __builtin_amdgcn_s_setprio(2); break;
     default: __builtin_amdgcn_s_setprio(3); break;
   }
-#endif
-}
-
-__device__ __forceinline__ bf16x8 hz_bits_to_bf16x8(__attribute__((ext_vector_type(4))) unsigned int v) {
-  return *reinterpret_cast<bf16x8*>(&v);
 }
 
 // The body, called by every wave of the workgroup: NW waves, each producing NT 16-column tiles per job (NW x NT = 4 x 4
 // for the stand-alone kernel, 16 x 2 inside the persistent search kernel, whose 16 waves also own one tree each).
-// `lds`: the row image, MT * row_stride bf16.
+// `lds`: the row image, MT * row_stride elements.
 // The input rows of a workgroup: gathered here from state_src (STAGE_GATHER), or handed over by the caller's waves in
 // registers (STAGE_REGS: wave w holds rows w, 16 + w, ..; lane l its l-th 16-B chunk in row_frag[rt].v[l / 64]; NW == 16) and
 // written into the image here, after the weight ring has been started -- the rows' load latency hides under it.
@@ -134,7 +152,7 @@ struct RowFrag {
   uint4 v[2];
 };
 // FINAL = false: stop after the last layer (logits stay in the image; the caller's waves read them there).
-template <int RT, int NW, int NT, int STAGE = STAGE_GATHER, bool FINAL = true>
+template <class EL, int RT, int NW, int NT, int STAGE = STAGE_GATHER, bool FINAL = true>
 __device__ __forceinline__ void mlp_body(
     const hz_mlp_header_t& H, const hz_mlp_job_t* __restrict__ jobs, const uint16_t* __restrict__ wstream,
     const float* __restrict__ bias, const float* __restrict__ act_tab, const uint16_t* __restrict__ state_src,
@@ -142,6 +160,7 @@ __device__ __forceinline__ void mlp_body(
     const int32_t* __restrict__ actions, uint16_t* __restrict__ hidden_out, float* __restrict__ out_reward,
     float* __restrict__ out_value, float* __restrict__ out_policy, int n_rows, uint16_t* lds, int row0,
     const RowFrag* row_frag) {
+  typedef typename EL::v8 v8;
   constexpr int NTHR = 64 * NW;
   constexpr bool PRESTAGED = STAGE != STAGE_GATHER;
   constexpr int MT = 16 * RT;
@@ -163,16 +182,11 @@ __device__ __forceinline__ void mlp_body(
   // memory pipe busy meanwhile), then all row loads of this thread at once: two latencies in total, not two per trip.
   // this wave's job entries: 8 dwords per job, lane 8*(j % 8) + f of register j / 8 holds field f of job j.  One vector
   // load now instead of one scalar load (a dependent L2 round trip in front of every job) inside the job loop.
-#ifdef HZ_MLP_X_REVWAVE  // experiment: which wave streams which share of the weights, reversed (results unchanged)
-  const int vwave = NW - 1 - wave;
-#else
-  const int vwave = wave;
-#endif
   int jv[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int jl = 8 * i + (lane >> 3);
-    jv[i] = jl < H.n_jobs ? reinterpret_cast<const int*>(jobs)[((size_t)jl * NW + vwave) * 8 + (lane & 7)] : 0;
+    jv[i] = jl < H.n_jobs ? reinterpret_cast<const int*>(jobs)[((size_t)jl * NW + wave) * 8 + (lane & 7)] : 0;
   }
   const int chunks = H.in_width / 8;
   const int n_stage = MT * chunks;
@@ -187,37 +201,22 @@ __device__ __forceinline__ void mlp_body(
   __builtin_amdgcn_sched_barrier(0);
   // this wave's weight stream
   // uniform base + per-lane 16-B offset: the k-loop advances the base on the scalar unit, not with 64-bit VALU adds
-  const bf16x8* wbase = reinterpret_cast<const bf16x8*>(wstream + H.wave_stream_off[vwave]);
+  const v8* wbase = reinterpret_cast<const v8*>(wstream + H.wave_stream_off[wave]);
   const long long kss = H.kstep_stride / 8;  // in 16-B fragments-per-lane units
-#if defined(HZ_MLP_X_BUFLOAD)  // experiment: buffer loads with an explicit cache policy (1 = sc0, 2 = nt, 16 = sc1)
-  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wstream, 0, 0x7fffffff, 0x00020000);
-  const int wvoff = (int)(H.wave_stream_off[vwave] * 2) + lane * 16;
-  typedef __attribute__((ext_vector_type(4))) unsigned int hz_u32x4;
-#define wp(k, t) hz_bits_to_bf16x8(__builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff + (t) * 1024, (int)((long long)(k) * kss * 16), HZ_MLP_X_BUFLOAD))
-#elif defined(HZ_MLP_X_NT)  // experiment: non-temporal (streaming) weight loads
-#define wp(k, t) __builtin_nontemporal_load(&wbase[(long long)(k) * kss + (t) * 64 + lane])
-#else
 #define wp(k, t) wbase[(long long)(k) * kss + (t) * 64 + lane]
-#endif
   // Prefetch distance in k-steps.  16-row shapes: HZ_RING - 1 (2 costs 1.7 % moves/s at 4096 envs).  32-row shape: 2 -- one
   // ring slot stays spare, so the refill of a slot does not have to wait for the four MFMAs that have just read it
   // (3: -2.1 % moves/s at 8192 envs, 1: -1.6 %; A/B on one box, tools/ab_bench.sh).
-#ifndef HZ_PF2
-#define HZ_PF2 2
-#endif
-#ifndef HZ_PF1
-#define HZ_PF1 (HZ_RING - 1)
-#endif
-#define HZ_PF (RT == 1 ? HZ_PF1 : HZ_PF2)
-  bf16x8 wf[HZ_RING][NT];
+  constexpr int PF = RT == 1 ? HZ_RING - 1 : 2;
+  v8 wf[HZ_RING][NT];
 #pragma unroll
-  for (int d = 0; d < (HZ_BURST == 1 ? HZ_PF : HZ_RING - HZ_BURST); ++d)
+  for (int d = 0; d < PF; ++d)
 #pragma unroll
     for (int t = 0; t < NT; ++t) wf[d][t] = wp(d, t);
   __builtin_amdgcn_sched_barrier(0);
 
   // stage the states into the image; rows past N read as zero
-#ifndef HZ_MLP_X_NOSTAGE
+#ifndef HZ_MLP_X_NOSTAGE  // (experiment switch, tools/mlp_variants.py)
   for (int base = 0; !PRESTAGED && base < n_stage; base += NTHR * SU) {
     uint4 v[SU];
 #pragma unroll
@@ -300,9 +299,7 @@ __device__ __forceinline__ void mlp_body(
       }
     }
     const unsigned long long p_j0 = PROF_NOW();
-#ifndef HZ_MLP_X_NOBAR  // (experiment switch, tools/mlp_variants.py)
     if (J.flags & HZ_MLP_BARRIER) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // LDS only: loads stay in flight
-#endif
     if (J.flags & HZ_MLP_STORE_HIDDEN) {
       const int chunks = H.hidden / 8;
       for (int i = tid; i < MT * chunks; i += NTHR) {
@@ -320,68 +317,36 @@ __device__ __forceinline__ void mlp_body(
     const unsigned long long p_j1 = PROF_NOW();
     // the first activation fragments right behind the barrier: this LDS round trip is the one latency nothing hides
     const uint16_t* src = lds + (size_t)r0 * rs + J.src_off + kq;
-    // activation fragments, BQD - 1 k-steps ahead of their use (RT = 2 has the registers for one step ahead only; its
-    // four MFMAs per k-step cover the LDS round trip)
-#ifndef HZ_BQD2
-#define HZ_BQD2 2  // (3: measured no faster, more spills)
-#endif
-    constexpr int BQD = RT == 1 ? 4 : HZ_BQD2;
-#ifndef HZ_BQPF1
-#define HZ_BQPF1 3  // how many k-steps ahead the 16-row shapes read their activation fragments (experiment switch)
-#endif
-    constexpr int BQPF = RT == 1 ? HZ_BQPF1 : BQD - 1;
-    bf16x8 bq[BQD][RT];
+    // activation fragments, BQPF k-steps ahead of their use (RT = 2 has the registers for one step ahead only -- two
+    // measured no faster, with more spills; its four MFMAs per k-step cover the LDS round trip)
+    constexpr int BQD = RT == 1 ? 4 : 2;
+    constexpr int BQPF = BQD - 1;
+    v8 bq[BQD][RT];
 #pragma unroll
     for (int d = 0; d < BQPF; ++d)
       if (d < J.ks) {
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) bq[d][rt] = *reinterpret_cast<const bf16x8*>(src + (size_t)(16 * rt) * rs + 32 * d);
+        for (int rt = 0; rt < RT; ++rt) bq[d][rt] = *reinterpret_cast<const v8*>(src + (size_t)(16 * rt) * rs + 32 * d);
       }
     f32x4 acc[NT][RT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) acc[t][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#ifdef HZ_MLP_X_SPLITACC  // experiment: odd k-steps accumulate into a second set (twice the independent MFMA chains)
-    f32x4 acc2[NT][RT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) acc2[t][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#define HZ_ACC(U) (((U) & 1) ? acc2 : acc)
-#else
-#define HZ_ACC(U) acc
-#endif
     __builtin_amdgcn_sched_barrier(0);
 
-#ifdef HZ_MLP_X_NOMFMA2  // experiment (results garbage): only the first row tile's MFMAs
-#define HZ_MFMA_RT 1
-#else
-#define HZ_MFMA_RT RT
-#endif
-#define HZ_MLP_LOADS(S, U)                                                                                           \
-    if (HZ_BURST == 1) {                                                                                             \
-      _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                                 \
-          wf[((U) + HZ_PF) % HZ_RING][t] = wp(gstep + (S) + HZ_PF, t);                                              \
-    } else if ((U) % 2 == 0) { /* two k-steps' fragments back to back: longer bursts per wave on the memory pipe */ \
-      _Pragma("unroll") for (int t = 0; t < 2 * NT; ++t)                                                             \
-          wf[((U) + HZ_RING - 2 + t / NT) % HZ_RING][t % NT] = wp(gstep + (S) + HZ_RING - 2 + t / NT, t % NT);          \
-    }                                                                                                                \
-    if (HZ_MLP_BREAD) { /* unconditional: the last trips read past the K range, into fragments nobody uses */       \
+    // one k-step: request the fragments PF steps ahead (weights) / BQPF steps ahead (activations; unconditional: the last
+    // trips read past the K range, into fragments nobody uses), then this step's MFMAs
+#define HZ_MLP_STEP(S, U)                                                                                            \
+    {                                                                                                                \
+      _Pragma("unroll") for (int t = 0; t < NT; ++t) wf[((U) + PF) % HZ_RING][t] = wp(gstep + (S) + PF, t);          \
       _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                                              \
-          bq[((U) + BQPF) % BQD][rt] =                                                                               \
-              *reinterpret_cast<const bf16x8*>(src + (size_t)(16 * rt) * rs + 32 * ((S) + BQPF));                    \
-    }                                                                                                                \
-    __builtin_amdgcn_sched_barrier(0);
-#define HZ_MLP_MFMAS(S, U)                                                                                           \
-    _Pragma("unroll") for (int t = 0; t < NT; ++t) _Pragma("unroll") for (int rt = 0; rt < HZ_MFMA_RT; ++rt)           \
-        HZ_ACC(U)[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[(U) % HZ_RING][t], bq[(U) % BQD][rt], HZ_ACC(U)[t][rt], 0, 0, 0); \
-    __builtin_amdgcn_sched_barrier(0);
-#ifdef HZ_MLP_X_MFMAFIRST  // experiment: a k-step's MFMAs in front of its loads (the slot they refill was read a step earlier)
-#define HZ_MLP_STEP(S, U) { HZ_MLP_MFMAS(S, U) HZ_MLP_LOADS(S, U) }
-#else
-#define HZ_MLP_STEP(S, U) { HZ_MLP_LOADS(S, U) HZ_MLP_MFMAS(S, U) }
-#endif
+          bq[((U) + BQPF) % BQD][rt] = *reinterpret_cast<const v8*>(src + (size_t)(16 * rt) * rs + 32 * ((S) + BQPF)); \
+      __builtin_amdgcn_sched_barrier(0);                                                                             \
+      _Pragma("unroll") for (int t = 0; t < NT; ++t) _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)               \
+          acc[t][rt] = EL::mfma(wf[(U) % HZ_RING][t], bq[(U) % BQD][rt], acc[t][rt]);                                \
+      __builtin_amdgcn_sched_barrier(0);                                                                             \
+    }
 
     // all but the last 8 k-steps in a loop, the last 8 peeled: the 32 fragment loads they issue sit between the
     // bias / action-row loads above and their first use, so the compiler can wait with vmcnt(>=28) instead of draining
@@ -390,53 +355,29 @@ __device__ __forceinline__ void mlp_body(
     const unsigned long long p_j2 = PROF_NOW();
     int s = 0;
     const int prio_grp = wave >> 2;
-#ifndef HZ_PRIO_SHIFT
-#define HZ_PRIO_SHIFT 2  // the priorities rotate every 2^HZ_PRIO_SHIFT k-steps (experiment switch; -1: fixed, youngest first)
-#endif
-#ifdef HZ_PRIO_BIAS  // experiment: the youngest group always first, the other three rotate below it
-#define HZ_PRIO_EXPR(PH) (prio_grp == 3 ? 3 : (prio_grp + (PH)) % 3)
-#else
-#define HZ_PRIO_EXPR(PH) (prio_grp + (PH))
-#endif
-#ifdef HZ_PRIO_RT2  // experiment: the rotation for the 32-row shape as well
-#define HZ_PRIO_ON true
-#else
-#define HZ_PRIO_ON (RT == 1)
-#endif
-#define HZ_PRIO_AT(S, U)                                                                                  \
-  if (HZ_PRIO_ON && HZ_PRIO_SHIFT >= 0 && ((U) & ((1 << (HZ_PRIO_SHIFT < 0 ? 0 : HZ_PRIO_SHIFT)) - 1)) == 0) \
-    hz_rotate_prio(HZ_PRIO_EXPR((int)((gstep + (S)) >> (HZ_PRIO_SHIFT < 0 ? 0 : HZ_PRIO_SHIFT))));
-    if (HZ_PRIO_ON && HZ_PRIO_SHIFT < 0) hz_rotate_prio(prio_grp);
+    // the priorities rotate every 4 k-steps, 16-row shapes only (see hz_rotate_prio)
+#define HZ_PRIO_AT(S, U) \
+  if (RT == 1 && ((U) & 3) == 0) hz_rotate_prio(prio_grp + (int)((gstep + (S)) >> 2));
     for (; s + 8 < J.ks; s += 8) {
       HZ_PRIO_AT(s, 0) HZ_MLP_STEP(s, 0)
-      HZ_PRIO_AT(s + 1, 1) HZ_MLP_STEP(s + 1, 1)
-      HZ_PRIO_AT(s + 2, 2) HZ_MLP_STEP(s + 2, 2)
-      HZ_PRIO_AT(s + 3, 3) HZ_MLP_STEP(s + 3, 3)
+      HZ_MLP_STEP(s + 1, 1)
+      HZ_MLP_STEP(s + 2, 2)
+      HZ_MLP_STEP(s + 3, 3)
       HZ_PRIO_AT(s + 4, 4) HZ_MLP_STEP(s + 4, 4)
-      HZ_PRIO_AT(s + 5, 5) HZ_MLP_STEP(s + 5, 5)
-      HZ_PRIO_AT(s + 6, 6) HZ_MLP_STEP(s + 6, 6)
-      HZ_PRIO_AT(s + 7, 7) HZ_MLP_STEP(s + 7, 7)
+      HZ_MLP_STEP(s + 5, 5)
+      HZ_MLP_STEP(s + 6, 6)
+      HZ_MLP_STEP(s + 7, 7)
     }
     HZ_PRIO_AT(s, 0) HZ_MLP_STEP(s, 0)
-    HZ_PRIO_AT(s + 1, 1) HZ_MLP_STEP(s + 1, 1)
-    HZ_PRIO_AT(s + 2, 2) HZ_MLP_STEP(s + 2, 2)
-    HZ_PRIO_AT(s + 3, 3) HZ_MLP_STEP(s + 3, 3)
+    HZ_MLP_STEP(s + 1, 1)
+    HZ_MLP_STEP(s + 2, 2)
+    HZ_MLP_STEP(s + 3, 3)
     HZ_PRIO_AT(s + 4, 4) HZ_MLP_STEP(s + 4, 4)
-    HZ_PRIO_AT(s + 5, 5) HZ_MLP_STEP(s + 5, 5)
-    HZ_PRIO_AT(s + 6, 6) HZ_MLP_STEP(s + 6, 6)
-    HZ_PRIO_AT(s + 7, 7) HZ_MLP_STEP(s + 7, 7)
+    HZ_MLP_STEP(s + 5, 5)
+    HZ_MLP_STEP(s + 6, 6)
+    HZ_MLP_STEP(s + 7, 7)
 #undef HZ_PRIO_AT
-#undef HZ_PRIO_EXPR
 #undef HZ_MLP_STEP
-#undef HZ_MLP_LOADS
-#undef HZ_MLP_MFMAS
-#ifdef HZ_MLP_X_SPLITACC
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) acc[t][rt] += acc2[t][rt];
-#endif
-#undef HZ_ACC
     gstep += J.ks;
     PROF_ADD(p_loop, p_j2);
     const unsigned long long p_j3 = PROF_NOW();
@@ -445,7 +386,7 @@ __device__ __forceinline__ void mlp_body(
     if (acc[0][0][0] + acc[NT - 1][0][0] + bv[0].x + av[0][0].x == 12345.678f) lds[tid] = 1;
     continue;
 #endif
-    // epilogue: bias (+ action row) (+ residual) (+ ReLU) in fp32, round to bf16, 4 consecutive columns per lane
+    // epilogue: bias (+ action row) (+ residual) (+ ReLU) in fp32, round to EL, 4 consecutive columns per lane
     const bool relu = J.flags & HZ_MLP_RELU;
     // all residual fragments in one batch of LDS reads (one wait), not one round trip per column tile
     uint2 rr[NT][RT];
@@ -459,7 +400,7 @@ __device__ __forceinline__ void mlp_body(
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) rr[t][rt] = make_uint2(0u, 0u);  // bf16 +0: adds nothing
+        for (int rt = 0; rt < RT; ++rt) rr[t][rt] = make_uint2(0u, 0u);  // +0 in either format: adds nothing
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -469,25 +410,24 @@ __device__ __forceinline__ void mlp_body(
         const size_t rowbase = (size_t)(16 * rt + r0) * rs;
         float v[4] = {acc[t][rt][0] + bv[t].x + av[t][rt].x, acc[t][rt][1] + bv[t].y + av[t][rt].y,
                       acc[t][rt][2] + bv[t].z + av[t][rt].z, acc[t][rt][3] + bv[t].w + av[t][rt].w};
-        v[0] += bf2f((uint16_t)(rr[t][rt].x & 0xffffu)); v[1] += bf2f((uint16_t)(rr[t][rt].x >> 16));
-        v[2] += bf2f((uint16_t)(rr[t][rt].y & 0xffffu)); v[3] += bf2f((uint16_t)(rr[t][rt].y >> 16));
+        v[0] += EL::lo(rr[t][rt].x); v[1] += EL::hi(rr[t][rt].x);
+        v[2] += EL::lo(rr[t][rt].y); v[3] += EL::hi(rr[t][rt].y);
         if (relu) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = (v[r] > 0.0f || v[r] != v[r]) ? v[r] : 0.0f;
         }
         uint2 o;
-        o.x = pack_bf16(v[0], v[1]);
-        o.y = pack_bf16(v[2], v[3]);
+        o.x = EL::pack(v[0], v[1]);
+        o.y = EL::pack(v[2], v[3]);
         *reinterpret_cast<uint2*>(lds + rowbase + J.dst_off + col) = o;
       }
     }
     PROF_ADD(p_epi, p_j3);
   }
+#undef wp
   const unsigned long long p_jobs_done = PROF_NOW();
   (void)p_jobs_done;
-#ifndef HZ_MLP_X_NOPRIO
   __builtin_amdgcn_s_setprio(0);
-#endif
   if (FINAL) __syncthreads();  // (without the final stage the caller's own barrier follows)
   // heads -> scalars / policy logits: 32 lanes per (row, head) pair
 #ifndef HZ_MLP_X_NOFINAL
@@ -497,14 +437,14 @@ __device__ __forceinline__ void mlp_body(
       const int r = pair >> 1, head = pair & 1;
       if (row0 + r < n_rows) {  // (uniform over the 32 lanes of a pair)
         const uint16_t* row = lds + (size_t)r * rs;
-        const float x = row32_support_to_scalar(row + (head ? H.off_value : H.off_reward), H.support_size, H.support_min, l32);
+        const float x = row32_support_to_scalar<EL>(row + (head ? H.off_value : H.off_reward), H.support_size, H.support_min, l32);
         if (l32 == 0) (head ? out_value : out_reward)[row0 + r] = x;
       }
     }
     for (int i = tid; i < MT * H.num_actions; i += NTHR) {
       const int r = i / H.num_actions, a = i % H.num_actions;
       if (row0 + r < n_rows) {
-        float x = bf2f(lds[(size_t)r * rs + H.off_policy + a]);
+        float x = EL::one(lds[(size_t)r * rs + H.off_policy + a]);
         if (x != x) x = 0.0f;  // core/mcts.py:48-49
         out_policy[(size_t)(row0 + r) * H.num_actions + a] = x;
       }
@@ -523,4 +463,3 @@ __device__ __forceinline__ void mlp_body(
   }
 #endif
 }
-

@@ -18,7 +18,7 @@ struct SearchArgs {
   const uint16_t* wstream;
   const float* bias;
   const float* act_tab;
-  uint16_t* pool;          // [S][N][hidden] bf16; plane 0 = root hidden states
+  uint16_t* pool;          // [S][N][hidden] bf16 / fp16 (the MLP header's dtype); plane 0 = root hidden states
   long long plane_stride;  // elements
   long long row_stride;
   int32_t* ix;             // [N] scratch: leaf parent entry of the current simulation (= pool plane)
@@ -80,6 +80,7 @@ __device__ __forceinline__ RowFrag search_first_descent(const TreeView& tv, cons
   return search_request_row(tv, H, a, entry, tree, lane);
 }
 
+template <class EL>
 __device__ __forceinline__ RowFrag search_backup_descent(const TreeView& tv, const hz_mlp_header_t& H, const SearchArgs& a,
                                                          const SearchLds& L, int row0, int tree, int lane, int srow, int sim,
                                                          bool more, TreeLocal& tl, float4& root_row) {
@@ -96,15 +97,11 @@ __device__ __forceinline__ RowFrag search_backup_descent(const TreeView& tv, con
   // lane a takes policy logit a
   {
     const uint16_t* row = L.image + (size_t)srow * H.row_stride;
-#ifdef HZ_SEARCH_X_NOHEADS  // experiment (tools/search_profile.py): what the two scalar transforms cost; results are garbage
-    const float x = bf2f(row[((lane >> 5) ? H.off_value : H.off_reward) + 100]);
-#else
-    const float x = row32_support_to_scalar(row + ((lane >> 5) ? H.off_value : H.off_reward), H.support_size,
-                                            H.support_min, lane & 31);
-#endif
+    const float x = row32_support_to_scalar<EL>(row + ((lane >> 5) ? H.off_value : H.off_reward), H.support_size,
+                                                H.support_min, lane & 31);
     float pl = 0.0f;
     if (lane < tv.A) {
-      pl = bf2f(row[H.off_policy + lane]);
+      pl = EL::one(row[H.off_policy + lane]);
       if (pl != pl) pl = 0.0f;  // core/mcts.py:48-49
     }
     tl.leaf_reward = hz_readlane_f(x, 0);
@@ -121,9 +118,7 @@ __device__ __forceinline__ RowFrag search_backup_descent(const TreeView& tv, con
   f.v[0] = f.v[1] = make_uint4(0u, 0u, 0u, 0u);
   if (lane == a0) root_row = first;  // the one record of the root's row this backup changed
   if (more) {
-#ifndef HZ_SEARCH_X_NOFENCE  // experiment: what draining the backup's record stores before the descent costs
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-#endif
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // (measured: costs nothing)
     int entry;
     TP(5);
     tl.publish = sim + 2 == a.sims;  // the last descent
@@ -134,10 +129,10 @@ __device__ __forceinline__ RowFrag search_backup_descent(const TreeView& tv, con
   return f;
 }
 
-template <int RT>
+template <class EL, int RT>
 __device__ __forceinline__ void search_inference(const hz_mlp_header_t& H, const SearchArgs& a, const SearchLds& L, int sim,
                                                  int n_rows, int row0, const RowFrag* rows) {
-  mlp_body<RT, 16, 2, STAGE_REGS, false>(H, a.jobs, a.wstream, a.bias, a.act_tab, a.pool, a.row_stride, nullptr, a.plane_stride,
+  mlp_body<EL, RT, 16, 2, STAGE_REGS, false>(H, a.jobs, a.wstream, a.bias, a.act_tab, a.pool, a.row_stride, nullptr, a.plane_stride,
                                  L.act_s - row0, a.pool + (size_t)(sim + 1) * a.plane_stride, nullptr, nullptr, nullptr,
                                  n_rows, L.image, row0, rows);
 }
@@ -156,7 +151,7 @@ extern "C" int hz_search_profile_read(unsigned long long* host) {
 // RT = 16-row tiles per workgroup: 1 = one tree per wave (a workgroup per CU covers 4096 trees on 256 CUs); 2 = two trees
 // per wave, taken one after the other in the tree phases, and 32 rows per weight fragment in the inference -- for more
 // trees than 16 x #CUs, where the workgroups would otherwise queue and stream the weights once per 16 rows.
-template <int RT>
+template <class EL, int RT>
 __global__ __launch_bounds__(1024, 1) void k_search(TreeView tv, hz_mlp_header_t H, SearchArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
   constexpr int MT = 16 * RT;
@@ -178,11 +173,7 @@ __global__ __launch_bounds__(1024, 1) void k_search(TreeView tv, hz_mlp_header_t
 #pragma unroll
   for (int s = 0; s < RT; ++s) {
     const int srow = 16 * s + wave;
-#ifdef HZ_SEARCH_X_HALFTREES  // experiment: only 8 of the 16 waves do tree work (is the tree phase issue-bound?)
-    mine[s] = row0 + srow < tv.N && wave < 8;
-#else
     mine[s] = row0 + srow < tv.N;
-#endif
     tl[s].exp_tab = L.exp_s;
     tl[s].pbc_reg = (tv.S < 64 && lane <= tv.S) ? tv.pbc_tab[lane] : 0.0f;
     tl[s].sqrt_reg = sqrtf((float)lane + 1.0f);
@@ -203,7 +194,7 @@ __global__ __launch_bounds__(1024, 1) void k_search(TreeView tv, hz_mlp_header_t
     unsigned long long t1 = SP_NOW();
     // (no barrier here: the inference's own barrier after staging orders the waves' rows and actions)
     unsigned long long t2 = SP_NOW();
-    search_inference<RT>(H, a, L, sim, tv.N, row0, rows);
+    search_inference<EL, RT>(H, a, L, sim, tv.N, row0, rows);
     unsigned long long t3 = SP_NOW();
     __syncthreads();  // leaf outputs visible; the row image is free again
     unsigned long long t4 = SP_NOW();
@@ -212,7 +203,7 @@ __global__ __launch_bounds__(1024, 1) void k_search(TreeView tv, hz_mlp_header_t
 #pragma unroll
     for (int s = 0; s < RT; ++s)
       if (mine[s])
-        rows[s] = search_backup_descent(tv, H, a, L, row0, row0 + 16 * s + wave, lane_t, 16 * s + wave, sim, sim + 1 < a.sims,
+        rows[s] = search_backup_descent<EL>(tv, H, a, L, row0, row0 + 16 * s + wave, lane_t, 16 * s + wave, sim, sim + 1 < a.sims,
                                         tl[s], root_row[s]);
     p_tree += t1 - t0; p_wait1 += t2 - t1; p_mlp += t3 - t2; p_wait2 += t4 - t3;
     t0 = t4;
@@ -227,6 +218,7 @@ __global__ __launch_bounds__(1024, 1) void k_search(TreeView tv, hz_mlp_header_t
 
 // 32 trees per workgroup, the two trees of a wave side by side in its two 32-lane halves (hz_tree_half_dev.h; A <= 32,
 // hidden <= 512): the tree phase of a simulation costs one tree's instruction stream, not two.
+template <class EL>
 __global__ __launch_bounds__(1024, 1) void k_search_half(TreeView tv, hz_mlp_header_t H, SearchArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
   constexpr int MT = 32;
@@ -285,7 +277,7 @@ __global__ __launch_bounds__(1024, 1) void k_search_half(TreeView tv, hz_mlp_hea
     }
   }
   for (int sim = 0; sim < a.sims; ++sim) {
-    mlp_body<2, 16, 2, STAGE_REGS_HALF, false>(H, a.jobs, a.wstream, a.bias, a.act_tab, a.pool, a.row_stride, nullptr,
+    mlp_body<EL, 2, 16, 2, STAGE_REGS_HALF, false>(H, a.jobs, a.wstream, a.bias, a.act_tab, a.pool, a.row_stride, nullptr,
                                                a.plane_stride, L.act_s - row0, a.pool + (size_t)(sim + 1) * a.plane_stride,
                                                nullptr, nullptr, nullptr, tv.N, L.image, row0, &rows);
     __syncthreads();  // leaf outputs visible; the row image is free again
@@ -297,11 +289,11 @@ __global__ __launch_bounds__(1024, 1) void k_search_half(TreeView tv, hz_mlp_hea
     {  // the leaf's heads, from the row image into registers: each half's 32 lanes turn first its reward logits, then its
       // value logits into scalars (uniform within the half); lane l takes policy logit l
       const uint16_t* row = L.image + (size_t)(16 * q.h + wave) * H.row_stride;
-      t.leaf_reward = row32_support_to_scalar(row + H.off_reward, H.support_size, H.support_min, q.l);
-      t.leaf_value = row32_support_to_scalar(row + H.off_value, H.support_size, H.support_min, q.l);
+      t.leaf_reward = row32_support_to_scalar<EL>(row + H.off_reward, H.support_size, H.support_min, q.l);
+      t.leaf_value = row32_support_to_scalar<EL>(row + H.off_value, H.support_size, H.support_min, q.l);
       float pl = 0.0f;
       if (q.l < tv.A) {
-        pl = bf2f(row[H.off_policy + q.l]);
+        pl = EL::one(row[H.off_policy + q.l]);
         if (pl != pl) pl = 0.0f;  // core/mcts.py:48-49
       }
       t.leaf_logit = pl;
@@ -325,28 +317,30 @@ __global__ __launch_bounds__(1024, 1) void k_search_half(TreeView tv, hz_mlp_hea
 #undef HZ_HALF_SETUP
 }
 
-// 0 = choose by the tree count (two trees per wave once one per wave would need more workgroups than the device has
-// compute units), 16 / 32 = force (tests, tools)
-static int g_search_rows_per_workgroup = 0;
-static int g_search_side_by_side = -1;  // two trees per wave: -1 = side by side in the wave's halves when possible, 0 = one after the other
-extern "C" int hz_search_set_rows_per_workgroup(int rows) {
-  HZ_REQUIRE(rows == 0 || rows == 16 || rows == 32 || rows == -32,
-             "hz_search_set_rows_per_workgroup: %d (0 = auto, 16, 32, or -32 = 32 with the trees of a wave one after the other)", rows);
-  g_search_side_by_side = rows == -32 ? 0 : -1;
-  g_search_rows_per_workgroup = rows == -32 ? 32 : rows;
-  return 0;
-}
+// What this library remembers per DEVICE (ordinal of the tree handle, not the calling thread's current device): the compute-
+// unit count and, per kernel variant, the dynamic-LDS limit already raised with hipFuncSetAttribute (a per-device attribute).
+struct SearchDevice {
+  int n_cu;
+  size_t configured[6];
+};
+static SearchDevice g_search_dev[64];
 
+// rows per workgroup: 0 = choose by the tree count (two trees per wave once one per wave would need more workgroups than the
+// device has compute units), 16 / 32 = force, -32 = 32 with the two trees of a wave one after the other (tests, tools)
 extern "C" int hz_search_run(hz_tree_t* t, int num_simulations, const hz_mlp_header_t* H, const hz_mlp_job_t* jobs,
                              const void* wstream, const float* biases, const float* action_table, void* pool,
                              int64_t plane_stride, int64_t row_stride, int32_t* ix, int32_t* iy, int32_t* la,
-                             float* rewards, float* values, float* policy, void* stream) {
+                             float* rewards, float* values, float* policy, int rows_per_workgroup, void* stream) {
   HZ_REQUIRE(t && H && jobs && wstream && biases && action_table && pool && ix && iy && la && rewards && values && policy,
              "hz_search_run: NULL argument");
   HZ_REQUIRE(t->params_set, "hz_search_run: call hz_tree_set_params first");
   HZ_REQUIRE(num_simulations >= 1 && num_simulations < t->S,
              "hz_search_run: num_simulations=%d outside [1, tree capacity %d)", num_simulations, t->S);
   HZ_REQUIRE(t->next_entry == 1, "hz_search_run: the tree must be freshly prepared (hz_tree_prepare)");
+  HZ_REQUIRE(rows_per_workgroup == 0 || rows_per_workgroup == 16 || rows_per_workgroup == 32 || rows_per_workgroup == -32,
+             "hz_search_run: rows_per_workgroup %d (0 = auto, 16, 32, or -32 = 32 with the trees of a wave one after the other)",
+             rows_per_workgroup);
+  HZ_REQUIRE(H->dtype == HZ_BF16 || H->dtype == HZ_F16, "hz_search_run: header dtype must be HZ_BF16 or HZ_F16 (got %d)", H->dtype);
   HZ_REQUIRE(H->num_waves == 16 && H->tiles_per_wave == 2, "hz_search_run: the MLP must be laid out for 16 waves x 2 tiles");
   HZ_REQUIRE(H->num_actions == t->A, "hz_search_run: the MLP has %d actions, the tree %d", H->num_actions, t->A);
   HZ_REQUIRE(H->n_jobs > 0 && H->n_jobs <= 32 && H->support_size > 0 && H->support_size <= 256 &&
@@ -365,41 +359,44 @@ extern "C" int hz_search_run(hz_tree_t* t, int num_simulations, const hz_mlp_hea
              "hz_search_run: kstep_stride must be a multiple of 8 and at least one k-step (512 * tiles_per_wave)");
   HZ_REQUIRE(H->in_width > 0 && H->in_width % 8 == 0, "hz_search_run: in_width must be a positive multiple of 8");
   HZ_REQUIRE(H->in_width == H->hidden && H->hidden <= 1024, "hz_search_run: the recurrent inference maps a hidden state (<= 1024 wide) to a hidden state");
-  int rows_wg = g_search_rows_per_workgroup;
-  if (rows_wg == 0) {
-    static int n_cu = 0;
-    if (n_cu == 0) {
-      int dev = 0;
-      HZ_HIP(hipGetDevice(&dev));
-      HZ_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    }
-    rows_wg = (t->N + 15) / 16 > n_cu ? 32 : 16;
-  }
+  int rows_wg = rows_per_workgroup < 0 ? -rows_per_workgroup : rows_per_workgroup;
+  HZ_REQUIRE(t->device >= 0 && t->device < 64, "hz_search_run: device ordinal %d outside [0, 64)", t->device);
+  SearchDevice& dev = g_search_dev[t->device];
+  if (dev.n_cu == 0) HZ_HIP(hipDeviceGetAttribute(&dev.n_cu, hipDeviceAttributeMultiprocessorCount, t->device));
+  if (rows_wg == 0) rows_wg = (t->N + 15) / 16 > dev.n_cu ? 32 : 16;
   auto lds_for = [&](int mt) {
     return (size_t)mt * H->row_stride * sizeof(uint16_t) + (size_t)mt * (t->S + 1) * (16 + 4) + (size_t)mt * t->S * sizeof(float) +
            (size_t)(mt + 2) * sizeof(float) + 32 * 8 + 128 * sizeof(float) + 256;  // (+256: slack behind the last array)
   };
-  if (rows_wg == 32 && lds_for(32) > 160 * 1024 && g_search_rows_per_workgroup == 0) rows_wg = 16;
+  if (rows_wg == 32 && lds_for(32) > 160 * 1024 && rows_per_workgroup == 0) rows_wg = 16;
   const size_t lds_bytes = lds_for(rows_wg);
   HZ_REQUIRE(lds_bytes <= 160 * 1024, "hz_search_run: %zu B of LDS per workgroup exceed 160 KiB", lds_bytes);
-  const bool halves = rows_wg == 32 && g_search_side_by_side != 0 && t->A <= 32 && H->hidden <= 512;
-  static size_t configured[3] = {0, 0, 0};
-  const int variant = rows_wg == 32 ? (halves ? 2 : 1) : 0;
-  const void* fn = variant == 2 ? (const void*)k_search_half : variant == 1 ? (const void*)k_search<2> : (const void*)k_search<1>;
-  if (lds_bytes > configured[variant]) {
-    HZ_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    configured[variant] = lds_bytes;
-  }
+  const bool halves = rows_wg == 32 && rows_per_workgroup != -32 && t->A <= 32 && H->hidden <= 512;
   SearchArgs a;
   a.jobs = jobs; a.wstream = (const uint16_t*)wstream; a.bias = biases; a.act_tab = action_table;
   a.pool = (uint16_t*)pool; a.plane_stride = plane_stride; a.row_stride = row_stride;
   a.ix = ix; a.iy = iy; a.la = la; a.rew = rewards; a.val = values; a.pol = policy; a.sims = num_simulations;
-  if (variant == 2)
-    hipLaunchKernelGGL(k_search_half, dim3((t->N + 31) / 32), dim3(1024), lds_bytes, (hipStream_t)stream, view(t), *H, a);
-  else if (variant == 1)
-    hipLaunchKernelGGL(k_search<2>, dim3((t->N + 31) / 32), dim3(1024), lds_bytes, (hipStream_t)stream, view(t), *H, a);
-  else
-    hipLaunchKernelGGL(k_search<1>, dim3((t->N + 15) / 16), dim3(1024), lds_bytes, (hipStream_t)stream, view(t), *H, a);
+#define HZ_SEARCH_LAUNCH(VARIANT, KERNEL, GRID)                                                                       \
+  do {                                                                                                                \
+    if (lds_bytes > dev.configured[VARIANT]) {                                                                        \
+      HZ_HIP(hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));    \
+      dev.configured[VARIANT] = lds_bytes;                                                                            \
+    }                                                                                                                 \
+    hipLaunchKernelGGL(KERNEL, dim3(GRID), dim3(1024), lds_bytes, (hipStream_t)stream, view(t), *H, a);               \
+  } while (0)
+#define HZ_SEARCH_LAUNCH_EL(V0, EL)                                                       \
+  do {                                                                                    \
+    if (halves) HZ_SEARCH_LAUNCH(V0 + 2, k_search_half<EL>, (t->N + 31) / 32);            \
+    else if (rows_wg == 32) HZ_SEARCH_LAUNCH(V0 + 1, (k_search<EL, 2>), (t->N + 31) / 32); \
+    else HZ_SEARCH_LAUNCH(V0, (k_search<EL, 1>), (t->N + 15) / 16);                       \
+  } while (0)
+  int cur = -1;
+  HZ_HIP(hipGetDevice(&cur));
+  HZ_REQUIRE(cur == t->device, "hz_search_run: the calling thread's current device is %d, the tree lives on %d", cur, t->device);
+  if (H->dtype == HZ_F16) HZ_SEARCH_LAUNCH_EL(3, ElF16);
+  else HZ_SEARCH_LAUNCH_EL(0, ElBf16);
+#undef HZ_SEARCH_LAUNCH_EL
+#undef HZ_SEARCH_LAUNCH
   HZ_HIP(hipGetLastError());
   t->next_entry = num_simulations + 1;
   return 0;

@@ -219,18 +219,21 @@ class Roots:
         check(lib.hz_tree_get_distributions(self._h, out.data_ptr(), _stream()), "hz_tree_get_distributions")
         return out
 
-    def search_tensors(self, fused, pool, num_simulations, rew, val, pol):
+    def search_tensors(self, fused, pool, num_simulations, rew, val, pol, rows_per_workgroup=0):
         """Every simulation of one move in ONE persistent kernel (include/hz_search.h): `fused` is the engine's
-        FusedRecurrent laid out for 16 waves x 2 tiles, `pool` [S, N, H] bf16 with the root states in plane 0;
-        rew / val [N] f32 and pol [N, A] f32 are scratch.  Returns (ix, iy, last_actions) of the last simulation."""
+        FusedRecurrent laid out for 16 waves x 2 tiles, `pool` [S, N, H] in the engine's bf16 / fp16 with the root states
+        in plane 0; rew / val [N] f32 and pol [N, A] f32 are scratch; rows_per_workgroup: 0 = auto (16 | 32 | -32 force a
+        kernel shape: tests, measurements).  Returns (ix, iy, last_actions) of the last simulation."""
         import ctypes as C
         assert fused.waves == 16 and fused.tiles == 2 and pool.dim() == 3 and pool.shape[1] == self.root_num
+        assert pool.dtype == fused.engine.dtype, "the pool must be in the fused MLP's element format"
         assert self._sim == 0, "search_tensors needs freshly prepared roots"
         ix, iy, la = self._ix, self._iy, self._la
         check(lib.hz_search_run(self._h, int(num_simulations), C.byref(fused.header), fused.jobs.data_ptr(),
                                 fused.weights.data_ptr(), fused.biases.data_ptr(), fused.act_table.data_ptr(),
                                 pool.data_ptr(), pool.stride(0), pool.stride(1), ix.data_ptr(), iy.data_ptr(),
-                                la.data_ptr(), rew.data_ptr(), val.data_ptr(), pol.data_ptr(), _stream()),
+                                la.data_ptr(), rew.data_ptr(), val.data_ptr(), pol.data_ptr(), int(rows_per_workgroup),
+                                _stream()),
               "hz_search_run")
         self._sim += int(num_simulations)
         return ix, iy, la

@@ -15,9 +15,10 @@ from .model import InferenceEngine
 
 
 class MCTS(object):
-    def __init__(self, config, persistent=True):
+    def __init__(self, config, persistent=True, rows_per_workgroup=0):
         self.config = config
         self.persistent = persistent  # fused engines: the whole simulation loop as one persistent kernel
+        self.rows_per_workgroup = rows_per_workgroup  # of that kernel: 0 = auto, 16 / 32 / -32 force a shape (tests, tools)
 
     def run_multi(self, roots, model, hidden_state_roots, pool=None):
         """roots: hanabizero_amd.cytree.Roots (already prepared).  model: an InferenceEngine (fast path) or a
@@ -47,7 +48,7 @@ class MCTS(object):
                 fused16 = model.fused_shape(16, 2) if self.persistent else None
                 if fused16 is not None and fused16.lds_bytes(16) + 16 * (24 * (S + 1) + 4 * roots.action_num + 16) + 512 <= 160 * 1024:
                     # the whole loop below as ONE persistent kernel: a workgroup keeps 16 trees for all simulations
-                    roots.search_tensors(fused16, pool, S - 1, rew, val, pol)
+                    roots.search_tensors(fused16, pool, S - 1, rew, val, pol, self.rows_per_workgroup)
                     return
                 # 2 launches per simulation: [MFMA recurrent inference] [backup of sim k + descent of sim k+1]
                 ix, _, la = roots.traverse_tensors()  # the MFMA kernel gathers pool[ix, tree] itself

@@ -195,13 +195,15 @@ _FUSED_ACT = hasattr(torch, "_addmm_activation")
 
 
 class _Lin:
-    """y = x @ W^T + b with W [out, in] resident in `dtype` and handed to the GEMM as its transposed view (the "TN" form
-    hipBLASLt runs 15-20 % faster than a pre-transposed [in, out] copy for these shapes); optional in-place ReLU."""
+    """y = x @ W^T + b with W [out, in] resident in the engine's dtype and handed to the GEMM as its transposed view (the
+    "TN" form hipBLASLt runs 15-20 % faster than a pre-transposed [in, out] copy for these shapes); optional in-place
+    ReLU.  `put` = InferenceEngine._put: the device tensors are allocated by the first load() and overwritten in place by
+    later ones."""
 
-    def __init__(self, w, b, dtype, device):
-        self.w = w.contiguous().to(device=device, dtype=dtype)
+    def __init__(self, w, b, put):
+        self.w = put(w)
         self.wt = self.w.t()
-        self.b = b.to(device=device, dtype=dtype)
+        self.b = put(b)
 
     def __call__(self, x, relu=False, out=None):
         if relu and out is None and _FUSED_ACT:
@@ -225,14 +227,35 @@ class InferenceEngine:
         self.A, self.H = net.action_space_n, net.feature_size
         self.support = int(support)
         self.full = isinstance(net, MuZeroNetFull)
-        self.use_fused = (dtype == torch.bfloat16 and self.device.type == "cuda") if fused is None else bool(fused)
+        self.use_fused = (dtype in (torch.bfloat16, torch.float16) and self.device.type == "cuda") if fused is None else bool(fused)
         self.fused = None
         self._obs_pad = None  # (D, Dp, stack) once pad_observations() has been asked for
+        self._dev, self._seq = {}, 0  # device tensors by creation order within a load()
+        self._fused_shapes, self.fused_tail = {}, None
+        self.version = 0
         self.load(net)
 
+    def _put(self, t, dtype=None, name=None):
+        """The device-resident copy of host tensor `t`: allocated by the first load(), overwritten IN PLACE by every later
+        one.  A hipGraph captured over this engine (SelfPlayActor._capture) has the tensors' addresses baked in, so a
+        weight update must never move them: engine.load(net) after net.set_weights(...) is all a running actor needs."""
+        if name is None:
+            name, self._seq = "t%d" % self._seq, self._seq + 1
+        t = t.detach().to(dtype or self.dtype).contiguous()
+        cur = self._dev.get(name)
+        if cur is None:
+            cur = self._dev[name] = t.to(self.device)
+        else:
+            assert cur.shape == t.shape and cur.dtype == t.dtype, "load(): %s changed shape %s -> %s" % (name, tuple(cur.shape), tuple(t.shape))
+            cur.copy_(t)
+        return cur
+
     def load(self, net):
-        """(Re)build the folded weights from `net` (call after set_weights: selfplay_worker.py:177-184)."""
-        L = lambda lin, bn=None: _Lin(*_fold(lin, bn), self.dtype, self.device)
+        """(Re)build the folded weights from `net` (call after set_weights: selfplay_worker.py:177-184).  Every device
+        tensor keeps its address (see _put), so captured graphs and concurrent readers on this stream see the new weights
+        from their next replay on."""
+        self._seq = 0
+        L = lambda lin, bn=None: _Lin(*_fold(lin, bn), self._put)
         rep, dyn = net._representation, net._dynamics_state
         rw, ac, va = net._dynamics_reward, net._prediction_actor, net._prediction_value
         if self.full:
@@ -246,19 +269,19 @@ class InferenceEngine:
             self.pad_observations(self._obs_pad[0], self._obs_pad[2])
         # dynamics layer 1: split [W_state | W_action]; the one-hot product is a row lookup of W_action^T
         w1, b1 = _fold(dyn.fc1, dyn.bn1)
-        self.dyn1 = _Lin(w1[:, :self.H], b1, self.dtype, self.device)
-        self.dyn1_act = w1[:, self.H:].t().contiguous().to(device=self.device, dtype=self.dtype)  # [A, H]
+        self.dyn1 = _Lin(w1[:, :self.H], b1, self._put)
+        self.dyn1_act = self._put(w1[:, self.H:].t())  # [A, H]
         # ... and the same layer over the [state | one-hot | 0-pad] rows the traverse kernel writes (K padded to 32)
         self.onehot_cols = ((self.A + 31) // 32) * 32
         w1p = torch.zeros(w1.shape[0], self.H + self.onehot_cols)
         w1p[:, :w1.shape[1]] = w1
-        self.dyn1p = _Lin(w1p, b1, self.dtype, self.device)
+        self.dyn1p = _Lin(w1p, b1, self._put)
         self.dyn2, self.dyn3 = L(dyn.fc2, dyn.bn2), L(dyn.fc3, dyn.bn3)
         # the three heads' first layers share their input: one GEMM [512 -> 3h] (reward | actor | value)
         ws, bs = zip(_fold(rw[0], rw[1]), _fold(ac[0], ac[1]), _fold(va[0], va[1]))
         self.h = ws[0].shape[0]
-        self.heads1 = _Lin(torch.cat(ws, 0), torch.cat(bs, 0), self.dtype, self.device)
-        self.pred1 = _Lin(torch.cat(ws[1:], 0), torch.cat(bs[1:], 0), self.dtype, self.device)
+        self.heads1 = _Lin(torch.cat(ws, 0), torch.cat(bs, 0), self._put)
+        self.pred1 = _Lin(torch.cat(ws[1:], 0), torch.cat(bs[1:], 0), self._put)
         # search-loop form: each head block is h real columns + 32 pad columns whose first one is a constant 1
         # (zero weights, bias 1, ReLU(1) = 1): it carries the next layers' biases through plain batched GEMMs
         self.hp = self.h + 32
@@ -268,7 +291,7 @@ class InferenceEngine:
             one = torch.zeros(32)
             one[0] = 1.0
             bpad.append(torch.cat((b, one), 0))
-        self.heads1p = _Lin(torch.cat(wpad, 0), torch.cat(bpad, 0), self.dtype, self.device)
+        self.heads1p = _Lin(torch.cat(wpad, 0), torch.cat(bpad, 0), self._put)
         if self.full:
             self.rw_tail = [L(rw[3], rw[4]), L(rw[6])]
             self.ac_tail = [L(ac[3].fc1, ac[3].bn1), L(ac[3].fc2, ac[3].bn2), L(ac[4])]
@@ -282,9 +305,18 @@ class InferenceEngine:
             self.out_pad = ((max(2 * self.support + 1, self.A) + 31) // 32) * 32
             self.bw3 = self._stack([_fold(rw[3]), _fold(ac[3]), _fold(va[3])], self.out_pad, False)
         self.V = 2 * self.support + 1
-        self.fused = FusedRecurrent(net, self) if self.use_fused else None
-        self.fused_tail = FusedInitialTail(net, self, 8, 4) if (self.use_fused and self.full) else None  # 8 x 4: fastest stand-alone shape
-        self._net, self._fused_shapes = net, {(4, 4): self.fused}
+        self._net = net
+        if self.use_fused:
+            if not self._fused_shapes:
+                self._fused_shapes[(4, 4)] = FusedRecurrent(net, self)
+                self.fused_tail = FusedInitialTail(net, self, 8, 4) if self.full else None  # 8 x 4: fastest stand-alone shape
+            else:  # same job tables, new numbers: into the tensors the kernels (and captured graphs) already point at
+                for (waves, tiles), chain in self._fused_shapes.items():
+                    chain.reload(FusedRecurrent(net, self, waves, tiles, host_only=True))
+                if self.fused_tail is not None:
+                    self.fused_tail.reload(FusedInitialTail(net, self, 8, 4, host_only=True))
+            self.fused = self._fused_shapes[(4, 4)]
+        self.version += 1
 
     def pad_observations(self, D, stack, multiple=8):
         """Lay the first representation layer out for observation windows whose `stack` slots are padded from D to
@@ -297,12 +329,14 @@ class InferenceEngine:
         assert w.shape[1] == stack * D, (w.shape, stack, D)
         wp = torch.zeros(w.shape[0], stack, Dp)
         wp[:, :, :D] = w.view(w.shape[0], stack, D)
-        self.rep0p = _Lin(wp.reshape(w.shape[0], stack * Dp), b, self.dtype, self.device)
+        put = lambda t, _names=iter(("rep0p.w", "rep0p.b")): self._put(t, name=next(_names))
+        self.rep0p = _Lin(wp.reshape(w.shape[0], stack * Dp), b, put)
         self._obs_pad = (D, Dp, stack)
         return Dp
 
     def fused_shape(self, waves, tiles):
-        """The fused recurrent inference laid out for another workgroup shape (16 x 2: the persistent search kernel)."""
+        """The fused recurrent inference laid out for another workgroup shape (16 x 2: the persistent search kernel);
+        built on first use, refreshed in place by every later load()."""
         if not self.use_fused:
             return None
         if (waves, tiles) not in self._fused_shapes:
@@ -319,7 +353,7 @@ class InferenceEngine:
             out[k, self.h, :b.shape[0]] = b
             if carry_one:
                 out[k, self.h, self.h] = 1.0
-        return out.to(device=self.device, dtype=self.dtype)
+        return self._put(out)
 
     # -- pieces ---------------------------------------------------------------------------------------
     def _scalar(self, logits):
@@ -470,13 +504,15 @@ class _FusedChain:
     """A chain of Linear(+folded BN)(+residual)(+ReLU) layers as the job table + per-wave weight streams of the fused
     MFMA kernel (include/hz_mlp.h).  Subclasses describe the layers with add_dense / add_group and call _finish."""
 
-    def __init__(self, engine, waves, tiles):
+    def __init__(self, engine, waves, tiles, host_only=False):
         """waves x tiles: the workgroup shape of the kernel -- `waves` wavefronts, each producing `tiles` 16-column
         MFMA tiles per job (4 x 4 stand-alone, 16 x 2 inside the persistent search kernel).  Same arithmetic per
-        output column either way (k accumulates in the same order), so the shapes give identical bits."""
-        assert engine.dtype == torch.bfloat16, "the fused kernel computes in bf16 (fp32 accumulate)"
-        assert (waves, tiles) in ((4, 4), (8, 4), (8, 2), (16, 2))
+        output column either way (k accumulates in the same order), so the shapes give identical bits.
+        host_only: build the tables on the host only (the source of another chain's reload())."""
+        assert engine.dtype in (torch.bfloat16, torch.float16), "the fused kernel computes in bf16 or fp16 (fp32 accumulate)"
+        assert (waves, tiles) in ((4, 4), (8, 4), (16, 2))
         self.engine, self.device, self.waves, self.tiles = engine, engine.device, waves, tiles
+        self.host_only = host_only
         self.cw = 16 * tiles   # output columns of one job
         self._jobs = []        # [pass] -> dict(entries [wave] -> dict or None, barrier, store_hidden)
 
@@ -596,20 +632,34 @@ class _FusedChain:
                 W[:steps[wave], wave] = torch.cat(streams[wave]).view(-1, frag)
         hdr = MlpHeader(n_jobs=len(jobs), row_stride=rs, hidden=hidden, state_off=state_off, hidden_off=hidden_off,
                         off_reward=off_r, off_value=off_v, off_policy=off_p, support_size=V, support_min=-engine.support,
-                        num_actions=A, action_table_stride=biases.numel(), in_width=in_width, num_waves=waves,
-                        tiles_per_wave=tiles, kstep_stride=waves * tiles * 512)
+                        num_actions=A, action_table_stride=biases.numel(), in_width=in_width,
+                        dtype={torch.bfloat16: 1, torch.float16: 2}[engine.dtype],  # HZ_BF16 / HZ_F16 (include/hz_tree.h)
+                        num_waves=waves, tiles_per_wave=tiles, kstep_stride=waves * tiles * 512)
         for wave in range(waves):
             hdr.wave_stream_off[wave] = wave * frag
         self.header = hdr
         self.n_jobs = len(jobs)
         buf = (MlpJob * len(table))(*table)
-        self.jobs = torch.frombuffer(bytearray(bytes(buf)), dtype=torch.uint8).to(self.device)
-        self.weights = W.reshape(-1).to(device=self.device, dtype=torch.bfloat16).contiguous()
-        self.biases = biases.to(device=self.device, dtype=torch.float32).contiguous()
-        self.act_table = act_table.to(device=self.device, dtype=torch.float32).contiguous()
+        self._host = dict(jobs=torch.frombuffer(bytearray(bytes(buf)), dtype=torch.uint8),
+                          weights=W.reshape(-1).to(engine.dtype).contiguous(),  # (round-to-nearest-even from the fp32 fold)
+                          biases=biases.float().contiguous(), act_table=act_table.float().contiguous())
+        if not self.host_only:
+            for k, v in self._host.items():
+                setattr(self, k, v.to(self.device))
+            self._host = None
         self.row_stride = rs
         self.weight_bytes_per_wg = int(sum(sum(x.numel() for x in s) for s in streams) * 2)
         self._jobs = None
+
+    def reload(self, other):
+        """New weights into the device tensors this chain (and any hipGraph captured over it) already uses: `other` is the
+        same chain built host_only from the updated module."""
+        assert other.host_only and (other.waves, other.tiles, other.n_jobs) == (self.waves, self.tiles, self.n_jobs)
+        assert bytes(other.header) == bytes(self.header), "reload(): the layer chain changed shape"
+        for k, v in other._host.items():
+            cur = getattr(self, k)
+            assert cur.shape == v.shape and cur.dtype == v.dtype, k
+            cur.copy_(v)
 
     def lds_bytes(self, rows_per_wg):
         return rows_per_wg * self.row_stride * 2
@@ -638,8 +688,8 @@ class FusedRecurrent(_FusedChain):
     __call__(pool [S, N, H] bf16, ix [N] i32, actions [N] i32, hidden_out [N, H] bf16, out_reward [N], out_value [N],
              out_policy [N, A])   (fp32 outputs; buffers supplied by the caller, nothing is allocated)"""
 
-    def __init__(self, net, engine, waves=4, tiles=4):
-        super().__init__(engine, waves, tiles)
+    def __init__(self, net, engine, waves=4, tiles=4, host_only=False):
+        super().__init__(engine, waves, tiles, host_only)
         add_dense, add_group = self.add_dense, self.add_group
         H, A, h, full, V = engine.H, engine.A, engine.h, engine.full, 2 * engine.support + 1
         dyn, rw, ac, va = net._dynamics_state, net._dynamics_reward, net._prediction_actor, net._prediction_value
@@ -720,8 +770,8 @@ class FusedInitialTail(_FusedChain):
 
     __call__(x [N, 1024] bf16, hidden_out [N, H] bf16, out_value [N] f32, out_policy [N, A] f32)"""
 
-    def __init__(self, net, engine, waves=4, tiles=4):
-        super().__init__(engine, waves, tiles)
+    def __init__(self, net, engine, waves=4, tiles=4, host_only=False):
+        super().__init__(engine, waves, tiles, host_only)
         assert engine.full, "laid out for MuZeroNetFull"
         add_dense, add_group = self.add_dense, self.add_group
         H, A, h, V = engine.H, engine.A, engine.h, 2 * engine.support + 1
@@ -749,7 +799,7 @@ class FusedInitialTail(_FusedChain):
 
     def __call__(self, x, hidden_out, out_value, out_policy, rows_per_wg=None):
         N = x.shape[0]
-        assert x.dtype == torch.bfloat16 and x.shape[1] == self.in_width and x.stride(1) == 1
+        assert x.dtype == self.engine.dtype and x.shape[1] == self.in_width and x.stride(1) == 1
         if self._zeros is None or self._zeros[0].shape[0] < N:
             self._zeros = (torch.zeros(N, dtype=torch.int32, device=x.device), torch.empty(N, dtype=torch.float32, device=x.device))
         actions, dummy = self._zeros

@@ -60,7 +60,8 @@ typedef struct {
   int32_t in_width;              /* elements of an input row staged at state_off (multiple of 8; = hidden for the
                                     recurrent inference, the width of the last big representation layer for the tail
                                     of the initial inference) */
-  int32_t reserved;
+  int32_t dtype;                 /* element format of weights, activations and state rows: HZ_BF16 or HZ_F16
+                                    (include/hz_tree.h); accumulation and epilogues are fp32 in both */
   int32_t num_waves;             /* 4 (stand-alone kernel) or 16 (inside hz_search_run) */
   int32_t tiles_per_wave;        /* 16-column MFMA tiles per job: 4 with 4 waves, 2 with 16 waves */
   int64_t kstep_stride;          /* elements between consecutive k-steps of one wave's stream: 512 * tiles_per_wave when

@@ -25,21 +25,21 @@ extern "C" {
 /* t                freshly prepared tree (hz_tree_prepare), parameters set (hz_tree_set_params)
  * num_simulations  simulations to run: the reference runs config.num_simulations - 1 (core/mcts.py:27-29)
  * H, jobs, wstream, biases, action_table   the MLP as for hz_mlp_recurrent, laid out for num_waves = 16, tiles = 2
- * pool             [>= num_simulations + 1][N][hidden] bf16 (DEVICE), plane 0 = the roots' hidden states; plane k+1
+ * pool             [>= num_simulations + 1][N][hidden] bf16 or fp16 (DEVICE), plane 0 = the roots' hidden states; plane k+1
  *                  receives the hidden states simulation k produces; plane_stride / row_stride in elements
  * ix, iy, la       [N] i32 scratch (DEVICE): on return the values of the last simulation
  * rewards, values  [N] f32, policy [N][num_actions] f32 (DEVICE): reserved -- the leaf outputs stay on chip (row image ->
- *                  registers of the tree's wave) and these arrays are not written; they must still be valid pointers */
+ *                  registers of the tree's wave) and these arrays are not written; they must still be valid pointers
+ * rows_per_workgroup  trees per workgroup: 0 = chosen from the tree count and the compute-unit count of the tree's device
+ *                  (the product's setting), 16 or 32 = forced (tests, measurements); with 32 the two trees of a wavefront
+ *                  are searched side by side in its two 32-lane halves when num_actions <= 32 and hidden <= 512, -32 forces
+ *                  them one after the other.  The results do not depend on any of it.
+ * The MLP header's dtype (HZ_BF16 / HZ_F16) selects the element format of pool, weights and activations.
+ * The calling thread's current device must be the tree's. */
 int hz_search_run(hz_tree_t* t, int num_simulations, const hz_mlp_header_t* H, const hz_mlp_job_t* jobs,
                   const void* wstream, const float* biases, const float* action_table, void* pool,
                   int64_t plane_stride, int64_t row_stride, int32_t* ix, int32_t* iy, int32_t* la, float* rewards,
-                  float* values, float* policy, void* stream);
-
-/* Trees per workgroup of the following hz_search_run calls of this process: 0 = chosen from the tree count (default),
- * 16 or 32 = forced (tests, measurements); with 32 the two trees of a wavefront are searched side by side in its two
- * 32-lane halves when num_actions <= 32 and hidden <= 512, -32 forces them one after the other.  The results do not depend
- * on any of it. */
-int hz_search_set_rows_per_workgroup(int rows);
+                  float* values, float* policy, int rows_per_workgroup, void* stream);
 
 #ifdef __cplusplus
 }

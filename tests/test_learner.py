@@ -1,7 +1,6 @@
 """The learner step (hanabizero_amd/learner.py): targets, gradient shaping and the optimiser step against
-independent restatements in fp32 on the CPU; the bf16-autocast step on the GPU.
-The reference's own update_weights (core/train.py:59-314) cannot be imported here (it imports ray at module level), so this
-row's parity is pinned by restatement only -- DESIGN.md says so."""
+independent restatements in fp32 on the CPU; the bf16-autocast step on the GPU.  (The step itself and make_batch are pinned
+to the reference's own update_weights / batch workers by tests/test_reference_callers.py; these tests cover the pieces.)"""
 import numpy as np
 import pytest
 import torch
@@ -283,8 +282,8 @@ def test_self_play_to_learner_loop_on_one_gpu():
         losses.append(loss_data[1])
     assert np.isfinite(losses).all()
     learner.eval()
-    eng.load(learner.cpu())            # selfplay_worker.py:177-184: the actor picks the new weights up
-    actor._graph = None                # (the captured graph holds the old fused tables: capture again)
+    eng.load(learner.cpu())            # selfplay_worker.py:177-184: the actor picks the new weights up (in place: the
+                                       # captured hipGraph keeps pointing at live tensors, nothing is captured again)
     before = int(actor.out_count[0].item())
     for _ in range(8):
         actor.step()

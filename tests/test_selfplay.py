@@ -7,21 +7,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def ref_select_action(visit_counts, legal, u):
-    """core/utils.py:280-295 with temperature 1, non-deterministic; np.random.choice's algorithm with a given u."""
-    visit_counts = list(visit_counts)
-    for i in range(len(legal)):
-        if legal[i] == 0 and visit_counts[i] >= 1:
-            visit_counts[i] = 0
-    probs = [float(v) ** 1.0 for v in visit_counts]
-    total = sum(probs)
-    probs = [x / total for x in probs]
-    cdf = np.cumsum(np.array(probs, dtype=np.float64))
-    cdf /= cdf[-1]
-    a = int(cdf.searchsorted(u, side="right"))
-    pk = np.array(probs) / np.sum(probs)
-    ent = -np.sum(np.where(pk > 0, pk * np.log(np.where(pk > 0, pk, 1.0)), 0.0)) / np.log(2.0)
-    return a, ent, visit_counts
+from tests.restate import ref_select_action  # noqa: E402  (checked against the reference: tests/test_reference_callers.py)
 
 
 def make(game, N, sims, stack, dtype, use_graph, seed=3, peaked=False):
@@ -137,6 +123,41 @@ def test_graph_replay_equals_eager():
         assert (outs[0][2][k] == outs[1][2][k]).all(), k
 
 
+@pytest.mark.parametrize("game,dtype", [("Hanabi-Small", torch.bfloat16), ("Hanabi-Full", torch.float16)])
+def test_engine_load_reaches_a_graph_captured_actor(game, dtype):
+    """A weight update (net.set_weights(w); engine.load(net): selfplay_worker.py:177-184) must reach an actor whose lock-step
+    is a captured hipGraph -- the graph has the engine's tensor addresses baked in, so load() overwrites them in place.
+    A graph actor and an eager actor (which reads the engine's tensors at call time: the ground truth) play 3 moves,
+    both engines load new weights, they play 4 more: everything they record must agree, and must differ from a graph
+    actor that kept the old weights."""
+    import copy
+    runs = []
+    for use_graph, reload in ((True, True), (False, True), (True, False)):
+        cfg, eng, actor = make(game, 64, 12, 2, dtype, use_graph, seed=21)
+        ptrs = sorted(t.data_ptr() for t in eng._dev.values())
+        for _ in range(3):
+            actor.step()
+        if reload:
+            net2 = copy.deepcopy(eng._net)
+            g = torch.Generator().manual_seed(5)
+            with torch.no_grad():
+                for p in net2.parameters():
+                    p.add_(0.05 * torch.randn(p.shape, generator=g))
+            v_before = eng.version
+            eng.load(net2)
+            assert eng.version == v_before + 1
+            assert sorted(t.data_ptr() for t in eng._dev.values()) == ptrs, "load() moved a device tensor"
+        for _ in range(4):
+            actor.step()
+        torch.cuda.synchronize()
+        assert int(actor.illegal_steps) == 0
+        runs.append((actor.counts.clone(), actor.values.clone(), actor.action.clone(), actor.pool.clone(),
+                     actor.traj["action"].clone(), actor.traj_len.clone(), actor.env.probe().clone()))
+    for a, b in zip(runs[0], runs[1]):
+        assert torch.equal(a, b), "the graph actor did not see the weights the eager actor saw"
+    assert not torch.equal(runs[0][0], runs[2][0]) and not torch.equal(runs[0][3], runs[2][3]), "the new weights changed nothing"
+
+
 def test_root_noise_stream_is_dirichlet_and_sharding_independent():
     """hz_actor_draw: Dirichlet(alpha) rows (marginals Beta(alpha, (A-1) alpha), KS test), U[0,1) uniforms, and the
     draws of env i at move k depend only on (seed, global env id, k)."""
@@ -191,17 +212,20 @@ def test_select_action_kernel_edge_cases():
     assert act.tolist() == [10, 0, -1, 1, 0]
 
 
-@pytest.mark.parametrize("game,N,sims,peaked", [("Hanabi-Small", 100, 12, False), ("Hanabi-Full", 50, 50, False),
-                                                ("Hanabi-Full", 1000, 20, False), ("Hanabi-Full-5p", 70, 30, False),
-                                                ("Hanabi-Full", 4170, 8, False), ("Hanabi-Full", 45, 50, True)])
-def test_persistent_search_kernel_equals_launch_per_phase(game, N, sims, peaked):
+@pytest.mark.parametrize("game,N,sims,peaked,dtype", [
+    ("Hanabi-Small", 100, 12, False, torch.bfloat16), ("Hanabi-Full", 50, 50, False, torch.bfloat16),
+    ("Hanabi-Full", 1000, 20, False, torch.bfloat16), ("Hanabi-Full-5p", 70, 30, False, torch.bfloat16),
+    ("Hanabi-Full", 4170, 8, False, torch.bfloat16), ("Hanabi-Full", 45, 50, True, torch.bfloat16),
+    ("Hanabi-Small", 100, 12, False, torch.float16), ("Hanabi-Full", 1000, 20, False, torch.float16),
+    ("Hanabi-Full-5p", 70, 30, False, torch.float16), ("Hanabi-Full", 45, 50, True, torch.float16)])
+def test_persistent_search_kernel_equals_launch_per_phase(game, N, sims, peaked, dtype):
     """hz_search_run (all simulations in one persistent kernel, a workgroup per 16 trees) against the launch-per-phase
     search (hz_tree_traverse -> hz_mlp_recurrent -> hz_tree_backprop_traverse ...): bit-identical trees, hidden-state
     pools and leaf outputs; the launch-per-phase path itself is pinned to the oracle by the tests above."""
     from hanabizero_amd import cytree
-    from hanabizero_amd._lib import check, lib
     from hanabizero_amd.mcts import MCTS
-    cfg, eng, actor = make(game, N, sims, 2, torch.bfloat16, use_graph=False, peaked=peaked)
+    cfg, eng, actor = make(game, N, sims, 2, dtype, use_graph=False, peaked=peaked)
+    assert eng.fused is not None and eng.fused.header.dtype == {torch.bfloat16: 1, torch.float16: 2}[dtype]
     A = cfg.action_space_size
     g = torch.Generator(device="cuda").manual_seed(N)
     value0, logits0, hidden0 = actor.root_inference()
@@ -212,15 +236,14 @@ def test_persistent_search_kernel_equals_launch_per_phase(game, N, sims, peaked)
     # or one after the other (-32; what A = 48 gets either way); the library's own choice (two once the trees outnumber
     # 16 per compute unit: the last case)
     for persistent in (False, 16, 32, -32, "auto"):
-        check(lib.hz_search_set_rows_per_workgroup(0 if persistent == "auto" else int(persistent)), "hz_search_set_rows_per_workgroup")
         roots = cytree.Roots(N, A, sims, tie_seed=5, tree_id_base=17)
         roots.prepare(0.0 if peaked else cfg.root_exploration_fraction, noise, torch.zeros(N, device="cuda"), logits0, actor.legal)
         pool = torch.zeros(sims, N, eng.H, dtype=eng.dtype, device="cuda")
-        MCTS(cfg, persistent=bool(persistent)).run_multi(roots, eng, hidden0, pool=pool)
+        MCTS(cfg, persistent=bool(persistent), rows_per_workgroup=0 if persistent in (False, "auto") else int(persistent)
+             ).run_multi(roots, eng, hidden0, pool=pool)
         torch.cuda.synchronize()
         res.append((roots.distributions_tensor(), roots.values_tensor(), roots.trajectories_tensor(),
                     roots.minmax_tensors(), roots.path_len_tensor(), pool))
-    check(lib.hz_search_set_rows_per_workgroup(0), "hz_search_set_rows_per_workgroup")
     a = res[0]
     for b in res[1:]:
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[4], b[4])
@@ -295,7 +318,7 @@ def test_fused_launches_equal_their_separate_calls():
 
 
 def test_new_entry_points_report_bad_arguments():
-    """hz_actor_pack / hz_actor_packed_bytes / hz_env_reset_rows / hz_actor_begin_move_draw / hz_search_set_rows_per_workgroup:
+    """hz_actor_pack / hz_actor_packed_bytes / hz_env_reset_rows / hz_actor_begin_move_draw / hz_search_run:
     malformed calls come back as error codes with a message (the reference aborts or corrupts memory), nothing is launched."""
     import ctypes as C
     from hanabizero_amd._lib import HzError, RowsJob, check, lib
@@ -328,8 +351,13 @@ def test_new_entry_points_report_bad_arguments():
                                            actor.stack_buf.stride(0) * es, actor.stack, actor.Dp * es, 1,
                                            actor.move_count.data_ptr(), 0.0, actor.noise.data_ptr(), actor.uniform.data_ptr(), st),
               "begin_move_draw")
-    with pytest.raises(HzError):
-        check(lib.hz_search_set_rows_per_workgroup(48), "rows")
+    from hanabizero_amd import cytree
+    roots = cytree.Roots(32, actor.A, actor.S)
+    roots.prepare(0.25, actor.noise, actor.zeros_n, torch.zeros(32, actor.A, device="cuda"), actor.legal)
+    roots.set_params(cfg.pb_c_base, cfg.pb_c_init, cfg.discount, cfg.value_delta_max)
+    rew, pol = torch.zeros(32, device="cuda"), torch.zeros(32, actor.A, device="cuda")
+    with pytest.raises(HzError):  # rows per workgroup: 0, 16, 32 or -32
+        roots.search_tensors(eng.fused_shape(16, 2), actor.pool, actor.S - 1, rew, rew, pol, rows_per_workgroup=48)
     torch.cuda.synchronize()
     for _ in range(3):  # and the actor is still in working order
         actor.step()

@@ -1,4 +1,4 @@
-"""Lock-step time with one vs two trees per wavefront of the persistent search kernel (hz_search_set_rows_per_workgroup).
+"""Lock-step time with one vs two trees per wavefront of the persistent search kernel (hz_search_run's rows_per_workgroup argument).
 usage: python tools/search_rows.py [workload=full8192] [steps=12]"""
 import os
 import sys
@@ -22,8 +22,8 @@ def main():
     cfg = make_config(game, simulations=S, stack=stack, p_mcts_num=N)
     engine = bench.build_engine(cfg, torch.bfloat16, device, fused=None)
     for rows in (16, -32, 32):  # one tree per wave; two, one after the other; two, side by side in the halves
-        check(lib.hz_search_set_rows_per_workgroup(rows), "rows")
         actor = SelfPlayActor(cfg, engine, N, seed=0, device=device, use_graph=True)
+        actor.mcts.rows_per_workgroup = rows
         actor._capture()
         for _ in range(3):
             actor.step()
@@ -35,7 +35,6 @@ def main():
         dt = (time.perf_counter() - t0) / steps
         print("%s rows/workgroup %d: %.3f ms/step = %.0f moves/s" % (workload, rows, 1e3 * dt, N / dt), flush=True)
         del actor
-    check(lib.hz_search_set_rows_per_workgroup(0), "rows")
 
 
 if __name__ == "__main__":
