@@ -2,22 +2,27 @@
 """bench.py -- self-play moves/sec & MCTS sims/sec of the MI355X engine on BASELINE.json's headline workload.
 
 One "step" = one lock-step of the self-play hot path over every env of this GPU: root inference -> root prepare ->
-49 x (HIP select + gather -> dynamics/prediction GEMMs -> HIP expand/backup) -> read-out -> action sampling ->
-HIP env step + encode -> finished-game flush -> reset.  Inputs are resident in HBM; nothing is skipped.
+49 x (HIP select + gather -> dynamics/prediction nets -> HIP expand/backup) [one persistent kernel] -> read-out -> action
+sampling -> HIP env step + encode -> finished-game flush -> reset.  Inputs are resident in HBM; nothing is skipped.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Rank 0 prints ONE JSON line.  Besides the driver's contract fields it carries
-  roofline      the dominant hand-written kernel: algorithmic bytes per launch / average launch duration measured here
-                with HIP events on the launch stream (an instrumented eager pass over real search states after the
-                timed region), against the 8 TB/s HBM peak; `traffic` from profiles/ PMC summaries when present
-  cpu_baseline  the plain-C oracle (tree + env, no nets: the part the reference runs on CPU) timed on one host core
-                on a bounded sample of the same workload.  A reported baseline, not the target.
+  net_error     measured error of the nets in the dtype of this run against the reference nets' fp32 outputs (tests/golden)
+  roofline      the dominant hand-written kernel (k_search): arithmetic per launch / MEAN launch duration measured here with
+                HIP events on the launch stream, against the dense MFMA peak; beside it the L1<-L2 weight-stream rate
+                against the L2 peak (the binding resource), the min launch duration, and `traffic` = HBM bytes per launch
+                from the committed PMC passes (profiles/pmc_traffic.json, with the commit they were taken at)
+  cpu_baseline  the plain-C oracle (tree + env, no nets: the part the reference runs on CPU) on the GPU box's host cores:
+                one core on a bounded sample, tree-only / env-only splits, and one process per core.  A baseline, not the target.
+  also          (N = 1) other configurations measured in the same invocation: BASELINE configs[2] (8192 envs), the same
+                workload with fp16 nets (the reference's autocast format), and a sharp-policy net (deep search paths)
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -31,40 +36,159 @@ WORKLOADS = {
     "full8192": ("Hanabi-Full", 8192, 50, 4),     # BASELINE.json configs[2] (and [3] at --gpus 8)
     "full16384": ("Hanabi-Full", 16384, 50, 4),   # scaling probes beyond the named configs (288 GB HBM has room)
     "full32768": ("Hanabi-Full", 32768, 50, 4),
+    "full5p2048": ("Hanabi-Full-5p", 2048, 50, 4),  # BASELINE.json configs[4]'s game (A = 48, D = 1385), self-play part
 }
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-MFMA_BF16_PEAK_TFLOPS = 2500.0  # same guide: ~2.5 PFLOP/s dense bf16
+HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_PEAK_TFLOPS = 2500.0       # same guide: ~2.5 PFLOP/s dense bf16 (fp16 runs at the same rate)
+L2_PEAK_TBS = 34.5              # same guide, section L2: ~34.5 TB/s aggregate over the 8 XCDs
 
 
-def build_engine(cfg, dtype, device, fused=None):
+# ---------------------------------------------------------------------------------------------------- CPU baseline
+def cpu_worker(kind, game, A, S, trees, moves):
+    """Oracle tree and / or oracle env on ONE host core (this process): per move prepare + (S-1) x (traverse, backprop with
+    recorded fake-net outputs) [tree] and env step + encode [env].  No torch, no GPU.  Returns (moves/s, seconds)."""
+    import numpy as np
+    from oracle.cport import OracleEnv, OracleTree
+    rng = np.random.RandomState(0)
+    N = trees
+    env = OracleEnv(game, np.arange(N))
+    env.reset()
+    obs, legal = env.observe()
+    noises = rng.dirichlet([0.3] * A, N).astype(np.float32)
+    logits0 = rng.randn(N, A).astype(np.float32)
+    rew = (rng.randint(-1, 2, (S - 1, N)) * (rng.rand(S - 1, N) < 0.3)).astype(np.float32)
+    val = (rng.rand(S - 1, N) * 25).astype(np.float32)
+    lg = rng.randn(S - 1, N, A).astype(np.float32)
+    zeros = np.zeros(N, np.float32)
+    t0 = time.perf_counter()
+    for m in range(moves):
+        if kind in ("both", "tree"):
+            tree = OracleTree(N, A, S, seed=0, value_delta_max=0.006)  # the reference builds a new Roots per move
+            tree.prepare(0.25, noises, zeros, logits0, legal)
+            for sim in range(S - 1):
+                tree.traverse(sim, 19652, 1.25, 0.999)
+                tree.backprop(sim + 1, 0.999, rew[sim], val[sim], lg[sim])
+            dist = tree.distributions().astype(np.float64) * legal
+            act = (dist + 1e-3 * legal).argmax(1).astype(np.int32)
+        else:  # scripted legal actions
+            act = (legal * (1 + (np.arange(A) * 7 + m) % A)).argmax(1).astype(np.int32)
+        if kind in ("both", "env"):
+            _, done, _ = env.step(act)
+            if done.any():
+                env.reset(done)
+            obs, legal = env.observe()
+    dt = time.perf_counter() - t0
+    return N * moves / dt, dt
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(game, A, S, trees, moves, workload, max_procs):
+    """All legs as child processes that never import torch or touch the GPU (python bench.py --cpu-worker ...)."""
+    def spawn(kind, t, m):
+        return subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", kind, "--workload", workload,
+                                 "--cpu-sample-trees", str(t), "--cpu-sample-moves", str(m)], stdout=subprocess.PIPE, text=True)
+
+    def result(p):
+        out, _ = p.communicate()
+        return json.loads(out.strip().splitlines()[-1])
+    one = result(spawn("both", trees, moves))
+    tree = result(spawn("tree", trees, max(1, moves // 2)))
+    env = result(spawn("env", trees, moves * 12))
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    procs = max(1, min(avail, max_procs))
+    per = max(256, trees // 2)
+    t0 = time.perf_counter()
+    rs = [result(p) for p in [spawn("both", per, max(2, moves // 2)) for _ in range(procs)]]
+    wall = time.perf_counter() - t0
+    return {"value": one["moves_per_s"], "unit": "moves/s", "cores": 1, "kind": "port",
+            "sample": "oracle tree+env (no nets), %d envs x %d moves x %d sims, %.1f s on 1 core" % (trees, moves, S - 1, one["seconds"]),
+            "cpu_model": cpu_model(), "machine_cores": os.cpu_count(), "cores_available": avail,
+            "tree_only": {"value": tree["moves_per_s"], "unit": "root-searches/s", "cores": 1,
+                          "sample": "%d trees x %d moves x %d sims, %.1f s" % (trees, max(1, moves // 2), S - 1, tree["seconds"])},
+            "env_only": {"value": env["moves_per_s"], "unit": "env-steps/s (step + deal + encode)", "cores": 1,
+                         "sample": "%d envs x %d moves, %.1f s" % (trees, moves * 12, env["seconds"])},
+            "all_cores": {"value": sum(r["moves_per_s"] for r in rs), "unit": "moves/s", "cores": procs,
+                          "sample": "%d processes x (%d envs x %d moves), one per core, %.1f s wall" % (procs, per, max(2, moves // 2), wall)}}
+
+
+# ---------------------------------------------------------------------------------------------------- engine
+def build_engine(cfg, dtype, device, fused=None, net="random"):
+    """net: "random" = SURVEY 8d's fixed random init with the zero-initialised heads perturbed by N(0, 0.1);
+    "sharp" = the same with the policy head's output layer scaled up, so that priors concentrate on few actions per node the way
+    a trained policy's do and the search goes deep (the reference's tree walk: core/ctree/cnode.cpp:407-441)."""
     import torch
     from hanabizero_amd.model import InferenceEngine
     torch.manual_seed(0)
-    net = cfg.get_uniform_network()
-    with torch.no_grad():  # fixed random init, zero-initialised heads perturbed with N(0, 0.1)
-        for head in (net._prediction_value, net._dynamics_reward, net._prediction_actor):
+    network = cfg.get_uniform_network()
+    with torch.no_grad():
+        for head in (network._prediction_value, network._dynamics_reward, network._prediction_actor):
             head[-1].weight.normal_(0, 0.1)
             head[-1].bias.normal_(0, 0.1)
-    net.eval()
-    return InferenceEngine(net, cfg.value_support.max, dtype=dtype, device=device, fused=fused)
+        if net.startswith("sharp"):
+            scale = float(net.split(":")[1]) if ":" in net else 40.0
+            network._prediction_actor[-1].weight.mul_(scale)
+            network._prediction_actor[-1].bias.mul_(scale)
+    network.eval()
+    return InferenceEngine(network, cfg.value_support.max, dtype=dtype, device=device, fused=fused)
+
+
+def mean_path_edges(actor):
+    """Mean root -> leaf path length (edges) over ALL simulations of one search of the actor's current position
+    (launch-per-phase search; leaves the actor's own state alone except its scratch trees)."""
+    import torch
+    cfg, roots, eng = actor.cfg, actor.roots, actor.engine
+    N, S = actor.N, actor.S
+    actor._draw()
+    actor._drawn = True
+    value0, logits0, hidden0 = actor.root_inference()
+    roots.prepare(cfg.root_exploration_fraction, actor.noise, actor.zeros_n, logits0, actor.legal)
+    roots.set_params(cfg.pb_c_base, cfg.pb_c_init, cfg.discount, cfg.value_delta_max)
+    pool = torch.empty_like(actor.pool)
+    pool[0].copy_(hidden0)
+    rew = torch.empty(N, dtype=torch.float32, device=actor.device)
+    val = torch.empty(N, dtype=torch.float32, device=actor.device)
+    pol = torch.empty((N, actor.A), dtype=torch.float32, device=actor.device)
+    total = torch.zeros((), dtype=torch.float64, device=actor.device)
+    deepest = 0
+    ix, _, la = roots.traverse_tensors()
+    for sim in range(S - 1):
+        pl = roots.path_len_tensor()
+        total += pl.double().mean() - 1.0
+        deepest = max(deepest, int(pl.max()) - 1)
+        eng.fused(pool, ix, la, pool[sim + 1], rew, val, pol)
+        if sim < S - 2:
+            ix, _, la = roots.backprop_traverse_tensors(sim + 1, rew, val, pol)
+        else:
+            roots.backprop_tensors(sim + 1, rew, val, pol)
+    return float(total) / (S - 1), deepest
 
 
 def kernel_timing(actor, sample_sims=(4, 16, 28, 40), clones=8, replays=5):
-    """Average launch duration of the two hand-written tree kernels on LIVE search states, with HIP events.
+    """Launch durations of the hand-written kernels on LIVE search states, with HIP events on the launch stream.
 
-    An eager search of the actor's current position is run; at each sampled simulation the tree state is snapshotted
-    into `clones` independent handles (hz_tree_copy) and a hipGraph of `clones` back-to-back launches -- one per
-    snapshot, so no launch sees data the previous one left in cache -- is replayed between two HIP events on the
-    launch stream (torch's current stream).  An eager launch cannot be timed this way: on this stack an empty event
-    pair already reads ~26 us.  The figure includes the ~1-2 us dependent-launch boundary between graph nodes, which
-    rocprofv3's per-dispatch durations (profiles/) exclude.
-    Returns {kernel: (avg seconds per launch, launches)}, mean path edges, mean expanded entries."""
+    k_search (the kernel the product launches once per move): a hipGraph of 4 back-to-back launches, each on its own snapshot
+    (hz_tree_copy) of the freshly prepared trees of a live move -- a finished tree cannot be searched again and no launch sees
+    data the previous one left in cache -- between two events, 6 graphs: the MEAN over all 24 launches and the best graph's
+    mean are both reported.  (An eager launch cannot be timed this way: an empty event pair already reads ~26 us.)
+    The launch-per-phase kernels: the same with `clones` snapshots at each sampled simulation, best of `replays`.
+    Returns ({kernel: seconds per launch}, {k_search statistics}, launches, mean path edges, mean expanded entries)."""
     import torch
     cfg, roots, eng = actor.cfg, actor.roots, actor.engine
     N, S, oh = actor.N, actor.S, eng.onehot_cols
     actor._draw()
+    actor._drawn = True
     value0, logits0, hidden0 = actor.root_inference()
     roots.prepare(cfg.root_exploration_fraction, actor.noise, actor.zeros_n, logits0, actor.legal)
+    roots.set_params(cfg.pb_c_base, cfg.pb_c_init, cfg.discount, cfg.value_delta_max)
     actor.pool[0].copy_(hidden0)
     net_in = torch.empty((N, eng.H + oh), dtype=eng.dtype, device=actor.device)
     fused = getattr(eng, "fused", None)
@@ -74,7 +198,7 @@ def kernel_timing(actor, sample_sims=(4, 16, 28, 40), clones=8, replays=5):
     pol = torch.empty((N, actor.A), dtype=torch.float32, device=actor.device)
     launches, depth, entries = 0, 0.0, 0.0
     ev = lambda: torch.cuda.Event(enable_timing=True)
-    t_search = None
+    search = None
 
     def timed_graph(body):
         side = torch.cuda.Stream(device=actor.device)
@@ -86,133 +210,240 @@ def kernel_timing(actor, sample_sims=(4, 16, 28, 40), clones=8, replays=5):
 
     fused16 = eng.fused_shape(16, 2) if (fused is not None and getattr(actor.mcts, "persistent", False)) else None
     if fused16 is not None:
-        # the kernel the product path launches: ONE persistent search kernel per move.  4 launches per graph, each on
-        # its own snapshot of the freshly prepared trees (a finished tree cannot be searched again), best of 3 replays
-        best = 1e9
-        for _ in range(3):
+        per_graph = []
+        for _ in range(6):
             snaps = [roots.clone() for _ in range(4)]
             torch.cuda.synchronize()
-            g0 = timed_graph(lambda: [c.search_tensors(fused16, actor.pool, S - 1, rew, val, pol) for c in snaps])
+            g0 = timed_graph(lambda: [c.search_tensors(fused16, actor.pool, S - 1, rew, val, pol, actor.mcts.rows_per_workgroup)
+                                      for c in snaps])
             a, b = ev(), ev()
             a.record(); g0.replay(); b.record()
             torch.cuda.synchronize()
-            best = min(best, a.elapsed_time(b) * 1e-3 / 4)
+            per_graph.append(a.elapsed_time(b) * 1e-3 / 4)
             del g0, snaps
-        t_search = best
-    for sim in range(S - 1):
-        sampled = sim in sample_sims
-        if sampled:
-            snaps = [roots.clone() for _ in range(clones)]
-            ins = [torch.empty_like(net_in) for _ in range(clones)]
-            torch.cuda.synchronize()
+        search = {"mean_s": sum(per_graph) / len(per_graph), "min_s": min(per_graph), "launches": 4 * len(per_graph)}
+    if sample_sims:
+        for sim in range(S - 1):
+            sampled = sim in sample_sims
+            if sampled:
+                snaps = [roots.clone() for _ in range(clones)]
+                ins = [torch.empty_like(net_in) for _ in range(clones)]
+                torch.cuda.synchronize()
+                if fused is not None:
+                    g = timed_graph(lambda: [c.traverse_tensors() for c in snaps])
+                else:
+                    g = timed_graph(lambda: [c.traverse_tensors(actor.pool, b, onehot_cols=oh) for c, b in zip(snaps, ins)])
             if fused is not None:
-                g = timed_graph(lambda: [c.traverse_tensors() for c in snaps])
+                roots.traverse_tensors()
             else:
-                g = timed_graph(lambda: [c.traverse_tensors(actor.pool, b, onehot_cols=oh) for c, b in zip(snaps, ins)])
-        if fused is not None:
-            roots.traverse_tensors()
-        else:
-            roots.traverse_tensors(actor.pool, net_in, onehot_cols=oh)
-        if sampled:
-            best = 1e9
-            for _ in range(replays):
-                a, b = ev(), ev()
-                a.record(); g.replay(); b.record()
+                roots.traverse_tensors(actor.pool, net_in, onehot_cols=oh)
+            if sampled:
+                best = 1e9
+                for _ in range(replays):
+                    a, b = ev(), ev()
+                    a.record(); g.replay(); b.record()
+                    torch.cuda.synchronize()
+                    best = min(best, a.elapsed_time(b) * 1e-3 / clones)
+                tot["k_traverse"] += best
+                depth += float(roots.path_len_tensor().float().mean()) - 1.0
+                entries += sim + 1
+            if fused is not None:
+                ix_t, la_t = roots._ix, roots._la
+                fused(actor.pool, ix_t, la_t, actor.pool[sim + 1], rew, val, pol)
+                back = lambda c: c.backprop_tensors(sim + 1, rew, val, pol)
+            else:
+                r_log, v_log, p_log = eng.recurrent_heads(net_in, actor.pool[sim + 1])
+                back = lambda c: c.backprop_nets_tensors(sim + 1, r_log, v_log, eng.V, -eng.support, p_log)
+            if sampled and fused is not None:
+                # the MFMA kernel: 8 launches on 8 different input / output buffers
+                outs = [torch.empty_like(actor.pool[0]) for _ in range(clones)]
                 torch.cuda.synchronize()
-                best = min(best, a.elapsed_time(b) * 1e-3 / clones)
-            tot["k_traverse"] += best
-            depth += float(roots.path_len_tensor().float().mean()) - 1.0
-            entries += sim + 1
-        if fused is not None:
-            ix_t, la_t = roots._ix, roots._la
-            fused(actor.pool, ix_t, la_t, actor.pool[sim + 1], rew, val, pol)
-            back = lambda c: c.backprop_tensors(sim + 1, rew, val, pol)
-        else:
-            r_log, v_log, p_log = eng.recurrent_heads(net_in, actor.pool[sim + 1])
-            back = lambda c: c.backprop_nets_tensors(sim + 1, r_log, v_log, eng.V, -eng.support, p_log)
-        if sampled and fused is not None:
-            # the MFMA kernel: 8 launches on 8 different input / output buffers
-            outs = [torch.empty_like(actor.pool[0]) for _ in range(clones)]
-            torch.cuda.synchronize()
-            g3 = timed_graph(lambda: [fused(actor.pool, ix_t, la_t, o, rew, val, pol) for o in outs])
-            best = 1e9
-            for _ in range(replays):
-                a, b = ev(), ev()
-                a.record(); g3.replay(); b.record()
-                torch.cuda.synchronize()
-                best = min(best, a.elapsed_time(b) * 1e-3 / clones)
-            tot["k_mlp_recurrent"] += best
-            del g3, outs
-        if sampled:
-            # each snapshot must expand entry sim+1 exactly once per replay: re-snapshot before every replay
-            best = 1e9
-            for _ in range(replays):
-                snaps2 = [c.clone() for c in snaps]
-                torch.cuda.synchronize()
-                g2 = timed_graph(lambda: [back(c) for c in snaps2])
-                a, b = ev(), ev()
-                a.record(); g2.replay(); b.record()
-                torch.cuda.synchronize()
-                best = min(best, a.elapsed_time(b) * 1e-3 / clones)
-                del g2, snaps2
-            tot["k_backprop"] += best
-            if fused is not None and sim < S - 2:
-                # the kernel the fused search actually launches: backup of this simulation + descent of the next
+                g3 = timed_graph(lambda: [fused(actor.pool, ix_t, la_t, o, rew, val, pol) for o in outs])
+                best = 1e9
+                for _ in range(replays):
+                    a, b = ev(), ev()
+                    a.record(); g3.replay(); b.record()
+                    torch.cuda.synchronize()
+                    best = min(best, a.elapsed_time(b) * 1e-3 / clones)
+                tot["k_mlp_recurrent"] += best
+                del g3, outs
+            if sampled:
+                # each snapshot must expand entry sim+1 exactly once per replay: re-snapshot before every replay
                 best = 1e9
                 for _ in range(replays):
                     snaps2 = [c.clone() for c in snaps]
                     torch.cuda.synchronize()
-                    g4 = timed_graph(lambda: [c.backprop_traverse_tensors(sim + 1, rew, val, pol) for c in snaps2])
+                    g2 = timed_graph(lambda: [back(c) for c in snaps2])
                     a, b = ev(), ev()
-                    a.record(); g4.replay(); b.record()
+                    a.record(); g2.replay(); b.record()
                     torch.cuda.synchronize()
                     best = min(best, a.elapsed_time(b) * 1e-3 / clones)
-                    del g4, snaps2
-                tot["k_backprop_traverse"] += best
-            launches += 1
-            del g, snaps, ins
-        back(roots)
+                    del g2, snaps2
+                tot["k_backprop"] += best
+                if fused is not None and sim < S - 2:
+                    # the kernel the launch-per-phase search launches: backup of this simulation + descent of the next
+                    best = 1e9
+                    for _ in range(replays):
+                        snaps2 = [c.clone() for c in snaps]
+                        torch.cuda.synchronize()
+                        g4 = timed_graph(lambda: [c.backprop_traverse_tensors(sim + 1, rew, val, pol) for c in snaps2])
+                        a, b = ev(), ev()
+                        a.record(); g4.replay(); b.record()
+                        torch.cuda.synchronize()
+                        best = min(best, a.elapsed_time(b) * 1e-3 / clones)
+                        del g4, snaps2
+                    tot["k_backprop_traverse"] += best
+                launches += 1
+                del g, snaps, ins
+            back(roots)
     torch.cuda.synchronize()
-    times = {k: v / launches for k, v in tot.items()}
-    if t_search is not None:
-        times["k_search"] = t_search
-    return times, launches * clones * replays, depth / launches, entries / launches
+    times = {k: v / launches for k, v in tot.items()} if launches else {}
+    return times, search, launches * clones * replays, (depth / launches if launches else None), (entries / launches if launches else None)
 
 
-def cpu_baseline(game, A, S, sample_trees, moves):
-    """Oracle tree + oracle env on ONE host core: prepare + (S-1) x (traverse, backprop with recorded fake-net outputs)
-    + env step + encode per move.  Returns moves/s."""
-    import numpy as np
-    from oracle.cport import OracleEnv, OracleTree
-    rng = np.random.RandomState(0)
-    N = sample_trees
-    env = OracleEnv(game, np.arange(N))
-    env.reset()
-    obs, legal = env.observe()
-    tree = OracleTree(N, A, S, seed=0, value_delta_max=0.006)
-    noises = rng.dirichlet([0.3] * A, N).astype(np.float32)
-    logits0 = rng.randn(N, A).astype(np.float32)
-    rew = (rng.randint(-1, 2, (S - 1, N)) * (rng.rand(S - 1, N) < 0.3)).astype(np.float32)
-    val = (rng.rand(S - 1, N) * 25).astype(np.float32)
-    lg = rng.randn(S - 1, N, A).astype(np.float32)
-    zeros = np.zeros(N, np.float32)
-    t0 = time.perf_counter()
-    done_moves = 0
-    for _ in range(moves):
-        tree = OracleTree(N, A, S, seed=0, value_delta_max=0.006)  # the reference builds a new Roots per move
-        tree.prepare(0.25, noises, zeros, logits0, legal)
-        for sim in range(S - 1):
-            tree.traverse(sim, 19652, 1.25, 0.999)
-            tree.backprop(sim + 1, 0.999, rew[sim], val[sim], lg[sim])
-        dist = tree.distributions().astype(np.float64) * legal
-        act = (dist + 1e-3 * legal).argmax(1).astype(np.int32)
-        _, done, _ = env.step(act)
-        if done.any():
-            env.reset(done)
-        obs, legal = env.observe()
-        done_moves += N
-    dt = time.perf_counter() - t0
-    return done_moves / dt, dt
+# ---------------------------------------------------------------------------------------------------- one self-play run
+class Run:
+    """One actor set-up + timed loop of `steps` lock-steps (the driver's contract for the primary run; the `also` runs reuse it)."""
+
+    def __init__(self, args, workload, dtype_name, device, rank, world, net="random", rows_per_workgroup=0):
+        import torch
+        from hanabizero_amd.config import make_config
+        from hanabizero_amd.selfplay import ActorGroup, SelfPlayActor
+        self.args, self.rank, self.world, self.device = args, rank, world, device
+        self.game, self.N, self.S, self.stack = WORKLOADS[workload]
+        self.workload, self.dtype_name, self.net = workload, dtype_name, net
+        self.flush_every = args.flush_every or (15 if self.game == "Hanabi-Small" else 40)
+        self.cfg = make_config(self.game, simulations=self.S, stack=self.stack, p_mcts_num=self.N)
+        self.dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[dtype_name]
+        self.engine = build_engine(self.cfg, self.dtype, device, fused=False if args.no_fused_mlp else None, net=net)
+        K, N = args.actors_per_gpu, self.N
+        assert N % K == 0
+        # outbox ring: 8 x envs games -- the asynchronous drain hands a flush interval's games out one interval later, and
+        # random-init play finishes a game every ~16 moves
+        self.actors = [SelfPlayActor(self.cfg, self.engine, N // K, seed=0, device=device, use_graph=not args.no_graph,
+                                     env_id_base=rank * N + k * (N // K), outbox_games=8 * (N // K),
+                                     stream=torch.cuda.Stream(device=device) if K > 1 else None) for k in range(K)]
+        for a in self.actors:
+            a.mcts.rows_per_workgroup = rows_per_workgroup
+        self.group = None
+        if args.branch_graph and K > 1:
+            for a in self.actors:
+                a.stream = None
+            self.group = ActorGroup(self.actors)
+        self.games = self.rec_bytes = 0
+        self.flush_s = 0.0
+        self.env_ids = set()
+        self._pending = False
+
+    def step_all(self):
+        if self.group is not None:
+            self.group.step()
+        else:
+            for a in self.actors:
+                a.step()
+
+    def _land(self, a, packed):
+        """One actor's packed finished games -> the replay owner (rank 0), on the actor's drain stream: a device-to-device
+        gather (hanabizero_amd.dist.gather_packed) landing in pinned host memory, where `unpack_packed` views them."""
+        import torch
+        from hanabizero_amd.dist import gather_packed
+        from hanabizero_amd.selfplay import packed_layout, unpack_packed
+        with torch.cuda.stream(a.drain_stream):
+            got = gather_packed(packed, a.A, a.W, dst=0)
+        if self.rank == 0 and got:
+            for buf, n, moves in got:
+                self.games += n
+                self.rec_bytes += packed_layout(n, moves, a.A, a.W)[1]
+                if self.args.check_env_ids:
+                    self.env_ids.update(int(x) for x in unpack_packed(buf, n, moves, a.A, a.W)["meta"][:, 2])
+
+    def flush(self, final=False):
+        """Finished games leave the actors WITHOUT stalling the lock-steps: every flush point finishes the drain whose
+        snapshot was requested one interval earlier (the host waits for that snapshot only -- the GPU meanwhile has the
+        interval's lock-steps queued) and requests the next snapshot; the final one waits for everything.
+        --sync-drain: the round-1 behaviour (device-wide synchronize + blocking drain at every flush point)."""
+        import torch
+        t0 = time.perf_counter()
+        if self.args.sync_drain:
+            torch.cuda.synchronize()
+            for a in self.actors:
+                self._land(a, self._blocking(a))
+        else:
+            for a in self.actors:
+                if self._pending:
+                    self._land(a, a.drain_end())
+                if final:
+                    self._land(a, self._blocking(a))
+                else:
+                    a.drain_begin()
+            self._pending = not final
+        self.flush_s += time.perf_counter() - t0
+
+    @staticmethod
+    def _blocking(a):
+        a.drain_begin()
+        return a.drain_end()
+
+    def setup(self):
+        import torch
+        if not self.args.no_graph:  # capture (2 eager lock-steps + the capture itself) is set-up, whatever --warmup says
+            if self.group is not None:
+                self.group._capture() if self.group._graph is None else None
+            else:
+                for a in self.actors:
+                    a._capture() if a._graph is None else None
+            self.step_all()  # the first replay instantiates / uploads the graph (tens of ms): set-up as well
+            torch.cuda.synchronize()
+
+    def timed(self, steps, warmup, barrier):
+        import torch
+        import torch.distributed as dist
+        for _ in range(warmup):
+            self.step_all()
+        self.flush(final=True)
+        if self.world > 1:  # the record gather's point-to-point channels exist before the timed region even if no game has ended yet
+            w = torch.zeros(16, dtype=torch.uint8, device=self.device if self.args.backend == "nccl" else "cpu")
+            dist.gather(w, [torch.empty_like(w) for _ in range(self.world)] if self.rank == 0 else None, dst=0)
+        torch.cuda.synchronize()
+        barrier()
+        self.games, self.rec_bytes, self.flush_s = 0, 0, 0.0
+        self.env_ids = set()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            self.step_all()
+            if (k + 1) % self.flush_every == 0 and k + 1 < steps:
+                self.flush()
+        self.flush(final=True)
+        torch.cuda.synchronize()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if self.world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=self.device if self.args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        assert all(int(a.illegal_steps) == 0 for a in self.actors), "an actor produced an illegal move"
+        return elapsed
+
+    def release(self):
+        import torch
+        self.actors, self.group, self.engine = [], None, None
+        torch.cuda.empty_cache()
+
+
+def net_error(game, dtype):
+    from tests.netgold import golden_net_error
+    g = "Hanabi-Full" if game.startswith("Hanabi-Full") else game  # (the 5p net is the Full net at other widths)
+    e = golden_net_error(g, dtype)
+    return {"against": "tests/golden/nets_%s.npz (reference MuZeroNet%s fp32 outputs)" % (g, "" if g == "Hanabi-Small" else "Full"),
+            "path": "fused MFMA kernels" if e["fused"] else "GEMM chain", "measure": "max / mean of |got - ref| / max(1, |ref|)",
+            "worst": e["worst"], **{k: v for k, v in e.items() if isinstance(v, dict)}}
+
+
+def git_head():
+    try:
+        return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL, text=True).strip()
+    except Exception:
+        return None
 
 
 def main():
@@ -221,23 +452,38 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="full4096", choices=sorted(WORKLOADS))
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"],
+                    help="format of the nets (weights, activations, hidden-state pool; fp32 accumulate): bf16 = BASELINE.json's, fp16 = the reference's autocast")
+    ap.add_argument("--net", default="random", help='"random" (SURVEY 8d) or "sharp[:scale]" (concentrated policy: deep paths)')
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for --gpus > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path on one GPU)")
     ap.add_argument("--share-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--no-fused-mlp", action="store_true", help="hipBLASLt GEMM chain instead of the fused MFMA kernel")
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
-    ap.add_argument("--flush-every", type=int, default=None, help="drain + gather finished games every this many steps and once at the end of the timed loop (default 40 for Hanabi-Full -- the outbox ring holds 4 x envs games: ~58 steps of random-init play -- and 15 for Hanabi-Small, whose games are shorter)")
+    ap.add_argument("--flush-every", type=int, default=None, help="hand finished games to the replay owner every this many steps and once at the end of the timed loop (default 40 for Hanabi-Full, 15 for Hanabi-Small, whose games are shorter)")
+    ap.add_argument("--sync-drain", action="store_true", help="round-1 drain: device-wide synchronize + blocking drain at every flush point")
+    ap.add_argument("--check-env-ids", action="store_true", help="collect the global env ids of the gathered games (rehearsal tests)")
     ap.add_argument("--actors-per-gpu", type=int, default=1,
                     help="split this GPU's envs over this many concurrent actors (own hipGraph + stream each)")
     ap.add_argument("--branch-graph", action="store_true", help="with --actors-per-gpu > 1: one hipGraph with a branch per actor")
+    ap.add_argument("--rows-per-workgroup", type=int, default=0, choices=[0, 16, 32, -32], help="force a shape of the search kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the extra configurations measured after the primary run")
+    ap.add_argument("--phase-kernels", action="store_true", help="roofline pass: also time the launch-per-phase kernels (`other`)")
     ap.add_argument("--cpu-sample-trees", type=int, default=4096)
-    ap.add_argument("--cpu-sample-moves", type=int, default=24)
+    ap.add_argument("--cpu-sample-moves", type=int, default=16)
+    ap.add_argument("--cpu-procs", type=int, default=16, help="upper bound on the processes of the all-cores CPU leg (a 1-GPU box's CPU share)")
+    ap.add_argument("--cpu-worker", default=None, choices=["both", "tree", "env"], help=argparse.SUPPRESS)
     args = ap.parse_args()
 
-    import numpy as np
+    if args.cpu_worker:  # a child of cpu_baseline(): oracle only, before anything imports torch
+        game, _, S, _ = WORKLOADS[args.workload]
+        A = {"Hanabi-Small": 11, "Hanabi-Full": 20, "Hanabi-Full-5p": 48}[game]
+        v, dt = cpu_worker(args.cpu_worker, game, A, S, args.cpu_sample_trees, args.cpu_sample_moves)
+        print(json.dumps({"moves_per_s": v, "seconds": dt}), flush=True)
+        return
+
     import torch
     import torch.distributed as dist
 
@@ -257,91 +503,17 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    from hanabizero_amd.config import make_config
-    from hanabizero_amd.dist import gather_packed, reserve_landing
-    from hanabizero_amd.selfplay import SelfPlayActor, packed_layout
-
-    game, N, S, stack = WORKLOADS[args.workload]
-    if args.flush_every is None:
-        args.flush_every = 15 if game == "Hanabi-Small" else 40
-    cfg = make_config(game, simulations=S, stack=stack, p_mcts_num=N)
-    dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype]
-    engine = build_engine(cfg, dtype, device, fused=False if args.no_fused_mlp else None)
-    K = args.actors_per_gpu
-    assert N % K == 0
-    actors = [SelfPlayActor(cfg, engine, N // K, seed=0, device=device, use_graph=not args.no_graph,
-                            env_id_base=rank * N + k * (N // K),
-                            stream=torch.cuda.Stream(device=device) if K > 1 else None) for k in range(K)]
-    actor = actors[0]
-    group = None
-    if args.branch_graph and K > 1:
-        from hanabizero_amd.selfplay import ActorGroup
-        for a in actors:
-            a.stream = None
-        group = ActorGroup(actors)
-
-    def step_all():
-        if group is not None:
-            group.step()
-        else:
-            for a in actors:
-                a.step()
-
     def barrier():
         if world > 1:
             dist.barrier()
 
-    games, rec_bytes = 0, 0
+    from hanabizero_amd.dist import reserve_landing
+    run = Run(args, args.workload, args.dtype, device, rank, world, net=args.net, rows_per_workgroup=args.rows_per_workgroup)
+    game, N, S, stack = run.game, run.N, run.S, run.stack
     if rank == 0:  # the replay owner's pinned landing buffers (about 4.5 KB per finished Hanabi-Full game)
         reserve_landing(16384 * N, world)
-
-    flush_s = 0.0
-
-    def flush():
-        """Finished games -> the replay owner (rank 0): one packed byte buffer per actor, gathered device to device
-        (hanabizero_amd.dist.gather_packed), landing in pinned host memory on rank 0 where `unpack_packed` views it."""
-        nonlocal games, rec_bytes, flush_s
-        torch.cuda.synchronize()
-        tf0 = time.perf_counter()
-        for a in actors:
-            got = gather_packed(a.drain_packed(), a.A, a.W, dst=0)
-            if rank == 0 and got:
-                for buf, n, moves in got:
-                    games += n
-                    rec_bytes += packed_layout(n, moves, a.A, a.W)[1]
-        flush_s += time.perf_counter() - tf0
-
-    if not args.no_graph:  # capture (2 eager lock-steps + the capture itself) is set-up, whatever --warmup says
-        if group is not None:
-            group._capture() if group._graph is None else None
-        else:
-            for a in actors:
-                a._capture() if a._graph is None else None
-        step_all()  # the first replay instantiates / uploads the graph (tens of ms): set-up as well
-        torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step_all()
-    flush()
-    if world > 1:  # the record gather's point-to-point channels exist before the timed region even if no game has ended yet
-        w = torch.zeros(16, dtype=torch.uint8, device=device if args.backend == "nccl" else "cpu")
-        dist.gather(w, [torch.empty_like(w) for _ in range(world)] if rank == 0 else None, dst=0)
-    torch.cuda.synchronize()
-    barrier()
-    games, rec_bytes, flush_s = 0, 0, 0.0
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step_all()
-        if (k + 1) % args.flush_every == 0:
-            flush()
-    flush()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    assert all(int(a.illegal_steps) == 0 for a in actors), "an actor produced an illegal move"
+    run.setup()
+    elapsed = run.timed(args.steps, args.warmup, barrier)
 
     moves = world * N * args.steps
     out = {
@@ -354,71 +526,118 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32 tree + integer env (bit-exact), %s nets" % args.dtype,
         "data": "synthetic",
-        "config": {"workload": "%s 2p, %d envs/GPU, %d sims/move (%d run, as the reference), stack %d, random-init "
-                               "nets (heads N(0,0.1)), global obs" % (game, N, S, S - 1, stack),
-                   "envs_per_gpu": N, "actors_per_gpu": K, "simulations": S, "hipgraph": not args.no_graph, "parallelism": "actor-per-GPU x%d" % world,
-                   "games_finished": games, "record_bytes_gathered": rec_bytes,
-                   "drain_gather_ms_total": 1e3 * flush_s},
+        "config": {"workload": "%s, %d envs/GPU, %d sims/move (%d run, as the reference), stack %d, %s nets, global obs" % (
+                       game + ("" if game.endswith("5p") else " 2p"), N, S, S - 1, stack,
+                       "random-init (heads N(0,0.1))" if args.net == "random" else "random-init with a sharpened policy head (%s)" % args.net),
+                   "envs_per_gpu": N, "actors_per_gpu": args.actors_per_gpu, "simulations": S, "hipgraph": not args.no_graph,
+                   "parallelism": "actor-per-GPU x%d" % world, "drain": "synchronous" if args.sync_drain else "asynchronous (side stream, one interval behind)",
+                   "games_finished": run.games, "record_bytes_gathered": run.rec_bytes, "drain_gather_ms_total": 1e3 * run.flush_s},
     }
+    if args.check_env_ids and rank == 0:
+        out["config"]["env_id_min_max_distinct"] = [min(run.env_ids), max(run.env_ids), len(run.env_ids)] if run.env_ids else None
+    if rank == 0 and not args.no_roofline:
+        out["net_error"] = net_error(game, run.dtype)
 
     if rank == 0 and not args.no_roofline:
-        times, launches, dbar, sbar = kernel_timing(actor)
+        actor, engine, cfg, dtype = run.actors[0], run.engine, run.cfg, run.dtype
+        times, search, launches, dbar, sbar = kernel_timing(actor, sample_sims=(4, 16, 28, 40) if (args.phase_kernels or engine.fused is None) else ())
+        if dbar is None:
+            dbar, _ = mean_path_edges(actor)
+            sbar = (S - 1) / 2.0
         A, H, e = cfg.action_space_size, engine.H, (4 if dtype == torch.float32 else 2)
         V = engine.V
-        # algorithmic bytes per launch (DESIGN.md section 4; SURVEY.md 8d per-tree figures x N trees per launch)
         Nk = actor.N  # trees per launch (per actor)
-        b_trav = Nk * (16 * A * dbar + (0 if engine.fused is not None else 2 * H * e))                          # child rows per level + hidden row in and out
-        # fused backup: policy logits + the two categorical head rows in (net dtype), child rows out, header, backup, min-max
-        b_back = Nk * (A * e + 2 * V * e + 16 * A + 16 + 16 * (dbar + 1) + 12 * sbar)
+        # algorithmic bytes per launch (DESIGN.md section 4; SURVEY.md 8d per-tree figures x N trees per launch)
+        b_trav = Nk * (16 * A * dbar + (0 if engine.fused is not None else 2 * H * e))
         fused_on = engine.fused is not None
-        if fused_on:  # plain backup: fp32 reward/value/policy in (SURVEY 8d formula)
-            b_back = Nk * (4 * A + 16 * A + 16 + 8 + 16 * (dbar + 1) + 12 * sbar)
-        kern = {"k_traverse": (b_trav, times["k_traverse"]), "k_backprop": (b_back, times["k_backprop"])}
-        if fused_on and times.get("k_backprop_traverse", 0) > 0:
-            kern["k_backprop_traverse"] = (b_trav + b_back, times["k_backprop_traverse"])
-        other = {k: {"bound": "hbm", "avg_launch_us": t * 1e6, "bytes_per_launch": b, "GBps": b / t / 1e9, "frac": b / t / 1e9 / HBM_PEAK_GBS}
-                 for k, (b, t) in kern.items()}
+        b_back = Nk * ((4 * A + 16 * A + 16 + 8 + 16 * (dbar + 1) + 12 * sbar) if fused_on else
+                       (A * e + 2 * V * e + 16 * A + 16 + 16 * (dbar + 1) + 12 * sbar))
+        other = {}
+        if times:
+            kern = {"k_traverse": (b_trav, times["k_traverse"]), "k_backprop": (b_back, times["k_backprop"])}
+            if fused_on and times.get("k_backprop_traverse", 0) > 0:
+                kern["k_backprop_traverse"] = (b_trav + b_back, times["k_backprop_traverse"])
+            other = {k: {"bound": "hbm", "avg_launch_us": t * 1e6, "bytes_per_launch": b, "GBps": b / t / 1e9, "frac": b / t / 1e9 / HBM_PEAK_GBS}
+                     for k, (b, t) in kern.items()}
         flops = engine.flops_per_sample() * Nk
-        if fused_on:
+        if fused_on and times:
             t = times["k_mlp_recurrent"]
             other["k_mlp_recurrent"] = {"bound": "mfma", "avg_launch_us": t * 1e6, "flop_per_launch": flops,
-                                        "TFLOPps": flops / t / 1e12, "frac": flops / t / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                                        "TFLOPps": flops / t / 1e12, "frac": flops / t / 1e12 / MFMA_PEAK_TFLOPS,
                                         "weight_bytes_per_wg": engine.fused.weight_bytes_per_wg}
-        if fused_on and "k_search" in times:
-            # the persistent search kernel: all S-1 simulations of a move; MFMA work = (S-1) recurrent inferences, its
-            # tree phases add the algorithmic HBM bytes of (S-1) backups and descents
-            t = times["k_search"]
-            fl = flops * (S - 1)
-            other["k_search"] = {"bound": "mfma", "avg_launch_us": t * 1e6, "flop_per_launch": fl,
-                                 "TFLOPps": fl / t / 1e12, "frac": fl / t / 1e12 / MFMA_BF16_PEAK_TFLOPS,
-                                 "simulations_per_launch": S - 1,
-                                 "weight_bytes_streamed_per_cu_per_simulation": engine.fused.weight_bytes_per_wg,
-                                 "tree_bytes_per_launch": (b_trav + b_back) * (S - 1)}
-        traffic_all = {}
+        traffic_all, traffic_src = {}, None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
-                traffic_all = json.load(open(pmc)).get(args.workload, {})
+                data = json.load(open(pmc))
+                traffic_all = data.get(args.workload, {})
+                traffic_src = {"file": "profiles/pmc_traffic.json", "taken_at_commit": traffic_all.get("_commit"),
+                               "this_run_commit": git_head(), "note": "a committed measurement (two rocprofv3 --pmc passes, tools/pmc_traffic.py), not collected in this run"}
             except Exception:
                 traffic_all = {}
-        dom = max(other, key=lambda k: other[k]["avg_launch_us"])
-        d = other[dom]
-        if d["bound"] == "hbm":
-            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": d["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": d["frac"], "traffic": traffic_all.get(dom)}
-        else:
-            out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": d["TFLOPps"], "peak": MFMA_BF16_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": d["frac"], "traffic": traffic_all.get(dom)}
-        out["roofline"].update({"avg_launch_us": d["avg_launch_us"], "launches_timed": launches,
-                                "mean_path_edges": dbar, "mean_expanded_entries": sbar,
-                                "method": "HIP events around hipGraph replays of back-to-back launches on independent snapshots of live search states (4 for k_search, 8 for the per-phase kernels)",
-                                "other": other})
+        if fused_on and search is not None:
+            # the persistent search kernel: all S-1 simulations of a move; MFMA work = (S-1) recurrent inferences, its tree phases
+            # add the algorithmic HBM bytes of (S-1) backups and descents; every workgroup streams the whole weight set from L2
+            # once per simulation
+            t = search["mean_s"]
+            fl = flops * (S - 1)
+            rows_wg = 16 if (actor.mcts.rows_per_workgroup == 16 or (actor.mcts.rows_per_workgroup == 0 and (Nk + 15) // 16 <= torch.cuda.get_device_properties(device).multi_processor_count)) else 32
+            wgs = (Nk + rows_wg - 1) // rows_wg
+            l2_bytes = wgs * engine.fused.weight_bytes_per_wg * (S - 1) + 2 * Nk * H * e * (S - 1)
+            out["roofline"] = {"bound": "mfma", "kernel": "k_search", "achieved": fl / t / 1e12, "peak": MFMA_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": fl / t / 1e12 / MFMA_PEAK_TFLOPS,
+                               "traffic": traffic_all.get("k_search"), "traffic_source": traffic_src,
+                               "avg_launch_us": t * 1e6, "min_launch_us": search["min_s"] * 1e6, "launches_timed": search["launches"],
+                               "flop_per_launch": fl, "simulations_per_launch": S - 1, "trees_per_workgroup": rows_wg, "workgroups": wgs,
+                               "l2_stream": {"bytes_per_launch": l2_bytes, "achieved_TBps": l2_bytes / t / 1e12, "peak_TBps": L2_PEAK_TBS,
+                                             "frac": l2_bytes / t / 1e12 / L2_PEAK_TBS,
+                                             "note": "L1<-L2 weight stream (every workgroup pulls all %d weight bytes per simulation) + pool rows: the resource that binds this kernel" % engine.fused.weight_bytes_per_wg},
+                               "hbm_algorithmic": {"bytes_per_launch": (b_trav + b_back + 2 * Nk * H * e) * (S - 1),
+                                                   "GBps": (b_trav + b_back + 2 * Nk * H * e) * (S - 1) / t / 1e9,
+                                                   "frac_of_hbm_peak": (b_trav + b_back + 2 * Nk * H * e) * (S - 1) / t / 1e9 / HBM_PEAK_GBS},
+                               "mean_path_edges": dbar, "mean_expanded_entries": sbar,
+                               "method": "HIP events around hipGraph replays of 4 back-to-back launches on independent snapshots of live search states; mean over 6 graphs (avg_launch_us) and the best graph (min_launch_us)",
+                               "other": other}
+        elif other:
+            dom = max(other, key=lambda k: other[k]["avg_launch_us"])
+            d = other[dom]
+            out["roofline"] = {"bound": d["bound"], "kernel": dom, "achieved": d.get("GBps", d.get("TFLOPps")),
+                               "peak": HBM_PEAK_GBS if d["bound"] == "hbm" else MFMA_PEAK_TFLOPS,
+                               "unit": "GB/s" if d["bound"] == "hbm" else "TFLOP/s", "frac": d["frac"], "traffic": traffic_all.get(dom),
+                               "traffic_source": traffic_src, "avg_launch_us": d["avg_launch_us"], "launches_timed": launches,
+                               "mean_path_edges": dbar, "mean_expanded_entries": sbar, "other": other}
+
+    if rank == 0 and world == 1 and not args.no_also:
+        # other configurations, same invocation, same box (each: own actors + hipGraph; steps as the primary run)
+        also = {}
+        run.release()
+        del run
+        plan = []
+        if args.workload == "full4096" and args.net == "random":
+            plan = [("full8192", "full8192", args.dtype, "random"), ("fp16" if args.dtype != "fp16" else "bf16", args.workload, "fp16" if args.dtype != "fp16" else "bf16", "random"),
+                    ("deep_paths", args.workload, args.dtype, "sharp")]
+        for name, wl, dt, net in plan:
+            r = Run(args, wl, dt, device, 0, 1, net=net)
+            r.setup()
+            el = r.timed(args.steps, args.warmup, lambda: None)
+            entry = {"workload": wl, "dtype": dt, "net": net, "value": r.N * args.steps / el, "unit": "moves/s",
+                     "ms_per_step": 1e3 * el / args.steps, "steps": args.steps, "games_finished": r.games}
+            if not args.no_roofline:
+                _, search, _, _, _ = kernel_timing(r.actors[0], sample_sims=())
+                if search:
+                    entry["k_search_avg_launch_us"], entry["k_search_min_launch_us"] = search["mean_s"] * 1e6, search["min_s"] * 1e6
+                if net != "random":
+                    entry["mean_path_edges"], entry["deepest_path_edges"] = mean_path_edges(r.actors[0])
+                if dt != args.dtype:
+                    entry["net_error_worst"] = net_error(r.game, r.dtype)["worst"]
+            also[name] = entry
+            r.release()
+            del r
+        out["also"] = also
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:  # (rank 0 at N = 1 only)
-        v, dt = cpu_baseline(game, cfg.action_space_size, S, args.cpu_sample_trees, args.cpu_sample_moves)
-        out["cpu_baseline"] = {"value": v, "unit": "moves/s", "cores": 1, "kind": "port",
-                               "sample": "oracle tree+env (no nets), %d envs x %d moves x %d sims, %.1f s on 1 core" % (
-                                   args.cpu_sample_trees, args.cpu_sample_moves, S - 1, dt)}
+        cfgA = {"Hanabi-Small": 11, "Hanabi-Full": 20, "Hanabi-Full-5p": 48}[game]
+        out["cpu_baseline"] = cpu_baseline(game, cfgA, S, args.cpu_sample_trees, args.cpu_sample_moves, args.workload, args.cpu_procs)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

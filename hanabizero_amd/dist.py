@@ -115,7 +115,9 @@ def gather_packed(packed, A, W, dst=0, group=None):
     or None.  Two collectives: all_gather of (n, moves), one gather of the byte buffers (padded to the longest; device to
     device over xGMI under "nccl": the sending ranks never copy their records to the host).  Returns on `dst` a list of
     (host uint8 numpy buffer in pinned memory, n, moves) per rank with games -- `unpack_packed` views them without a
-    copy; the buffers are reused by the next call -- elsewhere None.  Works without a process group (world 1)."""
+    copy; the buffers are reused by the next call -- elsewhere None.  Works without a process group (world 1).
+    Everything is enqueued on the CALLER's current stream and only that stream is waited for, so called under
+    ``with torch.cuda.stream(actor.drain_stream)`` the gather overlaps the lock-steps queued on the main stream."""
     from .selfplay import packed_layout
     n, moves = (0, 0) if packed is None else (int(packed[1]), int(packed[2]))
     if _alone(group):
@@ -123,7 +125,8 @@ def gather_packed(packed, A, W, dst=0, group=None):
             return []
         host = _pinned_bytes(("r", 0), packed[0].numel())
         host.copy_(packed[0], non_blocking=True)
-        torch.cuda.synchronize() if packed[0].is_cuda else None
+        if packed[0].is_cuda:  # (this stream only: lock-steps queued on other streams keep running)
+            torch.cuda.current_stream(packed[0].device).synchronize()
         return [(host.numpy(), n, moves)]
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     backend = dist.get_backend(group)
@@ -149,8 +152,8 @@ def gather_packed(packed, A, W, dst=0, group=None):
             host = _pinned_bytes(("r", r), sizes[r])
             host.copy_(bufs[r][:sizes[r]], non_blocking=True)
             out.append((host, int(every[r, 0]), int(every[r, 1])))
-    if device.type == "cuda":
-        torch.cuda.synchronize()
+    if device.type == "cuda":  # (this stream only: lock-steps queued on other streams keep running)
+        torch.cuda.current_stream(device).synchronize()
     return [(h.numpy(), a, b) for h, a, b in out]
 
 

@@ -105,9 +105,13 @@ class ReplayBuffer:
             game_id, pos = self.game_look_up[idx]
             games.append(self.buffer[game_id - self.base_idx])
             positions.append(pos)
-        return games, positions, indices, weights.astype(np.float32), [1.0] * batch_size
+        # stamped with the eviction epoch it was drawn in (the reference stamps wall-clock time on both sides,
+        # replay_buffer.py:171, 205): remove_to_fit shifts every index, so write-backs of older batches must be dropped
+        return games, positions, indices, weights.astype(np.float32), [self.clear_time + 1] * batch_size
 
     def update_priorities(self, batch_indices, batch_priorities, make_time=None):
+        """Priority write-back of a batch drawn by prepare_batch_context; entries drawn before the latest eviction
+        (make_time <= clear_time) are ignored, as in the reference (replay_buffer.py:174-178)."""
         for i in range(len(batch_indices)):
             if make_time is None or make_time[i] > self.clear_time:
                 self.priorities[batch_indices[i]] = batch_priorities[i]

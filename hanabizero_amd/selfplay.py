@@ -91,7 +91,7 @@ class SelfPlayActor:
         self.cap = int(outbox_games or max(4 * N, 1024))
         self.out = {k: torch.zeros((self.cap,) + v.shape[1:], dtype=v.dtype, device=d) for k, v in self.traj.items()}
         self.out_meta = z(self.cap, 4, dtype=torch.int32)
-        self.out_count = z(2, dtype=torch.int64)   # games finished so far | their total moves since the last drain
+        self.out_count = z(2, dtype=torch.int64)   # games finished so far | their total moves (both cumulative)
         self.slot = z(N, dtype=torch.int32)
         self.tmp_packed = z(N, W, dtype=torch.int32)
         self.tmp_legal = z(N, A, dtype=torch.uint8)
@@ -117,7 +117,10 @@ class SelfPlayActor:
         self.flush_job = RowsJob()  # hz_actor_flush as data: the masked reset of every lock-step carries it (hz_env_reset_rows)
         check(lib.hz_actor_flush_job(C.byref(self.bufs), C.byref(self.flush_job)), "hz_actor_flush_job")
         self.total_moves = 0
-        self._drained = 0
+        self._drained = 0          # games / moves handed out by drains so far (host-side mirrors of out_count)
+        self._moves_drained = 0
+        self.drain_stream = None   # side stream of the asynchronous drain (drain_begin / drain_end), created on first use
+        self._snap = None
         self._drawn = False  # the coming move's noise / uniforms are already in self.noise / self.uniform
         self._graph = None
         self.use_graph = use_graph
@@ -221,11 +224,13 @@ class SelfPlayActor:
         self.total_moves += self.N
 
     # -- finished games ------------------------------------------------------------------------------------------
+    def _work_stream(self):
+        return self.stream if self.stream is not None else torch.cuda.current_stream(self.device)
+
     def drain(self):
         """Packed records of the games finished since the last drain (synchronises).  Returns a dict of numpy arrays
         with a leading games axis, or None.  Must be called at least once per `cap` finished games."""
-        if self.stream is not None:
-            self.stream.synchronize()
+        self._work_stream().synchronize()
         count = int(self.out_count[0].item())
         n = count - self._drained
         if n <= 0:
@@ -240,35 +245,60 @@ class SelfPlayActor:
             t = tmax + 1 if k in ("legal", "obs") else tmax
             rec[k] = v.index_select(0, idx)[:, :t].contiguous().cpu().numpy()
         rec["meta"] = meta.cpu().numpy()
-        with torch.cuda.stream(self.stream if self.stream is not None else torch.cuda.current_stream()):
-            self.out_count[1:].zero_()
         self._drained = count
+        self._moves_drained += int(rec["meta"][:, 0].sum())
         return rec
 
+    def drain_begin(self):
+        """First half of a drain that never stalls the lock-steps: snapshot (finished games, their total moves) as of
+        the work enqueued so far.  Non-blocking -- the counters travel to pinned host memory on `drain_stream`, which
+        waits for the lock-steps enqueued up to now and for nothing enqueued later."""
+        if self.drain_stream is None:
+            self.drain_stream = torch.cuda.Stream(device=self.device)
+            self._count_host = torch.zeros(2, dtype=torch.int64).pin_memory()
+        assert self._snap is None, "drain_begin: the previous snapshot has not been consumed (drain_end)"
+        self.drain_stream.wait_stream(self._work_stream())
+        with torch.cuda.stream(self.drain_stream):
+            self._count_host.copy_(self.out_count, non_blocking=True)
+            self._snap = torch.cuda.Event()
+            self._snap.record(self.drain_stream)
 
-    def drain_packed(self):
-        """The games finished since the last drain as ONE byte buffer that stays on the device: (uint8 tensor, n games,
-        their total moves) or None.  `packed_layout(n, moves, A, W)` describes it; hanabizero_amd.dist.gather_packed moves such buffers to the
-        replay owner GPU-to-GPU (no host copy on the sending ranks), `unpack_packed` views one on the host."""
-        if self.stream is not None:
-            self.stream.synchronize()
-        count, moves = (int(x) for x in self.out_count.tolist())  # the one host round trip of a drain
-        n = count - self._drained
+    def drain_end(self):
+        """Second half: the games finished up to the snapshot of drain_begin as ONE byte buffer that stays on the device:
+        (uint8 tensor, n games, their total moves) or None.  Blocks the host until the snapshot has been taken (i.e. until
+        the lock-steps enqueued BEFORE drain_begin are done), not for lock-steps enqueued since; the packing runs on
+        `drain_stream` beside them.  The buffer belongs to `drain_stream`: consume it under
+        ``with torch.cuda.stream(actor.drain_stream)`` (what bench.py does with dist.gather_packed) or make your stream
+        wait for it.  `packed_layout(n, moves, A, W)` describes the buffer; `unpack_packed` views one on the host."""
+        assert self._snap is not None, "drain_end without drain_begin"
+        self._snap.synchronize()
+        self._snap = None
+        count, moves_total = (int(x) for x in self._count_host.tolist())
+        n, moves = count - self._drained, moves_total - self._moves_drained
         if n <= 0:
             return None
         if n > self.cap:
             raise RuntimeError("outbox overflow: %d games finished since the last drain, capacity %d" % (n, self.cap))
         total = int(lib.hz_actor_packed_bytes(n, moves, self.A, self.W, None))
-        buf = torch.empty(total, dtype=torch.uint8, device=self.device)
-        starts = torch.empty(n + 1, dtype=torch.int32, device=self.device)
-        with torch.cuda.stream(self.stream if self.stream is not None else torch.cuda.current_stream()):
+        with torch.cuda.stream(self.drain_stream):
+            buf = torch.empty(total, dtype=torch.uint8, device=self.device)
+            starts = torch.empty(n + 1, dtype=torch.int32, device=self.device)
             check(lib.hz_actor_pack(C.byref(self.bufs), self._drained, n, moves, starts.data_ptr(), buf.data_ptr(), total,
                                     _stream()), "hz_actor_pack")
-            self.out_count[1:].zero_()
-        if self.stream is not None:
-            torch.cuda.current_stream().wait_stream(self.stream)  # the caller reads `buf` on its own stream
-        self._drained = count
+        self._drained, self._moves_drained = count, moves_total
         return buf, n, moves
+
+    def drain_packed(self):
+        """drain_begin + drain_end in one blocking call: the games finished by the work enqueued so far, usable on the
+        caller's current stream.  (Two kernels and one 16-byte read-back; `hanabizero_amd.dist.gather_packed` moves such
+        buffers to the replay owner GPU-to-GPU, no host copy on the sending ranks.)"""
+        self.drain_begin()
+        got = self.drain_end()
+        if got is not None:
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_stream(self.drain_stream)
+            got[0].record_stream(cur)
+        return got
 
 
 class ActorGroup:

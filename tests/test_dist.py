@@ -137,3 +137,32 @@ def test_collectives_over_rccl_one_rank():
     finally:
         hd._SHORT_CIRCUIT = True
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu_over_gloo():
+    """bench.py's N > 1 path exactly as the driver launches it (python -m torch.distributed.run --nproc-per-node 2 bench.py
+    --gpus 2 ...), rehearsed on the test box's one GPU: both ranks use cuda:0, the collectives go over gloo.  Checks the one
+    JSON line rank 0 prints: two ranks' worth of moves, finished games gathered from BOTH ranks (global env ids from each
+    rank's disjoint range), the asynchronous drain in use."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--backend", "gloo", "--share-device", "--steps", "24",
+           "--warmup", "2", "--workload", "small4096", "--flush-every", "8", "--no-cpu-baseline", "--no-roofline", "--no-also",
+           "--check-env-ids"]
+    p = subprocess.run(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    N = 4096
+    assert d["n_gpus"] == 2 and d["steps"] == 24 and d["scaling"] == "weak" and d["metric"] == "selfplay_moves_per_sec"
+    assert d["value"] == pytest.approx(2 * N * 24 / (d["ms_per_step"] * 24e-3), rel=1e-6)
+    cfg = d["config"]
+    assert cfg["drain"].startswith("asynchronous") and cfg["games_finished"] > N and cfg["record_bytes_gathered"] > 0
+    lo, hi, distinct = cfg["env_id_min_max_distinct"]
+    assert 0 <= lo < N <= hi < 2 * N and distinct > N  # games of rank 0's envs [0, N) and of rank 1's [N, 2N)

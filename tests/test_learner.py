@@ -237,6 +237,18 @@ def test_replay_buffer_bookkeeping():
     assert dropped >= 1 and rb.get_total_len() == sum(len(g) for g in rb.buffer) <= 40 + 9
     gid, gpos = rb.game_look_up[0]
     assert gid - rb.base_idx == 0 and gpos == 0
+    # a batch drawn BEFORE the eviction indexes positions that have moved: its write-back is dropped ...
+    before = rb.priorities.copy()
+    rb.update_priorities(idx, np.full(6, 123.0), mt)
+    assert np.array_equal(rb.priorities, before)
+    # ... a batch drawn AFTER it is applied (and keeps being applied after later evictions, each with its own epoch)
+    for _ in range(2):
+        games, pos, idx2, w2, mt2 = rb.prepare_batch_context(6, beta=0.4)
+        rb.update_priorities(idx2, np.full(6, 0.25), mt2)
+        assert (rb.priorities[idx2] == 0.25).all()
+        for _ in range(5):
+            rb.save_game(G(9), True, 0)
+        assert rb.remove_to_fit() >= 1
 
 
 @pytest.mark.gpu

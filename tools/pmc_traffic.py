@@ -11,7 +11,7 @@ import json
 import os
 import sys
 
-KERNELS = {"k_search": "k_search<", "k_traverse": "k_traverse(", "k_backprop": "k_backprop<", "k_backprop_traverse": "k_backprop_traverse<", "k_mlp_recurrent": "k_mlp_recurrent",
+KERNELS = {"k_search": ("k_search<", "k_search_half<"), "k_traverse": "k_traverse(", "k_backprop": "k_backprop<", "k_backprop_traverse": "k_backprop_traverse<", "k_mlp_recurrent": "k_mlp_recurrent",
            "k_env_observe": "k_env_observe", "k_env_rules": "k_env_rules", "k_env_reset_rows": "k_env_reset_rows", "k_prepare": "k_prepare",
            "k_select_action": "k_select_action", "k_rows_scatter": "k_rows_scatter", "k_actor_draw": "k_actor_draw",
            "k_actor_record_search": "k_actor_record_search", "k_actor_record_step_slots": "k_actor_record_step_slots",
@@ -22,7 +22,7 @@ def mean_by_kernel(path):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         for key, needle in KERNELS.items():
-            if needle in r["Kernel_Name"]:
+            if any(n in r["Kernel_Name"] for n in ((needle,) if isinstance(needle, str) else needle)):
                 agg[key].append(float(r["Counter_Value"]))
     return {k: (sum(v) / len(v), len(v)) for k, v in agg.items()}
 
@@ -41,6 +41,11 @@ def main():
             w, nw = write[k]
             entry[k] = (2 * f + w) * 1024
             entry["_detail"][k] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "launches": min(nf, nw)}
+    try:  # (run in the authoring container on the merged gpurun_out/ files: the commit the measured tree was built from)
+        import subprocess
+        entry["_commit"] = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], text=True).strip()
+    except Exception:
+        entry["_commit"] = None
     data[workload] = entry
     json.dump(data, open(out_path, "w"), indent=1)
     print(json.dumps(entry, indent=1))
