@@ -331,7 +331,7 @@ class Run:
                 a.stream = None
             self.group = ActorGroup(self.actors)
         self.games = self.rec_bytes = 0
-        self.flush_s = 0.0
+        self.flush_s = self.wait_s = 0.0
         self.env_ids = set()
         self._pending = False
 
@@ -371,6 +371,9 @@ class Run:
         else:
             for a in self.actors:
                 if self._pending:
+                    tw = time.perf_counter()
+                    a._snap.synchronize()  # the snapshot of one interval ago: the GPU has this interval's lock-steps queued meanwhile
+                    self.wait_s += time.perf_counter() - tw
                     self._land(a, a.drain_end())
                 if final:
                     self._land(a, self._blocking(a))
@@ -406,7 +409,7 @@ class Run:
             dist.gather(w, [torch.empty_like(w) for _ in range(self.world)] if self.rank == 0 else None, dst=0)
         torch.cuda.synchronize()
         barrier()
-        self.games, self.rec_bytes, self.flush_s = 0, 0, 0.0
+        self.games, self.rec_bytes, self.flush_s, self.wait_s = 0, 0, 0.0, 0.0
         self.env_ids = set()
         t0 = time.perf_counter()
         for k in range(steps):
@@ -531,7 +534,11 @@ def main():
                        "random-init (heads N(0,0.1))" if args.net == "random" else "random-init with a sharpened policy head (%s)" % args.net),
                    "envs_per_gpu": N, "actors_per_gpu": args.actors_per_gpu, "simulations": S, "hipgraph": not args.no_graph,
                    "parallelism": "actor-per-GPU x%d" % world, "drain": "synchronous" if args.sync_drain else "asynchronous (side stream, one interval behind)",
-                   "games_finished": run.games, "record_bytes_gathered": run.rec_bytes, "drain_gather_ms_total": 1e3 * run.flush_s},
+                   "games_finished": run.games, "record_bytes_gathered": run.rec_bytes,
+                   # host time of the flush points: the drain work proper (pack + gather + landing copy; under --sync-drain also the
+                   # device-wide synchronize in front of it, which is what stalls the actors) and, asynchronous mode only, the
+                   # host's wait for the snapshot of one interval ago -- the GPU runs the queued lock-steps meanwhile
+                   "drain_gather_ms_total": 1e3 * (run.flush_s - run.wait_s), "drain_snapshot_wait_ms_total": 1e3 * run.wait_s},
     }
     if args.check_env_ids and rank == 0:
         out["config"]["env_id_min_max_distinct"] = [min(run.env_ids), max(run.env_ids), len(run.env_ids)] if run.env_ids else None

@@ -276,11 +276,19 @@ __global__ __launch_bounds__(1024, 1) void k_search_half(TreeView tv, hz_mlp_hea
       for (int u = 0; u < 2; ++u) rows.v[u] = (q.l + 32 * u) * 8 < H.hidden ? src[q.l + 32 * u] : make_uint4(0u, 0u, 0u, 0u);
     }
   }
+  unsigned long long p_tree = 0, p_mlp = 0, p_wait2 = 0;
+  (void)p_tree; (void)p_mlp; (void)p_wait2;
+  unsigned long long t0 = SP_NOW();
   for (int sim = 0; sim < a.sims; ++sim) {
+    const unsigned long long t2 = SP_NOW();
     mlp_body<EL, 2, 16, 2, STAGE_REGS_HALF, false>(H, a.jobs, a.wstream, a.bias, a.act_tab, a.pool, a.row_stride, nullptr,
                                                a.plane_stride, L.act_s - row0, a.pool + (size_t)(sim + 1) * a.plane_stride,
                                                nullptr, nullptr, nullptr, tv.N, L.image, row0, &rows);
+    const unsigned long long t3 = SP_NOW();
     __syncthreads();  // leaf outputs visible; the row image is free again
+    const unsigned long long t4 = SP_NOW();
+    p_tree += t2 - t0; p_mlp += t3 - t2; p_wait2 += t4 - t3;
+    t0 = t4;
     if (!any_mine) continue;
     int lane_t = lane;
     asm volatile("" : "+v"(lane_t));
@@ -315,6 +323,12 @@ __global__ __launch_bounds__(1024, 1) void k_search_half(TreeView tv, hz_mlp_hea
     }
   }
 #undef HZ_HALF_SETUP
+#ifdef HZ_SEARCH_PROFILE
+  if (blockIdx.x == 50 && lane == 0) {
+    unsigned long long* o = hz_search_prof + wave * 4;
+    o[0] = p_tree + (SP_NOW() - t0); o[1] = 0; o[2] = p_mlp; o[3] = p_wait2;
+  }
+#endif
 }
 
 // What this library remembers per DEVICE (ordinal of the tree handle, not the calling thread's current device): the compute-

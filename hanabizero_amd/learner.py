@@ -81,7 +81,7 @@ def adjust_lr(config, optimizer, step_count):
 
 
 # ---- batches (core/reanalyze_worker.py, the parts that do not search) ---------------------------------------------
-def make_batch(games, positions, config, value_fn, weights=None, rng=None):
+def make_batch(games, positions, config, value_fn, weights=None, rng=None, policy_re=None):
     """A learner batch in the reference's layout from finished ``GameHistory`` objects and sampled positions:
     inputs as BatchWorker_CPU.make_batch assembles them (reanalyze_worker.py:148-168: stacked observations padded with
     the last frame, actions padded with random ones past the end, mask), value / reward targets as
@@ -89,7 +89,9 @@ def make_batch(games, positions, config, value_fn, weights=None, rng=None):
     observation td_steps ahead, zero past the end), policy targets from the stored search statistics as
     _prepare_policy_non_re (:374-399: child visits, zeros past the end).  ``value_fn(obs [M, stack * D] float32 numpy)
     -> [M] values`` is the target model (e.g. ``lambda o: engine.initial(torch.from_numpy(o).cuda())[0].cpu().numpy()``).
-    Policy targets re-searched with the current model (reanalyze) come from hanabizero_amd.reanalyze.prepare_policy_re."""
+    policy_re: [R, U + 1, A] policy targets re-searched with the target model for the FIRST R positions of the batch
+    (hanabizero_amd.reanalyze.prepare_policy_re over reanalyze.policy_re_context(config, games[:R], positions[:R])); they
+    replace those rows' stored search statistics, as _prepare_target_gpu concatenates [reanalyzed | stored] (:412-419)."""
     rng = rng or np.random
     U, td, stack, A, g = config.num_unroll_steps, config.td_steps, config.stacked_observations, config.action_space_size, config.discount
     B = len(games)
@@ -131,6 +133,8 @@ def make_batch(games, positions, config, value_fn, weights=None, rng=None):
                 target_value[b, j], target_reward[b, j] = v, game.rewards[cur]
                 target_policy[b, j] = game.child_visits[cur]
             k += 1
+    if policy_re is not None and len(policy_re):
+        target_policy[:len(policy_re)] = policy_re
     w = np.ones(B, np.float32) if weights is None else np.asarray(weights, np.float32)
     inputs = (obs_batch, np.asarray(action_lst, np.int64), np.asarray(mask_lst, np.float32), np.arange(B), w, np.zeros(B))
     return inputs, (target_reward[:, :U + 1], target_value, target_policy)

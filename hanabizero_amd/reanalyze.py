@@ -14,6 +14,34 @@ from . import cytree
 from .mcts import MCTS
 
 
+def policy_re_context(config, games, positions, indices=None):
+    """What ``BatchWorker_CPU._prepare_policy_re_context`` (reanalyze_worker.py:101-144) hands to the searching worker for the
+    sampled (game, position) pairs whose policy targets are to be refreshed: for each of the num_unroll_steps + 1 unroll
+    positions the stacked observation window and the legal-action mask, or a zero window / all-illegal mask and
+    policy_mask 0 past the end of the game.  Returns the reference's 7-tuple with policy_obs_lst as one array
+    [B', stack, D] (the reference wraps it in a Ray ObjectRef)."""
+    U, stack, A = config.num_unroll_steps, config.stacked_observations, config.action_space_size
+    D = config.obs_shape // stack
+    n = len(games)
+    obs = np.zeros((n * (U + 1), stack, D), np.float32)
+    legal = np.zeros((n * (U + 1), A), np.float64)
+    mask = np.zeros(n * (U + 1), np.int64)
+    traj_lens, child_visits = [], []
+    k = 0
+    for game, pos in zip(games, positions):
+        T = len(game)
+        traj_lens.append(T)
+        child_visits.append(game.child_visits)
+        frames = np.asarray(game.obs(pos, U))
+        for cur in range(pos, pos + U + 1):
+            if cur < T:
+                mask[k] = 1
+                obs[k] = frames[cur - pos:cur - pos + stack]
+                legal[k] = game.legal_actions[cur]
+            k += 1
+    return obs, mask.tolist(), list(positions), list(range(n)) if indices is None else list(indices), child_visits, traj_lens, legal
+
+
 def prepare_policy_re(config, engine, policy_re_context, noises=None, generator=None, tie_seed=0, device=None):
     """policy_re_context = (policy_obs_lst, policy_mask, state_index_lst, indices, child_visits, traj_lens,
     legal_action_lst) exactly as BatchWorker_CPU builds it (reanalyze_worker.py:101-167); policy_obs_lst is an array

@@ -301,3 +301,66 @@ def test_self_play_to_learner_loop_on_one_gpu():
         actor.step()
     torch.cuda.synchronize()
     assert int(actor.illegal_steps) == 0 and int(actor.out_count[0].item()) > before
+
+
+@pytest.mark.gpu
+def test_config5_loop_hanabi_full_5p_with_reanalyze_on_one_gpu():
+    """BASELINE.json configs[4] on one GPU, Ray-free: Hanabi-Full 5 players (A = 48, D = 1385, mdp global) self-play ->
+    drain_packed -> gather_packed -> ReplayBuffer.ingest_packed -> prepare_batch_context -> reanalyze (policy_re_context +
+    prepare_policy_re: the second caller of the search kernels refreshes the policy targets of the reanalyzed part of the
+    batch with the target model) -> make_batch -> update_weights (bf16 autocast) -> engine.load -> the graph-captured actor
+    keeps playing with the new weights.  The loop of core/reanalyze_worker.py:148-204, 307-371, 402-422 + core/train.py:317-431."""
+    from hanabizero_amd.dist import gather_packed
+    from hanabizero_amd.learner import make_batch, make_optimizer, update_weights
+    from hanabizero_amd.model import InferenceEngine
+    from hanabizero_amd.reanalyze import policy_re_context, prepare_policy_re
+    from hanabizero_amd.replay import ReplayBuffer
+    from hanabizero_amd.selfplay import SelfPlayActor
+    from hanabizero_amd.config import make_config
+    cfg = make_config("Hanabi-Full-5p", simulations=20, stack=4, batch_size=64)
+    assert (cfg.action_space_size, cfg.obs_dim, cfg.mdp) == (48, 1385, "global")
+    torch.manual_seed(0)
+    net = cfg.get_uniform_network()
+    for p in net.parameters():
+        if float(p.detach().abs().sum()) == 0.0:
+            torch.nn.init.normal_(p, std=0.1)
+    net.eval()
+    eng = InferenceEngine(net, cfg.value_support.max, dtype=torch.bfloat16, device="cuda")       # the actors' model
+    target = InferenceEngine(net, cfg.value_support.max, dtype=torch.bfloat16, device="cuda")    # the reanalyze workers' target model
+    actor = SelfPlayActor(cfg, eng, 256, seed=4)
+    rb = ReplayBuffer(cfg)
+    for step in range(36):
+        actor.step()
+        if step % 12 == 11:
+            for buf, n, moves in gather_packed(actor.drain_packed(), actor.A, actor.W):
+                rb.ingest_packed(buf, n, moves)
+    assert rb.size() > 40 and rb.get_total_len() > 4 * cfg.batch_size
+    assert rb.buffer[0].legal_actions.shape[1] == 48 and rb.buffer[0].obs_history.shape[1] == 1385
+    learner = cfg.get_uniform_network().cuda()
+    learner.load_state_dict(net.state_dict())
+    opt = make_optimizer(learner, cfg)
+    for grp in opt.param_groups:
+        grp["lr"] = 0.02
+    value_fn = lambda o: target.initial(torch.from_numpy(o).cuda())[0].float().cpu().numpy()
+    R = int(cfg.batch_size * 0.5)  # revisit_policy_search_rate: half the batch gets re-searched policy targets
+    losses = []
+    for it in range(3):
+        games, pos, idx, w, mt = rb.prepare_batch_context(cfg.batch_size, beta=0.4)
+        ctx = policy_re_context(cfg, games[:R], pos[:R], idx[:R])
+        pol_re = prepare_policy_re(cfg, target, ctx, tie_seed=it)
+        assert pol_re.shape == (R, cfg.num_unroll_steps + 1, 48)
+        live = np.asarray(ctx[1]).reshape(R, -1) != 0
+        assert np.allclose(pol_re.sum(-1)[live], 1.0) and (pol_re.sum(-1)[~live] == 0).all()
+        batch = make_batch(games, pos, cfg, value_fn, weights=w, rng=np.random.RandomState(it), policy_re=pol_re)
+        assert np.array_equal(batch[1][2][:R], pol_re.astype(np.float32))
+        loss_data, prio = update_weights(learner, batch, opt, cfg, amp=torch.bfloat16)
+        rb.update_priorities(idx, prio, mt)
+        losses.append(loss_data[1])
+    assert np.isfinite(losses).all()
+    learner.eval()
+    eng.load(learner.cpu())
+    before = int(actor.out_count[0].item())
+    for _ in range(10):
+        actor.step()
+    torch.cuda.synchronize()
+    assert int(actor.illegal_steps) == 0 and int(actor.out_count[0].item()) > before

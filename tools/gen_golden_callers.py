@@ -18,7 +18,7 @@ as a reference stand-in).  What is recorded is data: inputs and the reference's 
                            _prepare_reward_value (:249-304) + _prepare_policy_non_re (:374-399): inputs and targets of a
                            learner batch for fixed games / positions with the reference net as target model
 
-Usage: python tools/gen_golden_callers.py
+Usage: python tools/gen_golden_callers.py [--only select_action|game_history|learner_step|batch_targets]
 """
 import argparse
 import os
@@ -300,11 +300,17 @@ def gen_batch_targets(R, game_name, stack):
     gpu.model.eval()
     batch_values, batch_rewards = gpu._prepare_reward_value(reward_value_context)
     batch_policies = gpu._prepare_policy_non_re(policy_non_re_context)
+    # the context of the reanalyzed policy targets for the first 5 positions (reanalyze_worker.py:101-144): what the search
+    # of _prepare_policy_re is prepared from (that search itself is pinned through the tree goldens + tests/test_callers.py)
+    re_num = 5
+    re_ctx = cpu._prepare_policy_re_context(list(range(re_num)), game_lst[:re_num], pos_lst[:re_num])
     out = dict(stack=stack, D=D, A=A, U=U, td_steps=td, discount=cfg.discount, pick=pick, positions=np.array(pos_lst),
                weights=weights_lst, in_obs=np.asarray(inputs_batch[0]).astype(np.uint8), in_action=np.asarray(inputs_batch[1]),
                in_mask=np.asarray(inputs_batch[2]), target_value=np.asarray(batch_values, np.float64),
                target_reward=np.asarray(batch_rewards, np.float64), target_policy=np.asarray(batch_policies, np.float64),
-               pad_action_seed=77)
+               pad_action_seed=77, re_num=re_num, re_obs=np.asarray(re_ctx[0]).astype(np.uint8), re_mask=np.asarray(re_ctx[1]),
+               re_state_index=np.asarray(re_ctx[2]), re_indices=np.asarray(re_ctx[3]), re_traj_lens=np.asarray(re_ctx[5]),
+               re_legal=np.asarray(re_ctx[6], np.float64))
     for i, raw in enumerate(raws):
         for k, v in raw.items():
             out["game%d_%s" % (i, k)] = v
@@ -314,12 +320,17 @@ def gen_batch_targets(R, game_name, stack):
 
 def main():
     assert os.path.exists(os.path.join(REF, "core", "train.py")), "needs /root/reference (authoring container)"
+    only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
     R = _reference()
-    gen_select_action(R)
-    gen_game_history(R)
-    gen_learner_step(R, "Hanabi-Small", stack=2, B=8)
-    gen_learner_step(R, "Hanabi-Full", stack=1, B=4)
-    gen_batch_targets(R, "Hanabi-Small", stack=2)
+    if only in (None, "select_action"):
+        gen_select_action(R)
+    if only in (None, "game_history"):
+        gen_game_history(R)
+    if only in (None, "learner_step"):
+        gen_learner_step(R, "Hanabi-Small", stack=2, B=8)
+        gen_learner_step(R, "Hanabi-Full", stack=1, B=4)
+    if only in (None, "batch_targets"):
+        gen_batch_targets(R, "Hanabi-Small", stack=2)
 
 
 if __name__ == "__main__":
