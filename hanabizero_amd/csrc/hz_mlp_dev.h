@@ -121,9 +121,12 @@ extern "C" int hz_mlp_profile_read_passes(unsigned long long* host) {
 #define PROF_ADD(var, t0) (void)(t0)
 #endif
 
-// Weight-fragment ring: HZ_RING slots of one k-step each.  Measured: 4 and 8 slots stream at the same
-// rate (the memory pipe's own queue is the limit), 4 leaves registers for 16 waves per workgroup.
-#define HZ_RING 4
+// Weight-fragment ring: RING slots of one k-step each.  16 waves per workgroup (128 registers per lane): 4 slots.  Workgroups of
+// <= 8 waves may hold 256 registers per lane: HZ_RING_WIDE slots, so that the loads in flight cover a layer boundary
+// (epilogue + barrier) and the weight stream does not stop there.
+#ifndef HZ_RING_WIDE
+#define HZ_RING_WIDE 4
+#endif
 
 // Issue priority of this wave for the next few k-steps.  The sequencer serves the oldest wave of a SIMD first, so with a
 // fixed priority wave w < 4 of a workgroup (the oldest on its SIMD) streams its share of a layer in half the time the
@@ -204,11 +207,12 @@ __device__ __forceinline__ void mlp_body(
   const v8* wbase = reinterpret_cast<const v8*>(wstream + H.wave_stream_off[wave]);
   const long long kss = H.kstep_stride / 8;  // in 16-B fragments-per-lane units
 #define wp(k, t) wbase[(long long)(k) * kss + (t) * 64 + lane]
-  // Prefetch distance in k-steps.  16-row shapes: HZ_RING - 1 (2 costs 1.7 % moves/s at 4096 envs).  32-row shape: 2 -- one
+  // Prefetch distance in k-steps.  16-row shapes: RING - 1 (2 costs 1.7 % moves/s at 4096 envs).  32-row shape: 2 -- one
   // ring slot stays spare, so the refill of a slot does not have to wait for the four MFMAs that have just read it
   // (3: -2.1 % moves/s at 8192 envs, 1: -1.6 %; A/B on one box, tools/ab_bench.sh).
-  constexpr int PF = RT == 1 ? HZ_RING - 1 : 2;
-  v8 wf[HZ_RING][NT];
+  constexpr int RING = NW <= 8 ? HZ_RING_WIDE : 4;
+  constexpr int PF = RT == 1 ? RING - 1 : RING - 2;
+  v8 wf[RING][NT];
 #pragma unroll
   for (int d = 0; d < PF; ++d)
 #pragma unroll
@@ -339,12 +343,12 @@ __device__ __forceinline__ void mlp_body(
     // trips read past the K range, into fragments nobody uses), then this step's MFMAs
 #define HZ_MLP_STEP(S, U)                                                                                            \
     {                                                                                                                \
-      _Pragma("unroll") for (int t = 0; t < NT; ++t) wf[((U) + PF) % HZ_RING][t] = wp(gstep + (S) + PF, t);          \
+      _Pragma("unroll") for (int t = 0; t < NT; ++t) wf[((U) + PF) % RING][t] = wp(gstep + (S) + PF, t);          \
       _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                                              \
           bq[((U) + BQPF) % BQD][rt] = *reinterpret_cast<const v8*>(src + (size_t)(16 * rt) * rs + 32 * ((S) + BQPF)); \
       __builtin_amdgcn_sched_barrier(0);                                                                             \
       _Pragma("unroll") for (int t = 0; t < NT; ++t) _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)               \
-          acc[t][rt] = EL::mfma(wf[(U) % HZ_RING][t], bq[(U) % BQD][rt], acc[t][rt]);                                \
+          acc[t][rt] = EL::mfma(wf[(U) % RING][t], bq[(U) % BQD][rt], acc[t][rt]);                                \
       __builtin_amdgcn_sched_barrier(0);                                                                             \
     }
 

@@ -127,7 +127,7 @@ def test_graph_replay_equals_eager():
 def test_engine_load_reaches_a_graph_captured_actor(game, dtype):
     """A weight update (net.set_weights(w); engine.load(net): selfplay_worker.py:177-184) must reach an actor whose lock-step
     is a captured hipGraph -- the graph has the engine's tensor addresses baked in, so load() overwrites them in place.
-    A graph actor and an eager actor (which reads the engine's tensors at call time: the ground truth) play 3 moves,
+    A graph actor and an eager actor (which reads the engine's tensors at call time: the ground truth) play 5 moves,
     both engines load new weights, they play 4 more: everything they record must agree, and must differ from a graph
     actor that kept the old weights."""
     import copy
@@ -135,7 +135,7 @@ def test_engine_load_reaches_a_graph_captured_actor(game, dtype):
     for use_graph, reload in ((True, True), (False, True), (True, False)):
         cfg, eng, actor = make(game, 64, 12, 2, dtype, use_graph, seed=21)
         ptrs = sorted(t.data_ptr() for t in eng._dev.values())
-        for _ in range(3):
+        for _ in range(3 if use_graph else 5):  # (capturing plays two warm-up moves of its own: 5 moves either way)
             actor.step()
         if reload:
             net2 = copy.deepcopy(eng._net)

@@ -12,8 +12,10 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 STRIP = ["-DHZ_MLP_X_NOEPI", "-DHZ_MLP_X_NOFINAL", "-DHZ_MLP_X_NOSTAGE"]
-VARIANTS = [("baseline", []), ("no epilogues", ["-DHZ_MLP_X_NOEPI"]), ("no epi/final/staging", STRIP)]
-SHAPES = [(4, 4), (8, 4), (16, 2)]
+RING8 = ["-DHZ_RING_WIDE=8"]  # (only workgroups of <= 8 waves have the registers for it: no effect on 16 x 2)
+VARIANTS = [("baseline", []), ("no epilogues", ["-DHZ_MLP_X_NOEPI"]), ("no epi/final/staging", STRIP),
+            ("ring 8", RING8), ("ring 8, no epilogues", RING8 + ["-DHZ_MLP_X_NOEPI"]), ("ring 8, no epi/final/staging", RING8 + STRIP)]
+SHAPES = [(8, 4), (16, 2)]
 
 
 def main():
@@ -31,7 +33,8 @@ def main():
     r, v, p = torch.empty(N, device="cuda"), torch.empty(N, device="cuda"), torch.empty(N, eng.A, device="cuda")
     V, I, I64 = C.c_void_p, C.c_int, C.c_int64
     src = os.path.join(ROOT, "hanabizero_amd", "csrc")
-    for name, flags, f in [(n + " %dx%d" % sh, fl, eng.fused_shape(*sh)) for sh in SHAPES for n, fl in VARIANTS]:
+    for name, flags, f in [(n + " %dx%d" % sh, fl, eng.fused_shape(*sh)) for sh in SHAPES for n, fl in VARIANTS
+                           if not (sh[0] > 8 and "ring 8" in n)]:
         mt = f.rows_per_wg(N)
         out = os.path.join(ROOT, "gpurun_out", "libmlp_var_%s.so" % "".join(c for c in name if c.isalnum()))
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
