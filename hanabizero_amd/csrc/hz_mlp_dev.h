@@ -202,21 +202,48 @@ __device__ __forceinline__ void mlp_body(
     plane0[u] = (!PRESTAGED && plane_index && i < n_stage && row < n_rows) ? (long long)plane_index[row] * plane_stride : 0;
   }
   __builtin_amdgcn_sched_barrier(0);
-  // this wave's weight stream
-  // uniform base + per-lane 16-B offset: the k-loop advances the base on the scalar unit, not with 64-bit VALU adds
-  const v8* wbase = reinterpret_cast<const v8*>(wstream + H.wave_stream_off[wave]);
-  const long long kss = H.kstep_stride / 8;  // in 16-B fragments-per-lane units
-#define wp(k, t) wbase[(long long)(k) * kss + (t) * 64 + lane]
+  // this wave's weight stream: a uniform base (scalar registers) + a per-lane byte offset that walks the stream
+  const char* wbase = reinterpret_cast<const char*>(wstream + H.wave_stream_off[wave]);
+  const unsigned int kss = (unsigned int)(H.kstep_stride * 2);  // bytes between consecutive k-steps of this wave's stream
   // Prefetch distance in k-steps.  16-row shapes: RING - 1 (2 costs 1.7 % moves/s at 4096 envs).  32-row shape: 2 -- one
   // ring slot stays spare, so the refill of a slot does not have to wait for the four MFMAs that have just read it
   // (3: -2.1 % moves/s at 8192 envs, 1: -1.6 %; A/B on one box, tools/ab_bench.sh).
   constexpr int RING = NW <= 8 ? HZ_RING_WIDE : 4;
   constexpr int PF = RT == 1 ? RING - 1 : RING - 2;
-  v8 wf[RING][NT];
+  // NT == 2 (the 16 x 2 shape of the persistent search kernel): the k-loop is hand-scheduled assembly (below) and its
+  // loads are invisible to the compiler; the other shapes keep the compiler-scheduled loop.
+  constexpr bool ASMK = NT == 2 && RING == 4;
+  v8 wf[RING][NT] = {};
+  unsigned int voff = (unsigned int)lane * 16u;  // ASMK: byte offset of the next fragment this lane requests
+  long long gstep = 0;                           // !ASMK: k-steps of this wave's stream consumed so far
+#define wp(k, t) (*reinterpret_cast<const v8*>(wbase + (long long)(k) * kss + ((t) * 1024u + (unsigned int)lane * 16u)))
+  if constexpr (ASMK) {
+    static_assert(!ASMK || PF == 3 || PF == 2, "ring of 4 k-steps");
+    if constexpr (PF == 3)
+      asm volatile(
+          "global_load_dwordx4 %[w00], %[voff], %[sa]\n\tglobal_load_dwordx4 %[w01], %[voff], %[sa] offset:1024\n\t"
+          "v_add_u32 %[voff], %[kss], %[voff]\n\t"
+          "global_load_dwordx4 %[w10], %[voff], %[sa]\n\tglobal_load_dwordx4 %[w11], %[voff], %[sa] offset:1024\n\t"
+          "v_add_u32 %[voff], %[kss], %[voff]\n\t"
+          "global_load_dwordx4 %[w20], %[voff], %[sa]\n\tglobal_load_dwordx4 %[w21], %[voff], %[sa] offset:1024\n\t"
+          "v_add_u32 %[voff], %[kss], %[voff]"
+          : [w00] "=&v"(wf[0][0]), [w01] "=&v"(wf[0][1]), [w10] "=&v"(wf[1][0]), [w11] "=&v"(wf[1][1]),
+            [w20] "=&v"(wf[2][0]), [w21] "=&v"(wf[2][1]), [voff] "+v"(voff)
+          : [sa] "s"(wbase), [kss] "s"(kss));
+    else
+      asm volatile(
+          "global_load_dwordx4 %[w00], %[voff], %[sa]\n\tglobal_load_dwordx4 %[w01], %[voff], %[sa] offset:1024\n\t"
+          "v_add_u32 %[voff], %[kss], %[voff]\n\t"
+          "global_load_dwordx4 %[w10], %[voff], %[sa]\n\tglobal_load_dwordx4 %[w11], %[voff], %[sa] offset:1024\n\t"
+          "v_add_u32 %[voff], %[kss], %[voff]"
+          : [w00] "=&v"(wf[0][0]), [w01] "=&v"(wf[0][1]), [w10] "=&v"(wf[1][0]), [w11] "=&v"(wf[1][1]), [voff] "+v"(voff)
+          : [sa] "s"(wbase), [kss] "s"(kss));
+  } else {
 #pragma unroll
-  for (int d = 0; d < PF; ++d)
+    for (int d = 0; d < PF; ++d)
 #pragma unroll
-    for (int t = 0; t < NT; ++t) wf[d][t] = wp(d, t);
+      for (int t = 0; t < NT; ++t) wf[d][t] = wp(d, t);
+  }
   __builtin_amdgcn_sched_barrier(0);
 
   // stage the states into the image; rows past N read as zero
@@ -269,7 +296,6 @@ __device__ __forceinline__ void mlp_body(
 
   const unsigned long long p_staged = PROF_NOW();
   (void)p_staged;
-  long long gstep = 0;  // k-steps of this wave's stream consumed so far
   for (int j = 0; j < H.n_jobs; ++j) {
     // this lane's place in the MFMA fragments, derived afresh per job from an opaque copy of the lane index: kept across
     // the jobs the derived LDS addresses are spilled at 128 registers per lane, and their reloads (scratch = vector
@@ -286,21 +312,22 @@ __device__ __forceinline__ void mlp_body(
     J.res_off = __builtin_amdgcn_readlane(jr, jb + 3);
     J.bias_off = __builtin_amdgcn_readlane(jr, jb + 4);
     J.flags = __builtin_amdgcn_readlane(jr, jb + 5);
-    // epilogue operands first, and BEFORE the layer barrier: they depend on nothing the other waves produce, their
-    // latency hides under the k-loop, and their address arithmetic stays off the path between barrier and first MFMA
-    float4 bv[NT], av[NT][RT];
+    // The accumulators start from the epilogue's additive term -- bias (+ the action's column of the first dynamics layer):
+    // one row of the action table per batch row (row num_actions = the bias alone) -- requested first and BEFORE the layer
+    // barrier: it depends on nothing the other waves produce.  Loads under no branch on the job's flags: every job takes them.
+    f32x4 acc[NT][RT];
     if (J.ks != 0) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        bv[t] = *reinterpret_cast<const float4*>(bias + J.bias_off + 16 * t + c4);
-        // unconditional loads (row num_actions of the table is all zeros): a load under a branch would make the
-        // compiler wait for EVERY outstanding load (vmcnt(0)) in the epilogue and drain the weight ring once per job
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
           const int arow = (J.flags & HZ_MLP_ACTION_ROW) ? act[rt] : H.num_actions;
-          av[t][rt] = *reinterpret_cast<const float4*>(act_tab + (size_t)arow * H.action_table_stride + J.bias_off + 16 * t + c4);
+          const float* p = act_tab + (size_t)arow * H.action_table_stride + J.bias_off + 16 * t + c4;
+          if constexpr (ASMK)  // (hidden from the compiler like the weight stream: it must not wait for them with vmcnt(0))
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(acc[t][rt]) : "v"(p));
+          else
+            acc[t][rt] = *reinterpret_cast<const f32x4*>(p);
         }
-      }
     }
     const unsigned long long p_j0 = PROF_NOW();
     if (J.flags & HZ_MLP_BARRIER) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // LDS only: loads stay in flight
@@ -319,50 +346,155 @@ __device__ __forceinline__ void mlp_body(
 #endif
     if (J.ks == 0) continue;
     const unsigned long long p_j1 = PROF_NOW();
-    // the first activation fragments right behind the barrier: this LDS round trip is the one latency nothing hides
     const uint16_t* src = lds + (size_t)r0 * rs + J.src_off + kq;
-    // activation fragments, BQPF k-steps ahead of their use (RT = 2 has the registers for one step ahead only -- two
-    // measured no faster, with more spills; its four MFMAs per k-step cover the LDS round trip)
-    constexpr int BQD = RT == 1 ? 4 : 2;
-    constexpr int BQPF = BQD - 1;
-    v8 bq[BQD][RT];
-#pragma unroll
-    for (int d = 0; d < BQPF; ++d)
-      if (d < J.ks) {
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) bq[d][rt] = *reinterpret_cast<const v8*>(src + (size_t)(16 * rt) * rs + 32 * d);
-      }
-    f32x4 acc[NT][RT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) acc[t][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    __builtin_amdgcn_sched_barrier(0);
-
-    // one k-step: request the fragments PF steps ahead (weights) / BQPF steps ahead (activations; unconditional: the last
-    // trips read past the K range, into fragments nobody uses), then this step's MFMAs
-#define HZ_MLP_STEP(S, U)                                                                                            \
-    {                                                                                                                \
-      _Pragma("unroll") for (int t = 0; t < NT; ++t) wf[((U) + PF) % RING][t] = wp(gstep + (S) + PF, t);          \
-      _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                                              \
-          bq[((U) + BQPF) % BQD][rt] = *reinterpret_cast<const v8*>(src + (size_t)(16 * rt) * rs + 32 * ((S) + BQPF)); \
-      __builtin_amdgcn_sched_barrier(0);                                                                             \
-      _Pragma("unroll") for (int t = 0; t < NT; ++t) _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)               \
-          acc[t][rt] = EL::mfma(wf[(U) % RING][t], bq[(U) % BQD][rt], acc[t][rt]);                                \
-      __builtin_amdgcn_sched_barrier(0);                                                                             \
-    }
-
-    // all but the last 8 k-steps in a loop, the last 8 peeled: the 32 fragment loads they issue sit between the
-    // bias / action-row loads above and their first use, so the compiler can wait with vmcnt(>=28) instead of draining
-    // the whole ring (its wait-count analysis forgets how many loads a loop issued)
     PROF_ADD(p_pre, p_j1);
     const unsigned long long p_j2 = PROF_NOW();
-    int s = 0;
-    const int prio_grp = wave >> 2;
-    // the priorities rotate every 4 k-steps, 16-row shapes only (see hz_rotate_prio)
+    if constexpr (ASMK) {
+      // ---- the k-loop, hand-scheduled (the compiler's own schedule of the same loop drained the weight ring at the start
+      // of every job and of every 8 k-steps: it packs address arithmetic into ring registers and serialises the refills
+      // behind the MFMAs -- 80 GB/s per CU where tools/l2_stream_bench.hip reaches 125 with the same access pattern).
+      // Per k-step: request the fragments PF k-steps ahead (ring slot (u + PF) % 4) and the activation fragments BQPF
+      // k-steps ahead, wait until this step's own fragments have arrived (loads and LDS reads return in order: at most
+      // 2 PF loads / the younger reads may remain), issue its MFMAs.  Blocks of 4 k-steps (ring positions are static),
+      // J.ks / 4 of them; the last block requests no activation fragments past the K range; the weight requests run on
+      // into the next job's first k-steps (the streams are contiguous) -- or into the zero padding behind the stream.
+      // What the compiler must not see move: every register below is an operand of this statement and of no compiler-
+      // generated copy (checked in the build: no spills, __graft_entry__.build()).
+      unsigned int cnt = (unsigned int)J.ks >> 2;
+      unsigned int la0 = (unsigned int)(uintptr_t)(__attribute__((address_space(3))) const uint16_t*)src;
+      const unsigned int prio = (unsigned int)((wave >> 2) + j) & 3u;  // issue priority rotates over the workgroup's four age groups
+      if (RT == 1) hz_rotate_prio((int)prio);
+      if constexpr (RT == 1) {
+        v8 b0, b1, b2, b3;
+#define HZ_K1(W0, W1, WN0, WN1, B, BN, BOFF, LGKM)                                                             \
+  "global_load_dwordx4 %[" WN0 "], %[voff], %[sa]\n\tglobal_load_dwordx4 %[" WN1 "], %[voff], %[sa] offset:1024\n\t" \
+  "v_add_u32 %[voff], %[kss], %[voff]\n\t" BN "s_waitcnt vmcnt(6) lgkmcnt(" LGKM ")\n\t"                        \
+  "v_mfma_f32_16x16x32_" HZ_EL_ASM " %[a0], %[" W0 "], %[" B "], %[a0]\n\t"                                      \
+  "v_mfma_f32_16x16x32_" HZ_EL_ASM " %[a1], %[" W1 "], %[" B "], %[a1]\n\t"
+#define HZ_K1_BODY(EL_ASM)                                                                                      \
+        asm volatile(                                                                                           \
+            "ds_read_b128 %[b0], %[la0]\n\tds_read_b128 %[b1], %[la0] offset:64\n\tds_read_b128 %[b2], %[la0] offset:128\n\t" \
+            "s_waitcnt vmcnt(0)\n"                                                                              \
+            "1:\n\t"                                                                                            \
+            HZ_K1("w00", "w01", "w30", "w31", "b0", "ds_read_b128 %[b3], %[la0] offset:192\n\t", 192, "3")        \
+            HZ_K1("w10", "w11", "w00", "w01", "b1", "ds_read_b128 %[b0], %[la0] offset:256\n\t", 256, "3")        \
+            HZ_K1("w20", "w21", "w10", "w11", "b2", "ds_read_b128 %[b1], %[la0] offset:320\n\t", 320, "3")        \
+            HZ_K1("w30", "w31", "w20", "w21", "b3", "ds_read_b128 %[b2], %[la0] offset:384\n\t", 384, "3")        \
+            "v_add_u32 %[la0], 0x100, %[la0]\n\t"                                                                \
+            "s_sub_u32 %[cnt], %[cnt], 1\n\ts_cmp_lg_u32 %[cnt], 1\n\ts_cbranch_scc1 1b\n\t"                     \
+            HZ_K1("w00", "w01", "w30", "w31", "b0", "ds_read_b128 %[b3], %[la0] offset:192\n\t", 192, "3")        \
+            HZ_K1("w10", "w11", "w00", "w01", "b1", "", 0, "2")                                                   \
+            HZ_K1("w20", "w21", "w10", "w11", "b2", "", 0, "1")                                                   \
+            HZ_K1("w30", "w31", "w20", "w21", "b3", "", 0, "0")                                                   \
+            "s_nop 7\n\ts_nop 7\n\ts_nop 7"                                                                      \
+            : [w00] "+v"(wf[0][0]), [w01] "+v"(wf[0][1]), [w10] "+v"(wf[1][0]), [w11] "+v"(wf[1][1]),              \
+              [w20] "+v"(wf[2][0]), [w21] "+v"(wf[2][1]), [w30] "+v"(wf[3][0]), [w31] "+v"(wf[3][1]),              \
+              [b0] "=&v"(b0), [b1] "=&v"(b1), [b2] "=&v"(b2), [b3] "=&v"(b3), [a0] "+v"(acc[0][0]), [a1] "+v"(acc[1][0]), \
+              [voff] "+v"(voff), [la0] "+v"(la0), [cnt] "+s"(cnt)                                                  \
+            : [sa] "s"(wbase), [kss] "s"(kss)                                                                     \
+            : "memory", "scc")
+        if constexpr (EL::code == HZ_BF16) {
+#define HZ_EL_ASM "bf16"
+          HZ_K1_BODY(bf16);
+#undef HZ_EL_ASM
+        } else {
+#define HZ_EL_ASM "f16"
+          HZ_K1_BODY(f16);
+#undef HZ_EL_ASM
+        }
+#undef HZ_K1_BODY
+#undef HZ_K1
+      } else {
+        // two row tiles: PF = 2 (one ring slot spare), activation fragments one k-step ahead in two slots per row tile
+        v8 b00, b01, b10, b11;
+        unsigned int la1 = la0 + (unsigned int)(16 * rs * 2);
+#define HZ_K2(W0, W1, WN0, WN1, B0, B1, BN, VM, LGKM)                                                           \
+  "global_load_dwordx4 %[" WN0 "], %[voff], %[sa]\n\tglobal_load_dwordx4 %[" WN1 "], %[voff], %[sa] offset:1024\n\t" \
+  "v_add_u32 %[voff], %[kss], %[voff]\n\t" BN "s_waitcnt vmcnt(" VM ") lgkmcnt(" LGKM ")\n\t"                    \
+  "v_mfma_f32_16x16x32_" HZ_EL_ASM " %[a00], %[" W0 "], %[" B0 "], %[a00]\n\t"                                   \
+  "v_mfma_f32_16x16x32_" HZ_EL_ASM " %[a01], %[" W0 "], %[" B1 "], %[a01]\n\t"                                   \
+  "v_mfma_f32_16x16x32_" HZ_EL_ASM " %[a10], %[" W1 "], %[" B0 "], %[a10]\n\t"                                   \
+  "v_mfma_f32_16x16x32_" HZ_EL_ASM " %[a11], %[" W1 "], %[" B1 "], %[a11]\n\t"
+#define HZ_RD2(B0, B1, OFF) "ds_read_b128 %[" B0 "], %[la0] offset:" #OFF "\n\tds_read_b128 %[" B1 "], %[la1] offset:" #OFF "\n\t"
+#define HZ_K2_BODY()                                                                                            \
+        asm volatile(                                                                                           \
+            HZ_RD2("b00", "b01", 0)                                                                               \
+            "s_waitcnt vmcnt(0)\n"                                                                              \
+            "1:\n\t"                                                                                            \
+            HZ_K2("w00", "w01", "w20", "w21", "b00", "b01", HZ_RD2("b10", "b11", 64), "4", "2")                    \
+            HZ_K2("w10", "w11", "w30", "w31", "b10", "b11", HZ_RD2("b00", "b01", 128), "4", "2")                   \
+            HZ_K2("w20", "w21", "w00", "w01", "b00", "b01", HZ_RD2("b10", "b11", 192), "4", "2")                   \
+            HZ_K2("w30", "w31", "w10", "w11", "b10", "b11", HZ_RD2("b00", "b01", 256), "4", "2")                   \
+            "v_add_u32 %[la0], 0x100, %[la0]\n\tv_add_u32 %[la1], 0x100, %[la1]\n\t"                              \
+            "s_sub_u32 %[cnt], %[cnt], 1\n\ts_cmp_lg_u32 %[cnt], 1\n\ts_cbranch_scc1 1b\n\t"                     \
+            HZ_K2("w00", "w01", "w20", "w21", "b00", "b01", HZ_RD2("b10", "b11", 64), "4", "2")                    \
+            HZ_K2("w10", "w11", "w30", "w31", "b10", "b11", HZ_RD2("b00", "b01", 128), "4", "2")                   \
+            HZ_K2("w20", "w21", "w00", "w01", "b00", "b01", HZ_RD2("b10", "b11", 192), "4", "2")                   \
+            HZ_K2("w30", "w31", "w10", "w11", "b10", "b11", "", "4", "0")                                          \
+            "s_nop 7\n\ts_nop 7\n\ts_nop 7"                                                                      \
+            : [w00] "+v"(wf[0][0]), [w01] "+v"(wf[0][1]), [w10] "+v"(wf[1][0]), [w11] "+v"(wf[1][1]),              \
+              [w20] "+v"(wf[2][0]), [w21] "+v"(wf[2][1]), [w30] "+v"(wf[3][0]), [w31] "+v"(wf[3][1]),              \
+              [b00] "=&v"(b00), [b01] "=&v"(b01), [b10] "=&v"(b10), [b11] "=&v"(b11),                              \
+              [a00] "+v"(acc[0][0]), [a01] "+v"(acc[0][1]), [a10] "+v"(acc[1][0]), [a11] "+v"(acc[1][1]),          \
+              [voff] "+v"(voff), [la0] "+v"(la0), [la1] "+v"(la1), [cnt] "+s"(cnt)                                 \
+            : [sa] "s"(wbase), [kss] "s"(kss)                                                                     \
+            : "memory", "scc")
+        if constexpr (EL::code == HZ_BF16) {
+#define HZ_EL_ASM "bf16"
+          HZ_K2_BODY();
+#undef HZ_EL_ASM
+        } else {
+#define HZ_EL_ASM "f16"
+          HZ_K2_BODY();
+#undef HZ_EL_ASM
+        }
+#undef HZ_K2_BODY
+#undef HZ_RD2
+#undef HZ_K2
+      }
+    } else {
+      // ---- the compiler-scheduled k-loop of the other shapes
+      // activation fragments, BQPF k-steps ahead of their use (RT = 2 has the registers for one step ahead only -- two
+      // measured no faster, with more spills; its four MFMAs per k-step cover the LDS round trip)
+      constexpr int BQD = RT == 1 ? 4 : 2;
+      constexpr int BQPF = BQD - 1;
+      v8 bq[BQD][RT];
+#pragma unroll
+      for (int d = 0; d < BQPF; ++d)
+        if (d < J.ks) {
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) bq[d][rt] = *reinterpret_cast<const v8*>(src + (size_t)(16 * rt) * rs + 32 * d);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+      // one k-step: request the fragments PF steps ahead (weights) / BQPF steps ahead (activations; unconditional: the last
+      // trips read past the K range, into fragments nobody uses), then this step's MFMAs
+#define HZ_MLP_STEP(S, U)                                                                                            \
+      {                                                                                                              \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t) wf[((U) + PF) % RING][t] = wp(gstep + (S) + PF, t);            \
+        _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                                            \
+            bq[((U) + BQPF) % BQD][rt] = *reinterpret_cast<const v8*>(src + (size_t)(16 * rt) * rs + 32 * ((S) + BQPF)); \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t) _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)             \
+            acc[t][rt] = EL::mfma(wf[(U) % RING][t], bq[(U) % BQD][rt], acc[t][rt]);                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+      }
+      // all but the last 8 k-steps in a loop, the last 8 peeled: the fragment loads they issue sit between the epilogue
+      // operands' loads above and their first use, so the compiler can wait with a counted vmcnt instead of draining the ring
+      int s = 0;
+      const int prio_grp = wave >> 2;
+      // the priorities rotate every 4 k-steps, 16-row shapes only (see hz_rotate_prio)
 #define HZ_PRIO_AT(S, U) \
   if (RT == 1 && ((U) & 3) == 0) hz_rotate_prio(prio_grp + (int)((gstep + (S)) >> 2));
-    for (; s + 8 < J.ks; s += 8) {
+      for (; s + 8 < J.ks; s += 8) {
+        HZ_PRIO_AT(s, 0) HZ_MLP_STEP(s, 0)
+        HZ_MLP_STEP(s + 1, 1)
+        HZ_MLP_STEP(s + 2, 2)
+        HZ_MLP_STEP(s + 3, 3)
+        HZ_PRIO_AT(s + 4, 4) HZ_MLP_STEP(s + 4, 4)
+        HZ_MLP_STEP(s + 5, 5)
+        HZ_MLP_STEP(s + 6, 6)
+        HZ_MLP_STEP(s + 7, 7)
+      }
       HZ_PRIO_AT(s, 0) HZ_MLP_STEP(s, 0)
       HZ_MLP_STEP(s + 1, 1)
       HZ_MLP_STEP(s + 2, 2)
@@ -371,26 +503,25 @@ __device__ __forceinline__ void mlp_body(
       HZ_MLP_STEP(s + 5, 5)
       HZ_MLP_STEP(s + 6, 6)
       HZ_MLP_STEP(s + 7, 7)
-    }
-    HZ_PRIO_AT(s, 0) HZ_MLP_STEP(s, 0)
-    HZ_MLP_STEP(s + 1, 1)
-    HZ_MLP_STEP(s + 2, 2)
-    HZ_MLP_STEP(s + 3, 3)
-    HZ_PRIO_AT(s + 4, 4) HZ_MLP_STEP(s + 4, 4)
-    HZ_MLP_STEP(s + 5, 5)
-    HZ_MLP_STEP(s + 6, 6)
-    HZ_MLP_STEP(s + 7, 7)
 #undef HZ_PRIO_AT
 #undef HZ_MLP_STEP
-    gstep += J.ks;
+      gstep += J.ks;
+    }
     PROF_ADD(p_loop, p_j2);
     const unsigned long long p_j3 = PROF_NOW();
 
 #ifdef HZ_MLP_X_NOEPI  // experiment (tools/mlp_variants.py): what the epilogues cost; results are garbage
-    if (acc[0][0][0] + acc[NT - 1][0][0] + bv[0].x + av[0][0].x == 12345.678f) lds[tid] = 1;
+    {
+      float x = 0.f;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) x += acc[t][rt][0] + acc[t][rt][1] + acc[t][rt][2] + acc[t][rt][3];  // (every MFMA stays alive)
+      if (x == 12345.678f) lds[tid] = 1;
+    }
     continue;
 #endif
-    // epilogue: bias (+ action row) (+ residual) (+ ReLU) in fp32, round to EL, 4 consecutive columns per lane
+    // epilogue: (+ residual) (+ ReLU) in fp32, round to EL, 4 consecutive columns per lane
     const bool relu = J.flags & HZ_MLP_RELU;
     // all residual fragments in one batch of LDS reads (one wait), not one round trip per column tile
     uint2 rr[NT][RT];
@@ -412,8 +543,7 @@ __device__ __forceinline__ void mlp_body(
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
         const size_t rowbase = (size_t)(16 * rt + r0) * rs;
-        float v[4] = {acc[t][rt][0] + bv[t].x + av[t][rt].x, acc[t][rt][1] + bv[t].y + av[t][rt].y,
-                      acc[t][rt][2] + bv[t].z + av[t][rt].z, acc[t][rt][3] + bv[t].w + av[t][rt].w};
+        float v[4] = {acc[t][rt][0], acc[t][rt][1], acc[t][rt][2], acc[t][rt][3]};
         v[0] += EL::lo(rr[t][rt].x); v[1] += EL::hi(rr[t][rt].x);
         v[2] += EL::lo(rr[t][rt].y); v[3] += EL::hi(rr[t][rt].y);
         if (relu) {
@@ -428,6 +558,10 @@ __device__ __forceinline__ void mlp_body(
     }
     PROF_ADD(p_epi, p_j3);
   }
+  if constexpr (ASMK)  // the last requests ran into the padding behind the stream: nobody waits for them, so wait here
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(wf[0][0]), "+v"(wf[0][1]), "+v"(wf[1][0]), "+v"(wf[1][1]), "+v"(wf[2][0]), "+v"(wf[2][1]),
+                   "+v"(wf[3][0]), "+v"(wf[3][1]));
 #undef wp
   const unsigned long long p_jobs_done = PROF_NOW();
   (void)p_jobs_done;

@@ -618,9 +618,12 @@ class _FusedChain:
                                     res_off=-1 if e["res"] is None else e["res"], bias_off=bias_off, flags=flags,
                                     reserved0=pass_ks))
         biases = torch.cat(bias_chunks)
-        act_table = torch.zeros(A + 1, biases.numel())      # row A stays zero: what jobs without an action row add
+        # the additive term of every output column, by action: the accumulators of the kernel START from a row of this table
+        # (row A = the bias alone: what jobs without an action row take; row a < A = bias + the action's column of the first
+        # dynamics layer), so its epilogue adds nothing
+        act_table = biases.unsqueeze(0).repeat(A + 1, 1)
         for off, blk in act_rows:                           # blk [n <= cw, A] = columns of the action block
-            act_table[:A, off:off + blk.shape[0]] = blk.t()
+            act_table[:A, off:off + blk.shape[0]] += blk.t()
         # weight streams, interleaved k-step by k-step: [k-step][wave][tiles * 512]; at any moment the waves of a
         # workgroup (all near the same k-step) read one contiguous region
         frag = tiles * 512

@@ -31,7 +31,7 @@ extern "C" {
 
 enum {
   HZ_MLP_RELU = 1,          /* ReLU in the epilogue */
-  HZ_MLP_ACTION_ROW = 2,    /* add action_table[action[row]][bias_off-relative column] (first dynamics layer) */
+  HZ_MLP_ACTION_ROW = 2,    /* start from action_table[action[row]] instead of action_table[num_actions] (first dynamics layer) */
   HZ_MLP_BARRIER = 4,       /* workgroup barrier before the job (layer boundary); same for the 4 waves of a job */
   HZ_MLP_STORE_HIDDEN = 8   /* after that barrier copy LDS columns [hidden_off, hidden_off+hidden) to hidden_out */
 };
@@ -43,7 +43,7 @@ typedef struct {
   int32_t src_off;   /* first input column */
   int32_t dst_off;   /* first of the 64 output columns */
   int32_t res_off;   /* first residual column (added before the ReLU) or -1 */
-  int32_t bias_off;  /* index of the 64 fp32 biases; also the column of action_table rows when HZ_MLP_ACTION_ROW */
+  int32_t bias_off;  /* first of this job's columns in action_table rows (and in biases) */
   int32_t flags;
   int32_t reserved0, reserved1;
 } hz_mlp_job_t;
@@ -73,7 +73,11 @@ typedef struct {
 
 /* jobs        [n_jobs][num_waves] hz_mlp_job_t (DEVICE)
  * wstream     packed bf16 weight streams (DEVICE; each stream followed by >= 8 k-steps of zero padding)
- * biases      fp32 (DEVICE), action_table [num_actions + 1][action_table_stride] fp32 (DEVICE; last row all zero)
+ * action_table [num_actions + 1][action_table_stride] fp32 (DEVICE): the additive term of every output column by action --
+ *             row a < num_actions = bias + the action's column of the first dynamics layer where a job has
+ *             HZ_MLP_ACTION_ROW, row num_actions = the bias alone.  The accumulators start from a row of it (fp32), the
+ *             MFMAs add the products on top, the epilogue adds only the residual.
+ * biases      fp32 (DEVICE): the biases alone, in the same column layout (kept for inspection; the kernel reads action_table)
  * state rows  row i is read from state_src + plane_index[i]*plane_stride + i*row_stride (bf16 elements);
  *             plane_index may be NULL (= 0).  With the search's pool [S][N][H]: plane_index = hz_tree_traverse's
  *             out_ix, plane_stride = N*H, row_stride = H -> the gather of core/mcts.py:31-36 happens here.

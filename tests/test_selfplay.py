@@ -142,7 +142,7 @@ def test_engine_load_reaches_a_graph_captured_actor(game, dtype):
             g = torch.Generator().manual_seed(5)
             with torch.no_grad():
                 for p in net2.parameters():
-                    p.add_(0.05 * torch.randn(p.shape, generator=g))
+                    p.add_(0.02 * torch.randn(p.shape, generator=g))
             v_before = eng.version
             eng.load(net2)
             assert eng.version == v_before + 1
@@ -153,9 +153,10 @@ def test_engine_load_reaches_a_graph_captured_actor(game, dtype):
         assert int(actor.illegal_steps) == 0
         runs.append((actor.counts.clone(), actor.values.clone(), actor.action.clone(), actor.pool.clone(),
                      actor.traj["action"].clone(), actor.traj_len.clone(), actor.env.probe().clone()))
-    for a, b in zip(runs[0], runs[1]):
-        assert torch.equal(a, b), "the graph actor did not see the weights the eager actor saw"
-    assert not torch.equal(runs[0][0], runs[2][0]) and not torch.equal(runs[0][3], runs[2][3]), "the new weights changed nothing"
+    bits = lambda t: t.view(torch.int16) if t.dtype in (torch.float16, torch.bfloat16) else (t.view(torch.int32) if t.dtype == torch.float32 else t)
+    for a, b in zip(runs[0], runs[1]):  # (bit patterns: fp16 hidden states of the perturbed net may hold inf / NaN)
+        assert torch.equal(bits(a), bits(b)), "the graph actor did not see the weights the eager actor saw"
+    assert not torch.equal(runs[0][0], runs[2][0]) and not torch.equal(bits(runs[0][3]), bits(runs[2][3])), "the new weights changed nothing"
 
 
 def test_root_noise_stream_is_dirichlet_and_sharding_independent():
@@ -248,7 +249,7 @@ def test_persistent_search_kernel_equals_launch_per_phase(game, N, sims, peaked,
     for b in res[1:]:
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[4], b[4])
         assert torch.equal(a[3][0], b[3][0]) and torch.equal(a[3][1], b[3][1])
-        assert torch.equal(a[5], b[5])
+        assert torch.equal(a[5].view(torch.int16), b[5].view(torch.int16))  # (bit patterns: a 49-deep fp16 chain of random nets overflows to inf / NaN)
     assert int(a[0].sum()) == N * (sims - 1)
     if peaked:  # paths longer than the 32 lanes a tree has in the side-by-side kernel: its backup runs in two chunks
         assert int(a[4].max()) > 34, int(a[4].max())
