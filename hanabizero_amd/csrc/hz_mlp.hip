@@ -27,6 +27,20 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_recurrent(
                        hidden_out, out_reward, out_value, out_policy, n_rows, lds, (int)blockIdx.x * 16 * RT, nullptr);
 }
 
+// The 16 waves x 2 tiles shape runs the hand-scheduled k-loop of hz_mlp_dev.h, whose weight ring lives in registers the
+// compiler is kept away from (HZ_ASMK_VGPRS).
+template <class EL, int RT>
+__global__ __launch_bounds__(1024, 1) __attribute__((amdgpu_num_vgpr(HZ_ASMK_VGPRS))) void k_mlp_recurrent16(
+    hz_mlp_header_t H, const hz_mlp_job_t* __restrict__ jobs, const uint16_t* __restrict__ wstream,
+    const float* __restrict__ bias, const float* __restrict__ act_tab, const uint16_t* __restrict__ state_src,
+    long long state_row_stride, const int32_t* __restrict__ plane_index, long long plane_stride,
+    const int32_t* __restrict__ actions, uint16_t* __restrict__ hidden_out, float* __restrict__ out_reward,
+    float* __restrict__ out_value, float* __restrict__ out_policy, int n_rows) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+  mlp_body<EL, RT, 16, 2>(H, jobs, wstream, bias, act_tab, state_src, state_row_stride, plane_index, plane_stride, actions,
+                          hidden_out, out_reward, out_value, out_policy, n_rows, lds, (int)blockIdx.x * 16 * RT, nullptr);
+}
+
 extern "C" int hz_mlp_recurrent(const hz_mlp_header_t* H, const hz_mlp_job_t* jobs, const void* wstream,
                                 const float* biases, const float* action_table, const void* state_src,
                                 int64_t row_stride, const int32_t* plane_index, int64_t plane_stride,
@@ -63,15 +77,16 @@ extern "C" int hz_mlp_recurrent(const hz_mlp_header_t* H, const hz_mlp_job_t* jo
   int dev = 0;
   HZ_HIP(hipGetDevice(&dev));
   HZ_REQUIRE(dev >= 0 && dev < 64, "hz_mlp_recurrent: device ordinal %d outside [0, 64)", dev);
-#define HZ_LAUNCH_EL(EL, RT, NW, NT)                                                                                 \
+#define HZ_LAUNCH_EL(EL, RT, NW, NT) HZ_LAUNCH_K((k_mlp_recurrent<EL, RT, NW, NT>), NW)
+#define HZ_LAUNCH_EL16(EL, RT) HZ_LAUNCH_K((k_mlp_recurrent16<EL, RT>), 16)
+#define HZ_LAUNCH_K(KERNEL, NW)                                                                                 \
   do {                                                                                                               \
     static size_t configured[64];                                                                                    \
     if (lds_bytes > configured[dev]) {                                                                               \
-      HZ_HIP(hipFuncSetAttribute((const void*)k_mlp_recurrent<EL, RT, NW, NT>,                                       \
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                       \
+      HZ_HIP(hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));   \
       configured[dev] = lds_bytes;                                                                                   \
     }                                                                                                                \
-    hipLaunchKernelGGL((k_mlp_recurrent<EL, RT, NW, NT>), dim3(grid), dim3(64 * NW), lds_bytes, (hipStream_t)stream,  \
+    hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(64 * NW), lds_bytes, (hipStream_t)stream,                            \
                        *H, jobs, (const uint16_t*)wstream, biases, action_table, (const uint16_t*)state_src,         \
                        (long long)row_stride, plane_index, (long long)plane_stride, actions, (uint16_t*)hidden_out,  \
                        out_reward, out_value, out_policy, num_rows);                                                 \
@@ -87,12 +102,17 @@ extern "C" int hz_mlp_recurrent(const hz_mlp_header_t* H, const hz_mlp_job_t* jo
   } else if (H->num_waves == 8) {
     if (rows_per_wg == 16) HZ_LAUNCH(1, 8, 4);
     else HZ_LAUNCH(2, 8, 4);
+  } else if (H->dtype == HZ_F16) {
+    if (rows_per_wg == 16) HZ_LAUNCH_EL16(ElF16, 1);
+    else HZ_LAUNCH_EL16(ElF16, 2);
   } else {
-    if (rows_per_wg == 16) HZ_LAUNCH(1, 16, 2);
-    else HZ_LAUNCH(2, 16, 2);
+    if (rows_per_wg == 16) HZ_LAUNCH_EL16(ElBf16, 1);
+    else HZ_LAUNCH_EL16(ElBf16, 2);
   }
 #undef HZ_LAUNCH
 #undef HZ_LAUNCH_EL
+#undef HZ_LAUNCH_EL16
+#undef HZ_LAUNCH_K
   HZ_HIP(hipGetLastError());
   return 0;
 }

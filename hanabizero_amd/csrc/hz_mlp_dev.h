@@ -128,6 +128,55 @@ extern "C" int hz_mlp_profile_read_passes(unsigned long long* host) {
 #define HZ_RING_WIDE 4
 #endif
 
+// The bias of two 16-column tiles (32 consecutive floats at a wave-uniform address) as the start values of two accumulators:
+// lane L gets floats [4 (L >> 4), 4 (L >> 4) + 4) of each tile -- the four output columns its accumulator holds.  The 128 B
+// come through the SCALAR cache (s_load into fixed scalar registers) and are handed out by four EXEC-masked rounds of
+// moves, one per 16-lane row: no vector-memory instruction (a vector load of the same values would occupy the L1's return
+// path as long as a whole weight fragment does), and nothing the compiler would wait for with vmcnt.  All lanes active.
+__device__ __forceinline__ void hz_bias_start_values(const float* uniform_row, f32x4& t0, f32x4& t1) {
+  float a0, a1, a2, a3, b0, b1, b2, b3;
+  asm volatile(
+      "s_load_dwordx16 s[68:83], %[p], 0x0\n\ts_load_dwordx16 s[84:99], %[p], 0x40\n\ts_waitcnt lgkmcnt(0)\n\t"
+      "s_mov_b32 exec_hi, 0\n\ts_mov_b32 exec_lo, 0xffff\n\t"
+      "v_mov_b32 %[a0], s68\n\tv_mov_b32 %[a1], s69\n\tv_mov_b32 %[a2], s70\n\tv_mov_b32 %[a3], s71\n\t"
+      "v_mov_b32 %[b0], s84\n\tv_mov_b32 %[b1], s85\n\tv_mov_b32 %[b2], s86\n\tv_mov_b32 %[b3], s87\n\t"
+      "s_mov_b32 exec_lo, 0xffff0000\n\t"
+      "v_mov_b32 %[a0], s72\n\tv_mov_b32 %[a1], s73\n\tv_mov_b32 %[a2], s74\n\tv_mov_b32 %[a3], s75\n\t"
+      "v_mov_b32 %[b0], s88\n\tv_mov_b32 %[b1], s89\n\tv_mov_b32 %[b2], s90\n\tv_mov_b32 %[b3], s91\n\t"
+      "s_mov_b32 exec_lo, 0\n\ts_mov_b32 exec_hi, 0xffff\n\t"
+      "v_mov_b32 %[a0], s76\n\tv_mov_b32 %[a1], s77\n\tv_mov_b32 %[a2], s78\n\tv_mov_b32 %[a3], s79\n\t"
+      "v_mov_b32 %[b0], s92\n\tv_mov_b32 %[b1], s93\n\tv_mov_b32 %[b2], s94\n\tv_mov_b32 %[b3], s95\n\t"
+      "s_mov_b32 exec_hi, 0xffff0000\n\t"
+      "v_mov_b32 %[a0], s80\n\tv_mov_b32 %[a1], s81\n\tv_mov_b32 %[a2], s82\n\tv_mov_b32 %[a3], s83\n\t"
+      "v_mov_b32 %[b0], s96\n\tv_mov_b32 %[b1], s97\n\tv_mov_b32 %[b2], s98\n\tv_mov_b32 %[b3], s99\n\t"
+      "s_mov_b64 exec, -1"
+      : [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3), [b0] "=&v"(b0), [b1] "=&v"(b1), [b2] "=&v"(b2), [b3] "=&v"(b3)
+      : [p] "s"(uniform_row)
+      : "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85",
+        "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99");
+  t0 = (f32x4){a0, a1, a2, a3};
+  t1 = (f32x4){b0, b1, b2, b3};
+}
+
+// The weight ring of the hand-scheduled k-loop (16 waves x 2 tiles): 4 slots x 2 fragments of 16 B per lane in FIXED
+// registers v[96:127], which no compiler-generated instruction ever touches: kernels that inline that k-loop are compiled
+// with __attribute__((amdgpu_num_vgpr(HZ_ASMK_VGPRS))) -- the register allocator stays below v96 -- and every asm statement
+// that names ring registers lists them as clobbers, which is what makes the kernel descriptor ask for all 128.  Loads into
+// them stay in flight across compiler-generated code (epilogues, barriers, the next job's decode); had they been C++ values,
+// a register copy at a loop back-edge or a spill would have read them before the data arrived (both were observed).
+#define HZ_ASMK_VGPRS 96
+#define HZ_W00 "v[96:99]"
+#define HZ_W01 "v[100:103]"
+#define HZ_W10 "v[104:107]"
+#define HZ_W11 "v[108:111]"
+#define HZ_W20 "v[112:115]"
+#define HZ_W21 "v[116:119]"
+#define HZ_W30 "v[120:123]"
+#define HZ_W31 "v[124:127]"
+#define HZ_RING_CLOBBER                                                                                                  \
+  "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", \
+      "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127"
+
 // Issue priority of this wave for the next few k-steps.  The sequencer serves the oldest wave of a SIMD first, so with a
 // fixed priority wave w < 4 of a workgroup (the oldest on its SIMD) streams its share of a layer in half the time the
 // youngest needs and then idles at the layer's barrier while the stragglers finish on a memory pipe they cannot fill alone
@@ -213,31 +262,20 @@ __device__ __forceinline__ void mlp_body(
   // NT == 2 (the 16 x 2 shape of the persistent search kernel): the k-loop is hand-scheduled assembly (below) and its
   // loads are invisible to the compiler; the other shapes keep the compiler-scheduled loop.
   constexpr bool ASMK = NT == 2 && RING == 4;
-  v8 wf[RING][NT] = {};
+  v8 wf[ASMK ? 1 : RING][NT];                    // !ASMK: the ring as C++ values (ASMK: the fixed registers above)
   unsigned int voff = (unsigned int)lane * 16u;  // ASMK: byte offset of the next fragment this lane requests
   long long gstep = 0;                           // !ASMK: k-steps of this wave's stream consumed so far
 #define wp(k, t) (*reinterpret_cast<const v8*>(wbase + (long long)(k) * kss + ((t) * 1024u + (unsigned int)lane * 16u)))
+#define HZ_LD(WN0, WN1) \
+  "global_load_dwordx4 " WN0 ", %[voff], %[sa]\n\tglobal_load_dwordx4 " WN1 ", %[voff], %[sa] offset:1024\n\tv_add_u32 %[voff], %[kss], %[voff]\n\t"
   if constexpr (ASMK) {
     static_assert(!ASMK || PF == 3 || PF == 2, "ring of 4 k-steps");
     if constexpr (PF == 3)
-      asm volatile(
-          "global_load_dwordx4 %[w00], %[voff], %[sa]\n\tglobal_load_dwordx4 %[w01], %[voff], %[sa] offset:1024\n\t"
-          "v_add_u32 %[voff], %[kss], %[voff]\n\t"
-          "global_load_dwordx4 %[w10], %[voff], %[sa]\n\tglobal_load_dwordx4 %[w11], %[voff], %[sa] offset:1024\n\t"
-          "v_add_u32 %[voff], %[kss], %[voff]\n\t"
-          "global_load_dwordx4 %[w20], %[voff], %[sa]\n\tglobal_load_dwordx4 %[w21], %[voff], %[sa] offset:1024\n\t"
-          "v_add_u32 %[voff], %[kss], %[voff]"
-          : [w00] "=&v"(wf[0][0]), [w01] "=&v"(wf[0][1]), [w10] "=&v"(wf[1][0]), [w11] "=&v"(wf[1][1]),
-            [w20] "=&v"(wf[2][0]), [w21] "=&v"(wf[2][1]), [voff] "+v"(voff)
-          : [sa] "s"(wbase), [kss] "s"(kss));
+      asm volatile(HZ_LD(HZ_W00, HZ_W01) HZ_LD(HZ_W10, HZ_W11) HZ_LD(HZ_W20, HZ_W21)
+                   : [voff] "+v"(voff) : [sa] "s"(wbase), [kss] "s"(kss) : HZ_RING_CLOBBER);
     else
-      asm volatile(
-          "global_load_dwordx4 %[w00], %[voff], %[sa]\n\tglobal_load_dwordx4 %[w01], %[voff], %[sa] offset:1024\n\t"
-          "v_add_u32 %[voff], %[kss], %[voff]\n\t"
-          "global_load_dwordx4 %[w10], %[voff], %[sa]\n\tglobal_load_dwordx4 %[w11], %[voff], %[sa] offset:1024\n\t"
-          "v_add_u32 %[voff], %[kss], %[voff]"
-          : [w00] "=&v"(wf[0][0]), [w01] "=&v"(wf[0][1]), [w10] "=&v"(wf[1][0]), [w11] "=&v"(wf[1][1]), [voff] "+v"(voff)
-          : [sa] "s"(wbase), [kss] "s"(kss));
+      asm volatile(HZ_LD(HZ_W00, HZ_W01) HZ_LD(HZ_W10, HZ_W11)
+                   : [voff] "+v"(voff) : [sa] "s"(wbase), [kss] "s"(kss) : HZ_RING_CLOBBER);
   } else {
 #pragma unroll
     for (int d = 0; d < PF; ++d)
@@ -296,13 +334,7 @@ __device__ __forceinline__ void mlp_body(
 
   const unsigned long long p_staged = PROF_NOW();
   (void)p_staged;
-  for (int j = 0; j < H.n_jobs; ++j) {
-    // this lane's place in the MFMA fragments, derived afresh per job from an opaque copy of the lane index: kept across
-    // the jobs the derived LDS addresses are spilled at 128 registers per lane, and their reloads (scratch = vector
-    // memory) would drain the weight ring in front of every k-loop
-    int lane_j = lane;
-    asm volatile("" : "+v"(lane_j));
-    const int r0 = lane_j & 15, kq = (lane_j >> 4) * 8, c4 = 4 * (lane_j >> 4);
+  auto job_of = [&](int j) {
     const int jsel = j >> 3, jb = (j & 7) * 8;
     const int jr = jsel == 0 ? jv[0] : (jsel == 1 ? jv[1] : (jsel == 2 ? jv[2] : jv[3]));
     hz_mlp_job_t J;
@@ -312,22 +344,65 @@ __device__ __forceinline__ void mlp_body(
     J.res_off = __builtin_amdgcn_readlane(jr, jb + 3);
     J.bias_off = __builtin_amdgcn_readlane(jr, jb + 4);
     J.flags = __builtin_amdgcn_readlane(jr, jb + 5);
-    // The accumulators start from the epilogue's additive term -- bias (+ the action's column of the first dynamics layer):
-    // one row of the action table per batch row (row num_actions = the bias alone) -- requested first and BEFORE the layer
-    // barrier: it depends on nothing the other waves produce.  Loads under no branch on the job's flags: every job takes them.
+    return J;
+  };
+  // The accumulators start from the epilogue's additive term -- bias (+ the action's column of the first dynamics layer): one
+  // row of the action table per batch row (row num_actions = the bias alone); the MFMAs add the products on top.
+  // The bias row is the same for every batch row, so a lane needs 4 of each tile's 16 values, chosen by its column quad:
+  // hz_bias_start_values (scalar cache + EXEC-masked moves; ASMK shapes) -- vector loads of them occupied the L1's 64 B/clk
+  // return path as long as whole weight fragments do (measured: 4 % of the inference at 16 rows per workgroup, 9 % at 32).
+  // Only the action-row job (the first dynamics layer) loads per-lane rows.
+  hz_mlp_job_t J = job_of(0);
+  for (int j = 0; j < H.n_jobs; ++j) {
+    // this lane's place in the MFMA fragments, derived afresh per job from an opaque copy of the lane index: kept across
+    // the jobs the derived LDS addresses are spilled at 128 registers per lane, and their reloads (scratch = vector
+    // memory) would drain the weight ring in front of every k-loop
+    int lane_j = lane;
+    asm volatile("" : "+v"(lane_j));
+    const int r0 = lane_j & 15, kq = (lane_j >> 4) * 8, c4 = 4 * (lane_j >> 4);
+    if (j > 0) J = job_of(j);
     f32x4 acc[NT][RT];
     if (J.ks != 0) {
+#ifdef HZ_MLP_X_NOAV  // experiment (tools/mlp_variants.py): what the start values cost; results are garbage
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-          const int arow = (J.flags & HZ_MLP_ACTION_ROW) ? act[rt] : H.num_actions;
-          const float* p = act_tab + (size_t)arow * H.action_table_stride + J.bias_off + 16 * t + c4;
-          if constexpr (ASMK)  // (hidden from the compiler like the weight stream: it must not wait for them with vmcnt(0))
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(acc[t][rt]) : "v"(p));
+        for (int rt = 0; rt < RT; ++rt) acc[t][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#else
+      if (J.flags & HZ_MLP_ACTION_ROW) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) {
+            const float* p = act_tab + (size_t)act[rt] * H.action_table_stride + J.bias_off + 16 * t + c4;
+            if constexpr (ASMK)  // (a load the compiler knows of inside this loop makes it wait with vmcnt(0) -- for the weight ring
+              asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(acc[t][rt]) : "v"(p));  //  too -- at EVERY job's start)
+            else
+              acc[t][rt] = *reinterpret_cast<const f32x4*>(p);
+          }
+        if constexpr (ASMK) {  // ... so this one job waits for its rows itself (it is the first: nothing else is in flight yet)
+          if constexpr (RT == 1)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(acc[0][0]), "+v"(acc[1][0]));
           else
-            acc[t][rt] = *reinterpret_cast<const f32x4*>(p);
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
         }
+      } else {
+        const float* brow = act_tab + (size_t)H.num_actions * H.action_table_stride + J.bias_off;  // wave-uniform
+        if constexpr (NT == 2) {
+          f32x4 sv[2];
+          hz_bias_start_values(brow, sv[0], sv[1]);
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) acc[t][rt] = sv[t];
+        } else {
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) acc[t][rt] = *reinterpret_cast<const f32x4*>(brow + 16 * t + c4);
+        }
+      }
+#endif
     }
     const unsigned long long p_j0 = PROF_NOW();
     if (J.flags & HZ_MLP_BARRIER) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // LDS only: loads stay in flight
@@ -358,87 +433,80 @@ __device__ __forceinline__ void mlp_body(
       // 2 PF loads / the younger reads may remain), issue its MFMAs.  Blocks of 4 k-steps (ring positions are static),
       // J.ks / 4 of them; the last block requests no activation fragments past the K range; the weight requests run on
       // into the next job's first k-steps (the streams are contiguous) -- or into the zero padding behind the stream.
-      // What the compiler must not see move: every register below is an operand of this statement and of no compiler-
-      // generated copy (checked in the build: no spills, __graft_entry__.build()).
+      // The ring lives in the fixed registers v[96:127] (see HZ_W00 ..): in flight across everything the compiler generates.
       unsigned int cnt = (unsigned int)J.ks >> 2;
       unsigned int la0 = (unsigned int)(uintptr_t)(__attribute__((address_space(3))) const uint16_t*)src;
-      const unsigned int prio = (unsigned int)((wave >> 2) + j) & 3u;  // issue priority rotates over the workgroup's four age groups
-      if (RT == 1) hz_rotate_prio((int)prio);
+      if (RT == 1) hz_rotate_prio((wave >> 2) + j);  // issue priority rotates over the workgroup's four age groups, job by job
       if constexpr (RT == 1) {
+        // one row tile: weights 3 k-steps ahead (4 ring slots), activation fragments 3 k-steps ahead in 4 slots
         v8 b0, b1, b2, b3;
-#define HZ_K1(W0, W1, WN0, WN1, B, BN, BOFF, LGKM)                                                             \
-  "global_load_dwordx4 %[" WN0 "], %[voff], %[sa]\n\tglobal_load_dwordx4 %[" WN1 "], %[voff], %[sa] offset:1024\n\t" \
-  "v_add_u32 %[voff], %[kss], %[voff]\n\t" BN "s_waitcnt vmcnt(6) lgkmcnt(" LGKM ")\n\t"                        \
-  "v_mfma_f32_16x16x32_" HZ_EL_ASM " %[a0], %[" W0 "], %[" B "], %[a0]\n\t"                                      \
-  "v_mfma_f32_16x16x32_" HZ_EL_ASM " %[a1], %[" W1 "], %[" B "], %[a1]\n\t"
-#define HZ_K1_BODY(EL_ASM)                                                                                      \
+#define HZ_RD1(B, OFF) "ds_read_b128 %[" B "], %[la0] offset:" #OFF "\n\t"
+#define HZ_K1(W0, W1, WN0, WN1, B, RD, LGKM)                                               \
+  HZ_LD(WN0, WN1) RD "s_waitcnt vmcnt(6) lgkmcnt(" LGKM ")\n\t"                            \
+  "v_mfma_f32_16x16x32_" HZ_EL_ASM " %[a0], " W0 ", %[" B "], %[a0]\n\t"                   \
+  "v_mfma_f32_16x16x32_" HZ_EL_ASM " %[a1], " W1 ", %[" B "], %[a1]\n\t"
+#define HZ_K1_BODY()                                                                                            \
         asm volatile(                                                                                           \
-            "ds_read_b128 %[b0], %[la0]\n\tds_read_b128 %[b1], %[la0] offset:64\n\tds_read_b128 %[b2], %[la0] offset:128\n\t" \
-            "s_waitcnt vmcnt(0)\n"                                                                              \
+            HZ_RD1("b0", 0) HZ_RD1("b1", 64) HZ_RD1("b2", 128)                                                    \
             "1:\n\t"                                                                                            \
-            HZ_K1("w00", "w01", "w30", "w31", "b0", "ds_read_b128 %[b3], %[la0] offset:192\n\t", 192, "3")        \
-            HZ_K1("w10", "w11", "w00", "w01", "b1", "ds_read_b128 %[b0], %[la0] offset:256\n\t", 256, "3")        \
-            HZ_K1("w20", "w21", "w10", "w11", "b2", "ds_read_b128 %[b1], %[la0] offset:320\n\t", 320, "3")        \
-            HZ_K1("w30", "w31", "w20", "w21", "b3", "ds_read_b128 %[b2], %[la0] offset:384\n\t", 384, "3")        \
+            HZ_K1(HZ_W00, HZ_W01, HZ_W30, HZ_W31, "b0", HZ_RD1("b3", 192), "3")                                    \
+            HZ_K1(HZ_W10, HZ_W11, HZ_W00, HZ_W01, "b1", HZ_RD1("b0", 256), "3")                                    \
+            HZ_K1(HZ_W20, HZ_W21, HZ_W10, HZ_W11, "b2", HZ_RD1("b1", 320), "3")                                    \
+            HZ_K1(HZ_W30, HZ_W31, HZ_W20, HZ_W21, "b3", HZ_RD1("b2", 384), "3")                                    \
             "v_add_u32 %[la0], 0x100, %[la0]\n\t"                                                                \
             "s_sub_u32 %[cnt], %[cnt], 1\n\ts_cmp_lg_u32 %[cnt], 1\n\ts_cbranch_scc1 1b\n\t"                     \
-            HZ_K1("w00", "w01", "w30", "w31", "b0", "ds_read_b128 %[b3], %[la0] offset:192\n\t", 192, "3")        \
-            HZ_K1("w10", "w11", "w00", "w01", "b1", "", 0, "2")                                                   \
-            HZ_K1("w20", "w21", "w10", "w11", "b2", "", 0, "1")                                                   \
-            HZ_K1("w30", "w31", "w20", "w21", "b3", "", 0, "0")                                                   \
+            HZ_K1(HZ_W00, HZ_W01, HZ_W30, HZ_W31, "b0", HZ_RD1("b3", 192), "3")                                    \
+            HZ_K1(HZ_W10, HZ_W11, HZ_W00, HZ_W01, "b1", "", "2")                                                   \
+            HZ_K1(HZ_W20, HZ_W21, HZ_W10, HZ_W11, "b2", "", "1")                                                   \
+            HZ_K1(HZ_W30, HZ_W31, HZ_W20, HZ_W21, "b3", "", "0")                                                   \
             "s_nop 7\n\ts_nop 7\n\ts_nop 7"                                                                      \
-            : [w00] "+v"(wf[0][0]), [w01] "+v"(wf[0][1]), [w10] "+v"(wf[1][0]), [w11] "+v"(wf[1][1]),              \
-              [w20] "+v"(wf[2][0]), [w21] "+v"(wf[2][1]), [w30] "+v"(wf[3][0]), [w31] "+v"(wf[3][1]),              \
-              [b0] "=&v"(b0), [b1] "=&v"(b1), [b2] "=&v"(b2), [b3] "=&v"(b3), [a0] "+v"(acc[0][0]), [a1] "+v"(acc[1][0]), \
+            : [b0] "=&v"(b0), [b1] "=&v"(b1), [b2] "=&v"(b2), [b3] "=&v"(b3), [a0] "+v"(acc[0][0]), [a1] "+v"(acc[1][0]), \
               [voff] "+v"(voff), [la0] "+v"(la0), [cnt] "+s"(cnt)                                                  \
             : [sa] "s"(wbase), [kss] "s"(kss)                                                                     \
-            : "memory", "scc")
+            : "memory", "scc", HZ_RING_CLOBBER)
         if constexpr (EL::code == HZ_BF16) {
 #define HZ_EL_ASM "bf16"
-          HZ_K1_BODY(bf16);
+          HZ_K1_BODY();
 #undef HZ_EL_ASM
         } else {
 #define HZ_EL_ASM "f16"
-          HZ_K1_BODY(f16);
+          HZ_K1_BODY();
 #undef HZ_EL_ASM
         }
 #undef HZ_K1_BODY
 #undef HZ_K1
+#undef HZ_RD1
       } else {
-        // two row tiles: PF = 2 (one ring slot spare), activation fragments one k-step ahead in two slots per row tile
+        // two row tiles: weights 2 k-steps ahead (one ring slot spare), activation fragments one k-step ahead in two slots per row tile
         v8 b00, b01, b10, b11;
         unsigned int la1 = la0 + (unsigned int)(16 * rs * 2);
-#define HZ_K2(W0, W1, WN0, WN1, B0, B1, BN, VM, LGKM)                                                           \
-  "global_load_dwordx4 %[" WN0 "], %[voff], %[sa]\n\tglobal_load_dwordx4 %[" WN1 "], %[voff], %[sa] offset:1024\n\t" \
-  "v_add_u32 %[voff], %[kss], %[voff]\n\t" BN "s_waitcnt vmcnt(" VM ") lgkmcnt(" LGKM ")\n\t"                    \
-  "v_mfma_f32_16x16x32_" HZ_EL_ASM " %[a00], %[" W0 "], %[" B0 "], %[a00]\n\t"                                   \
-  "v_mfma_f32_16x16x32_" HZ_EL_ASM " %[a01], %[" W0 "], %[" B1 "], %[a01]\n\t"                                   \
-  "v_mfma_f32_16x16x32_" HZ_EL_ASM " %[a10], %[" W1 "], %[" B0 "], %[a10]\n\t"                                   \
-  "v_mfma_f32_16x16x32_" HZ_EL_ASM " %[a11], %[" W1 "], %[" B1 "], %[a11]\n\t"
 #define HZ_RD2(B0, B1, OFF) "ds_read_b128 %[" B0 "], %[la0] offset:" #OFF "\n\tds_read_b128 %[" B1 "], %[la1] offset:" #OFF "\n\t"
+#define HZ_K2(W0, W1, WN0, WN1, B0, B1, RD, LGKM)                                             \
+  HZ_LD(WN0, WN1) RD "s_waitcnt vmcnt(4) lgkmcnt(" LGKM ")\n\t"                               \
+  "v_mfma_f32_16x16x32_" HZ_EL_ASM " %[a00], " W0 ", %[" B0 "], %[a00]\n\t"                   \
+  "v_mfma_f32_16x16x32_" HZ_EL_ASM " %[a01], " W0 ", %[" B1 "], %[a01]\n\t"                   \
+  "v_mfma_f32_16x16x32_" HZ_EL_ASM " %[a10], " W1 ", %[" B0 "], %[a10]\n\t"                   \
+  "v_mfma_f32_16x16x32_" HZ_EL_ASM " %[a11], " W1 ", %[" B1 "], %[a11]\n\t"
 #define HZ_K2_BODY()                                                                                            \
         asm volatile(                                                                                           \
             HZ_RD2("b00", "b01", 0)                                                                               \
-            "s_waitcnt vmcnt(0)\n"                                                                              \
             "1:\n\t"                                                                                            \
-            HZ_K2("w00", "w01", "w20", "w21", "b00", "b01", HZ_RD2("b10", "b11", 64), "4", "2")                    \
-            HZ_K2("w10", "w11", "w30", "w31", "b10", "b11", HZ_RD2("b00", "b01", 128), "4", "2")                   \
-            HZ_K2("w20", "w21", "w00", "w01", "b00", "b01", HZ_RD2("b10", "b11", 192), "4", "2")                   \
-            HZ_K2("w30", "w31", "w10", "w11", "b10", "b11", HZ_RD2("b00", "b01", 256), "4", "2")                   \
+            HZ_K2(HZ_W00, HZ_W01, HZ_W20, HZ_W21, "b00", "b01", HZ_RD2("b10", "b11", 64), "2")                     \
+            HZ_K2(HZ_W10, HZ_W11, HZ_W30, HZ_W31, "b10", "b11", HZ_RD2("b00", "b01", 128), "2")                    \
+            HZ_K2(HZ_W20, HZ_W21, HZ_W00, HZ_W01, "b00", "b01", HZ_RD2("b10", "b11", 192), "2")                    \
+            HZ_K2(HZ_W30, HZ_W31, HZ_W10, HZ_W11, "b10", "b11", HZ_RD2("b00", "b01", 256), "2")                    \
             "v_add_u32 %[la0], 0x100, %[la0]\n\tv_add_u32 %[la1], 0x100, %[la1]\n\t"                              \
             "s_sub_u32 %[cnt], %[cnt], 1\n\ts_cmp_lg_u32 %[cnt], 1\n\ts_cbranch_scc1 1b\n\t"                     \
-            HZ_K2("w00", "w01", "w20", "w21", "b00", "b01", HZ_RD2("b10", "b11", 64), "4", "2")                    \
-            HZ_K2("w10", "w11", "w30", "w31", "b10", "b11", HZ_RD2("b00", "b01", 128), "4", "2")                   \
-            HZ_K2("w20", "w21", "w00", "w01", "b00", "b01", HZ_RD2("b10", "b11", 192), "4", "2")                   \
-            HZ_K2("w30", "w31", "w10", "w11", "b10", "b11", "", "4", "0")                                          \
+            HZ_K2(HZ_W00, HZ_W01, HZ_W20, HZ_W21, "b00", "b01", HZ_RD2("b10", "b11", 64), "2")                     \
+            HZ_K2(HZ_W10, HZ_W11, HZ_W30, HZ_W31, "b10", "b11", HZ_RD2("b00", "b01", 128), "2")                    \
+            HZ_K2(HZ_W20, HZ_W21, HZ_W00, HZ_W01, "b00", "b01", HZ_RD2("b10", "b11", 192), "2")                    \
+            HZ_K2(HZ_W30, HZ_W31, HZ_W10, HZ_W11, "b10", "b11", "", "0")                                           \
             "s_nop 7\n\ts_nop 7\n\ts_nop 7"                                                                      \
-            : [w00] "+v"(wf[0][0]), [w01] "+v"(wf[0][1]), [w10] "+v"(wf[1][0]), [w11] "+v"(wf[1][1]),              \
-              [w20] "+v"(wf[2][0]), [w21] "+v"(wf[2][1]), [w30] "+v"(wf[3][0]), [w31] "+v"(wf[3][1]),              \
-              [b00] "=&v"(b00), [b01] "=&v"(b01), [b10] "=&v"(b10), [b11] "=&v"(b11),                              \
+            : [b00] "=&v"(b00), [b01] "=&v"(b01), [b10] "=&v"(b10), [b11] "=&v"(b11),                              \
               [a00] "+v"(acc[0][0]), [a01] "+v"(acc[0][1]), [a10] "+v"(acc[1][0]), [a11] "+v"(acc[1][1]),          \
               [voff] "+v"(voff), [la0] "+v"(la0), [la1] "+v"(la1), [cnt] "+s"(cnt)                                 \
             : [sa] "s"(wbase), [kss] "s"(kss)                                                                     \
-            : "memory", "scc")
+            : "memory", "scc", HZ_RING_CLOBBER)
         if constexpr (EL::code == HZ_BF16) {
 #define HZ_EL_ASM "bf16"
           HZ_K2_BODY();
@@ -449,8 +517,8 @@ __device__ __forceinline__ void mlp_body(
 #undef HZ_EL_ASM
         }
 #undef HZ_K2_BODY
-#undef HZ_RD2
 #undef HZ_K2
+#undef HZ_RD2
       }
     } else {
       // ---- the compiler-scheduled k-loop of the other shapes
@@ -559,9 +627,8 @@ __device__ __forceinline__ void mlp_body(
     PROF_ADD(p_epi, p_j3);
   }
   if constexpr (ASMK)  // the last requests ran into the padding behind the stream: nobody waits for them, so wait here
-    asm volatile("s_waitcnt vmcnt(0)"
-                 : "+v"(wf[0][0]), "+v"(wf[0][1]), "+v"(wf[1][0]), "+v"(wf[1][1]), "+v"(wf[2][0]), "+v"(wf[2][1]),
-                   "+v"(wf[3][0]), "+v"(wf[3][1]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory", HZ_RING_CLOBBER);
+#undef HZ_LD
 #undef wp
   const unsigned long long p_jobs_done = PROF_NOW();
   (void)p_jobs_done;

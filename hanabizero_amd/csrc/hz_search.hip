@@ -151,8 +151,9 @@ extern "C" int hz_search_profile_read(unsigned long long* host) {
 // RT = 16-row tiles per workgroup: 1 = one tree per wave (a workgroup per CU covers 4096 trees on 256 CUs); 2 = two trees
 // per wave, taken one after the other in the tree phases, and 32 rows per weight fragment in the inference -- for more
 // trees than 16 x #CUs, where the workgroups would otherwise queue and stream the weights once per 16 rows.
+// (amdgpu_num_vgpr: the compiler's registers end below the weight ring of the hand-scheduled k-loop, hz_mlp_dev.h)
 template <class EL, int RT>
-__global__ __launch_bounds__(1024, 1) void k_search(TreeView tv, hz_mlp_header_t H, SearchArgs a) {
+__global__ __launch_bounds__(1024, 1) __attribute__((amdgpu_num_vgpr(HZ_ASMK_VGPRS))) void k_search(TreeView tv, hz_mlp_header_t H, SearchArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
   constexpr int MT = 16 * RT;
   const int lane = threadIdx.x & 63;
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(1024, 1) void k_search(TreeView tv, hz_mlp_header_t
 // 32 trees per workgroup, the two trees of a wave side by side in its two 32-lane halves (hz_tree_half_dev.h; A <= 32,
 // hidden <= 512): the tree phase of a simulation costs one tree's instruction stream, not two.
 template <class EL>
-__global__ __launch_bounds__(1024, 1) void k_search_half(TreeView tv, hz_mlp_header_t H, SearchArgs a) {
+__global__ __launch_bounds__(1024, 1) __attribute__((amdgpu_num_vgpr(HZ_ASMK_VGPRS))) void k_search_half(TreeView tv, hz_mlp_header_t H, SearchArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
   constexpr int MT = 32;
   const int lane = threadIdx.x & 63;

@@ -13,9 +13,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 STRIP = ["-DHZ_MLP_X_NOEPI", "-DHZ_MLP_X_NOFINAL", "-DHZ_MLP_X_NOSTAGE"]
 RING8 = ["-DHZ_RING_WIDE=8"]  # (only workgroups of <= 8 waves have the registers for it: no effect on 16 x 2)
-VARIANTS = [("baseline", []), ("no epilogues", ["-DHZ_MLP_X_NOEPI"]), ("no epi/final/staging", STRIP),
-            ("ring 8", RING8), ("ring 8, no epilogues", RING8 + ["-DHZ_MLP_X_NOEPI"]), ("ring 8, no epi/final/staging", RING8 + STRIP)]
-SHAPES = [(8, 4), (16, 2)]
+NOAV = ["-DHZ_MLP_X_NOAV"]
+VARIANTS = [("baseline", []), ("no acc start loads", NOAV), ("no epilogues", ["-DHZ_MLP_X_NOEPI"]),
+            ("no acc start loads, no epilogues", NOAV + ["-DHZ_MLP_X_NOEPI"]), ("no acc start / epi / final / staging", NOAV + STRIP)]
+SHAPES = [(16, 2), (8, 4)]
 
 
 def main():
