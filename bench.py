@@ -469,7 +469,7 @@ def main():
     ap.add_argument("--actors-per-gpu", type=int, default=1,
                     help="split this GPU's envs over this many concurrent actors (own hipGraph + stream each)")
     ap.add_argument("--branch-graph", action="store_true", help="with --actors-per-gpu > 1: one hipGraph with a branch per actor")
-    ap.add_argument("--rows-per-workgroup", type=int, default=0, choices=[0, 16, 32, -32], help="force a shape of the search kernel")
+    ap.add_argument("--rows-per-workgroup", type=int, default=0, choices=[0, 16, -16, 32, -32], help="force a shape of the search kernel (include/hz_search.h)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the extra configurations measured after the primary run")
@@ -588,7 +588,7 @@ def main():
             # once per simulation
             t = search["mean_s"]
             fl = flops * (S - 1)
-            rows_wg = 16 if (actor.mcts.rows_per_workgroup == 16 or (actor.mcts.rows_per_workgroup == 0 and (Nk + 15) // 16 <= torch.cuda.get_device_properties(device).multi_processor_count)) else 32
+            rows_wg = 16 if (abs(actor.mcts.rows_per_workgroup) == 16 or (actor.mcts.rows_per_workgroup == 0 and (Nk + 15) // 16 <= torch.cuda.get_device_properties(device).multi_processor_count)) else 32
             wgs = (Nk + rows_wg - 1) // rows_wg
             l2_bytes = wgs * engine.fused.weight_bytes_per_wg * (S - 1) + 2 * Nk * H * e * (S - 1)
             out["roofline"] = {"bound": "mfma", "kernel": "k_search", "achieved": fl / t / 1e12, "peak": MFMA_PEAK_TFLOPS,

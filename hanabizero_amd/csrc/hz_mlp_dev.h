@@ -315,12 +315,12 @@ __device__ __forceinline__ void mlp_body(
         if (lane + 64 * u < chunks)
           *reinterpret_cast<uint4*>(lds + (size_t)(16 * rt + wave) * rs + H.state_off + (lane + 64 * u) * 8) = row_frag[rt].v[u];
   }
-  if (STAGE == STAGE_REGS_HALF) {  // wave w holds row w in lanes 0-31 and row 16 + w in lanes 32-63: lane l of a half
-    static_assert(STAGE != STAGE_REGS_HALF || (NW == 16 && RT == 2), "two rows per wave");  // its chunks l and 32 + l
-    const int hl = lane & 31, hrow = 16 * (lane >> 5) + wave;
+  if (STAGE == STAGE_REGS_HALF) {  // the first 8 RT waves hold two rows each: wave w row w in lanes 0-31 and row 8 RT + w in
+    static_assert(STAGE != STAGE_REGS_HALF || NW == 16, "two rows per tree-owning wave");  // lanes 32-63; lane l of a half its chunks l, 32 + l
+    const int hl = lane & 31, hrow = 8 * RT * (lane >> 5) + wave;
 #pragma unroll
     for (int u = 0; u < 2; ++u)
-      if (hl + 32 * u < chunks)
+      if (wave < 8 * RT && hl + 32 * u < chunks)
         *reinterpret_cast<uint4*>(lds + (size_t)hrow * rs + H.state_off + (hl + 32 * u) * 8) = row_frag[0].v[u];
   }
   __syncthreads();

@@ -217,12 +217,15 @@ __global__ __launch_bounds__(1024, 1) __attribute__((amdgpu_num_vgpr(HZ_ASMK_VGP
 #endif
 }
 
-// 32 trees per workgroup, the two trees of a wave side by side in its two 32-lane halves (hz_tree_half_dev.h; A <= 32,
-// hidden <= 512): the tree phase of a simulation costs one tree's instruction stream, not two.
-template <class EL>
+// Two trees per tree-owning wave, side by side in its two 32-lane halves (hz_tree_half_dev.h; A <= 32, hidden <= 512): the tree
+// phase of two trees costs one instruction stream.  TW = tree-owning waves: 16 -> 32 trees per workgroup (two 16-row tiles in
+// the inference); 8 -> 16 trees per workgroup, waves 8-15 sit the tree phase out -- the tree phase is bound by instruction
+// issue (the youngest of a SIMD's four waves takes twice as long as the oldest through the same work), so two streams per SIMD
+// instead of four take about half the time.
+template <class EL, int TW>
 __global__ __launch_bounds__(1024, 1) __attribute__((amdgpu_num_vgpr(HZ_ASMK_VGPRS))) void k_search_half(TreeView tv, hz_mlp_header_t H, SearchArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
-  constexpr int MT = 32;
+  constexpr int MT = 2 * TW;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int row0 = blockIdx.x * MT;
@@ -250,9 +253,9 @@ __global__ __launch_bounds__(1024, 1) __attribute__((amdgpu_num_vgpr(HZ_ASMK_VGP
 #define HZ_HALF_SETUP(LANE)                                                              \
   {                                                                                       \
     q.l = (LANE) & 31; q.h = (LANE) >> 5; q.hbase = 32 * q.h;                            \
-    const int srow = 16 * q.h + wave;                                                     \
+    const int srow = TW * q.h + (wave < TW ? wave : 0);                                   \
     t.tree = row0 + srow;                                                                 \
-    t.mine = t.tree < tv.N;                                                               \
+    t.mine = t.tree < tv.N && wave < TW;                                                  \
     t.path = L.path_s + srow * (tv.S + 1);                                                \
     t.prec = L.prec_s + srow * (tv.S + 1);                                                \
     t.lq = L.lds_q + srow * tv.S;                                                         \
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(1024, 1) __attribute__((amdgpu_num_vgpr(HZ_ASMK_VGP
   HZ_HALF_SETUP(lane)
   t.root_vsum = 0.0f; t.root_visit = 0; t.path_len = 1;
   t.leaf_reward = t.leaf_value = t.leaf_logit = 0.0f;
-  const bool any_mine = row0 + wave < tv.N;  // (rows are filled in order: the lower half's tree exists if any does)
+  const bool any_mine = wave < TW && row0 + wave < tv.N;  // (rows are filled in order: the lower half's tree exists if any does)
   if (any_mine) {
     if (t.mine) {
       t.root_visit = tv.root_visit[t.tree];
@@ -269,7 +272,7 @@ __global__ __launch_bounds__(1024, 1) __attribute__((amdgpu_num_vgpr(HZ_ASMK_VGP
       mx = tv.mm_max[t.tree];
       if (q.l < tv.A) root_row = tv.rec[(size_t)t.tree * tv.S * tv.A + q.l];
     }
-    const int entry = traverse_half(tv, q, t, 0, mn, mx, root_row, tab_s, L.act_s + 16 * q.h + wave, a.ix, a.iy,
+    const int entry = traverse_half(tv, q, t, 0, mn, mx, root_row, tab_s, L.act_s + TW * q.h + wave, a.ix, a.iy,
                                     a.sims == 1);
     if (t.mine) {
       const uint4* src = reinterpret_cast<const uint4*>(a.pool + ((size_t)entry * tv.N + t.tree) * (size_t)H.hidden);
@@ -282,7 +285,7 @@ __global__ __launch_bounds__(1024, 1) __attribute__((amdgpu_num_vgpr(HZ_ASMK_VGP
   unsigned long long t0 = SP_NOW();
   for (int sim = 0; sim < a.sims; ++sim) {
     const unsigned long long t2 = SP_NOW();
-    mlp_body<EL, 2, 16, 2, STAGE_REGS_HALF, false>(H, a.jobs, a.wstream, a.bias, a.act_tab, a.pool, a.row_stride, nullptr,
+    mlp_body<EL, TW / 8, 16, 2, STAGE_REGS_HALF, false>(H, a.jobs, a.wstream, a.bias, a.act_tab, a.pool, a.row_stride, nullptr,
                                                a.plane_stride, L.act_s - row0, a.pool + (size_t)(sim + 1) * a.plane_stride,
                                                nullptr, nullptr, nullptr, tv.N, L.image, row0, &rows);
     const unsigned long long t3 = SP_NOW();
@@ -297,7 +300,7 @@ __global__ __launch_bounds__(1024, 1) __attribute__((amdgpu_num_vgpr(HZ_ASMK_VGP
     const bool more = sim + 1 < a.sims;
     {  // the leaf's heads, from the row image into registers: each half's 32 lanes turn first its reward logits, then its
       // value logits into scalars (uniform within the half); lane l takes policy logit l
-      const uint16_t* row = L.image + (size_t)(16 * q.h + wave) * H.row_stride;
+      const uint16_t* row = L.image + (size_t)(TW * q.h + wave) * H.row_stride;
       t.leaf_reward = row32_support_to_scalar<EL>(row + H.off_reward, H.support_size, H.support_min, q.l);
       t.leaf_value = row32_support_to_scalar<EL>(row + H.off_value, H.support_size, H.support_min, q.l);
       float pl = 0.0f;
@@ -314,7 +317,7 @@ __global__ __launch_bounds__(1024, 1) __attribute__((amdgpu_num_vgpr(HZ_ASMK_VGP
     rows.v[0] = rows.v[1] = make_uint4(0u, 0u, 0u, 0u);
     if (more) {
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-      const int entry = traverse_half(tv, q, t, sim + 1, mn, mx, root_row, tab_s, L.act_s + 16 * q.h + wave, a.ix,
+      const int entry = traverse_half(tv, q, t, sim + 1, mn, mx, root_row, tab_s, L.act_s + TW * q.h + wave, a.ix,
                                       a.iy, sim + 2 == a.sims);
       if (t.mine) {
         const uint4* src = reinterpret_cast<const uint4*>(a.pool + ((size_t)entry * tv.N + t.tree) * (size_t)H.hidden);
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(1024, 1) __attribute__((amdgpu_num_vgpr(HZ_ASMK_VGP
   }
 #undef HZ_HALF_SETUP
 #ifdef HZ_SEARCH_PROFILE
-  if (blockIdx.x == 50 && lane == 0) {
+  if (blockIdx.x == 800 / MT && lane == 0) {
     unsigned long long* o = hz_search_prof + wave * 4;
     o[0] = p_tree + (SP_NOW() - t0); o[1] = 0; o[2] = p_mlp; o[3] = p_wait2;
   }
@@ -336,7 +339,7 @@ __global__ __launch_bounds__(1024, 1) __attribute__((amdgpu_num_vgpr(HZ_ASMK_VGP
 // unit count and, per kernel variant, the dynamic-LDS limit already raised with hipFuncSetAttribute (a per-device attribute).
 struct SearchDevice {
   int n_cu;
-  size_t configured[6];
+  size_t configured[8];
 };
 static SearchDevice g_search_dev[64];
 
@@ -352,8 +355,9 @@ extern "C" int hz_search_run(hz_tree_t* t, int num_simulations, const hz_mlp_hea
   HZ_REQUIRE(num_simulations >= 1 && num_simulations < t->S,
              "hz_search_run: num_simulations=%d outside [1, tree capacity %d)", num_simulations, t->S);
   HZ_REQUIRE(t->next_entry == 1, "hz_search_run: the tree must be freshly prepared (hz_tree_prepare)");
-  HZ_REQUIRE(rows_per_workgroup == 0 || rows_per_workgroup == 16 || rows_per_workgroup == 32 || rows_per_workgroup == -32,
-             "hz_search_run: rows_per_workgroup %d (0 = auto, 16, 32, or -32 = 32 with the trees of a wave one after the other)",
+  HZ_REQUIRE(rows_per_workgroup == 0 || rows_per_workgroup == 16 || rows_per_workgroup == 32 || rows_per_workgroup == -32 ||
+                 rows_per_workgroup == -16,
+             "hz_search_run: rows_per_workgroup %d (0 = auto, 16, 32; -16: 16 with two trees side by side on 8 waves; -32: 32 with the two trees of a wave one after the other)",
              rows_per_workgroup);
   HZ_REQUIRE(H->dtype == HZ_BF16 || H->dtype == HZ_F16, "hz_search_run: header dtype must be HZ_BF16 or HZ_F16 (got %d)", H->dtype);
   HZ_REQUIRE(H->num_waves == 16 && H->tiles_per_wave == 2, "hz_search_run: the MLP must be laid out for 16 waves x 2 tiles");
@@ -386,7 +390,10 @@ extern "C" int hz_search_run(hz_tree_t* t, int num_simulations, const hz_mlp_hea
   if (rows_wg == 32 && lds_for(32) > 160 * 1024 && rows_per_workgroup == 0) rows_wg = 16;
   const size_t lds_bytes = lds_for(rows_wg);
   HZ_REQUIRE(lds_bytes <= 160 * 1024, "hz_search_run: %zu B of LDS per workgroup exceed 160 KiB", lds_bytes);
-  const bool halves = rows_wg == 32 && rows_per_workgroup != -32 && t->A <= 32 && H->hidden <= 512;
+  // two trees per tree-owning wave, side by side: the default with 32 trees per workgroup; with 16 only on request (-16) --
+  // measured at 4096 envs: +1.4 % moves/s with random-init nets (mean path 2.2 edges), -12 % with a sharp policy (5.3 edges: a
+  // half that has reached its leaf idles through the other's remaining levels)
+  const bool halves = ((rows_wg == 32 && rows_per_workgroup != -32) || rows_per_workgroup == -16) && t->A <= 32 && H->hidden <= 512;
   SearchArgs a;
   a.jobs = jobs; a.wstream = (const uint16_t*)wstream; a.bias = biases; a.act_tab = action_table;
   a.pool = (uint16_t*)pool; a.plane_stride = plane_stride; a.row_stride = row_stride;
@@ -399,16 +406,17 @@ extern "C" int hz_search_run(hz_tree_t* t, int num_simulations, const hz_mlp_hea
     }                                                                                                                 \
     hipLaunchKernelGGL(KERNEL, dim3(GRID), dim3(1024), lds_bytes, (hipStream_t)stream, view(t), *H, a);               \
   } while (0)
-#define HZ_SEARCH_LAUNCH_EL(V0, EL)                                                       \
-  do {                                                                                    \
-    if (halves) HZ_SEARCH_LAUNCH(V0 + 2, k_search_half<EL>, (t->N + 31) / 32);            \
-    else if (rows_wg == 32) HZ_SEARCH_LAUNCH(V0 + 1, (k_search<EL, 2>), (t->N + 31) / 32); \
-    else HZ_SEARCH_LAUNCH(V0, (k_search<EL, 1>), (t->N + 15) / 16);                       \
+#define HZ_SEARCH_LAUNCH_EL(V0, EL)                                                                  \
+  do {                                                                                               \
+    if (halves && rows_wg == 32) HZ_SEARCH_LAUNCH(V0 + 2, (k_search_half<EL, 16>), (t->N + 31) / 32); \
+    else if (halves) HZ_SEARCH_LAUNCH(V0 + 3, (k_search_half<EL, 8>), (t->N + 15) / 16);             \
+    else if (rows_wg == 32) HZ_SEARCH_LAUNCH(V0 + 1, (k_search<EL, 2>), (t->N + 31) / 32);           \
+    else HZ_SEARCH_LAUNCH(V0, (k_search<EL, 1>), (t->N + 15) / 16);                                  \
   } while (0)
   int cur = -1;
   HZ_HIP(hipGetDevice(&cur));
   HZ_REQUIRE(cur == t->device, "hz_search_run: the calling thread's current device is %d, the tree lives on %d", cur, t->device);
-  if (H->dtype == HZ_F16) HZ_SEARCH_LAUNCH_EL(3, ElF16);
+  if (H->dtype == HZ_F16) HZ_SEARCH_LAUNCH_EL(4, ElF16);
   else HZ_SEARCH_LAUNCH_EL(0, ElBf16);
 #undef HZ_SEARCH_LAUNCH_EL
 #undef HZ_SEARCH_LAUNCH

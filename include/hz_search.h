@@ -31,9 +31,10 @@ extern "C" {
  * rewards, values  [N] f32, policy [N][num_actions] f32 (DEVICE): reserved -- the leaf outputs stay on chip (row image ->
  *                  registers of the tree's wave) and these arrays are not written; they must still be valid pointers
  * rows_per_workgroup  trees per workgroup: 0 = chosen from the tree count and the compute-unit count of the tree's device
- *                  (the product's setting), 16 or 32 = forced (tests, measurements); with 32 the two trees of a wavefront
- *                  are searched side by side in its two 32-lane halves when num_actions <= 32 and hidden <= 512, -32 forces
- *                  them one after the other.  The results do not depend on any of it.
+ *                  (the product's setting), 16 or 32 = forced (tests, measurements).  With 32, when num_actions <= 32 and
+ *                  hidden <= 512, a wavefront searches its TWO trees side by side in its two 32-lane halves; -32 forces them
+ *                  one after the other; -16 = 16 trees per workgroup side by side on 8 of the 16 wavefronts (measured: no
+ *                  faster than one per wavefront, slower on deep paths).  The results do not depend on any of it.
  * The MLP header's dtype (HZ_BF16 / HZ_F16) selects the element format of pool, weights and activations.
  * The calling thread's current device must be the tree's. */
 int hz_search_run(hz_tree_t* t, int num_simulations, const hz_mlp_header_t* H, const hz_mlp_job_t* jobs,

@@ -233,10 +233,10 @@ def test_persistent_search_kernel_equals_launch_per_phase(game, N, sims, peaked,
     noise = torch.rand(N, A, device="cuda", generator=g)
     noise = noise / noise.sum(1, keepdim=True)
     res = []
-    # launch per phase; one tree per wavefront of the persistent kernel; two, side by side in the wave's halves (A <= 32)
-    # or one after the other (-32; what A = 48 gets either way); the library's own choice (two once the trees outnumber
-    # 16 per compute unit: the last case)
-    for persistent in (False, 16, 32, -32, "auto"):
+    # launch per phase; the persistent kernel with 16 trees per workgroup: one per wavefront, or two side by side in the
+    # halves of 8 wavefronts (-16; A <= 32); with 32: side by side or one after the other (-32; what A = 48 gets either way);
+    # the library's own choice (32 once the trees outnumber 16 per compute unit: the last case)
+    for persistent in (False, 16, -16, 32, -32, "auto"):
         roots = cytree.Roots(N, A, sims, tie_seed=5, tree_id_base=17)
         roots.prepare(0.0 if peaked else cfg.root_exploration_fraction, noise, torch.zeros(N, device="cuda"), logits0, actor.legal)
         pool = torch.zeros(sims, N, eng.H, dtype=eng.dtype, device="cuda")

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_stream(const u32x4* __restrict__
 // 4: as 3 with two row tiles = 32 rows per workgroup).
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
-template <int NW, int NT, int DEPTH, int MODE>
+template <int NW, int NT, int DEPTH, int MODE, int PF = DEPTH - 1, int BA = 3>
 __global__ __launch_bounds__(64 * NW, 1) void k_stream_mfma(const bf16x8* __restrict__ w, long long ksteps, int iters,
                                                             unsigned int* __restrict__ sink) {
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
@@ -73,18 +73,18 @@ __global__ __launch_bounds__(64 * NW, 1) void k_stream_mfma(const bf16x8* __rest
     for (int rt = 0; rt < RT; ++rt) bq[d][rt] = *reinterpret_cast<const bf16x8*>(src + 16 * rt * RS + 32 * d);
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
-    for (int d = 0; d < DEPTH - 1; ++d)
+    for (int d = 0; d < PF; ++d)
 #pragma unroll
       for (int t = 0; t < NT; ++t) ring[d][t] = base[(long long)d * kss + t * 64];
     for (long long s = 0; s < ksteps; s += 16) {
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) ring[(u + DEPTH - 1) % DEPTH][t] = base[(s + u + DEPTH - 1) * kss + t * 64];
+        for (int t = 0; t < NT; ++t) ring[(u + PF) % DEPTH][t] = base[(s + u + PF) * kss + t * 64];
         if (MODE >= 2) {
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt)
-            bq[(u + 3) % 4][rt] = *reinterpret_cast<const bf16x8*>(src + 16 * rt * RS + 32 * ((u + 3) & 15));
+            bq[(u + BA) % 4][rt] = *reinterpret_cast<const bf16x8*>(src + 16 * rt * RS + 32 * ((u + BA) & 15));
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -131,19 +131,19 @@ __global__ __launch_bounds__(64 * NW, 1) void k_stream_mfma(const bf16x8* __rest
   if (x == 12345.678f) sink[threadIdx.x] = 1;
 }
 
-template <int NW, int NT, int DEPTH, int MODE>
+template <int NW, int NT, int DEPTH, int MODE, int PF = DEPTH - 1, int BA = 3>
 static void run_mfma(const char* name, const void* w, size_t bytes, int grid, unsigned int* sink) {
   const long long ksteps = (long long)(bytes / ((size_t)NW * NT * 1024)) / 16 * 16;
   const int iters = 49;
   const size_t lds_bytes = (size_t)32 * 1800 * 2;
-  CHECK(hipFuncSetAttribute((const void*)k_stream_mfma<NW, NT, DEPTH, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  CHECK(hipFuncSetAttribute((const void*)k_stream_mfma<NW, NT, DEPTH, MODE, PF, BA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   hipEvent_t a, b;
   CHECK(hipEventCreate(&a));
   CHECK(hipEventCreate(&b));
   float best = 1e9f;
   for (int rep = 0; rep < 5; ++rep) {
     CHECK(hipEventRecord(a));
-    hipLaunchKernelGGL((k_stream_mfma<NW, NT, DEPTH, MODE>), dim3(grid), dim3(64 * NW), lds_bytes, 0, (const bf16x8*)w, ksteps, iters, sink);
+    hipLaunchKernelGGL((k_stream_mfma<NW, NT, DEPTH, MODE, PF, BA>), dim3(grid), dim3(64 * NW), lds_bytes, 0, (const bf16x8*)w, ksteps, iters, sink);
     CHECK(hipEventRecord(b));
     CHECK(hipEventSynchronize(b));
     float ms;
@@ -205,6 +205,9 @@ int main(int argc, char** argv) {
   run_mfma<16, 2, 4, 2>("16 x 2, 4 in flight: MFMA, B from LDS", w, bytes, grid, sink);
   run_mfma<16, 2, 4, 3>("16 x 2, 4 in flight: + layer boundary / 16 k-steps", w, bytes, grid, sink);
   run_mfma<16, 2, 4, 4>("16 x 2, 4 in flight: + boundary, 32 rows", w, bytes, grid, sink);
+  run_mfma<16, 2, 4, 4, 2, 1>("16 x 2, 32 rows, weights 2 ahead, B 1 ahead (product)", w, bytes, grid, sink);
+  run_mfma<16, 2, 4, 4, 2, 3>("16 x 2, 32 rows, weights 2 ahead, B 3 ahead", w, bytes, grid, sink);
+  run_mfma<16, 2, 4, 4, 3, 1>("16 x 2, 32 rows, weights 3 ahead, B 1 ahead", w, bytes, grid, sink);
   run_mfma<8, 4, 4, 1>(" 8 x 4, 4 in flight: MFMA, B constant", w, bytes, grid, sink);
   run_mfma<8, 4, 4, 2>(" 8 x 4, 4 in flight: MFMA, B from LDS", w, bytes, grid, sink);
   run_mfma<8, 4, 4, 3>(" 8 x 4, 4 in flight: + layer boundary / 16 k-steps", w, bytes, grid, sink);
