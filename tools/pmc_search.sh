@@ -18,8 +18,9 @@ for group in \
   "TCC_READ_REQ_LATENCY_sum TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum" \
   "TCC_BUSY_avr TCC_CYCLE_sum TCC_IB_STALL_sum TCC_LATENCY_FIFO_FULL_sum" ; do
   i=$((i+1))
-  # (a group the hardware cannot collect in one pass makes rocprofv3 abort and then hang: bounded, and not fatal)
-  timeout -k 5 150 rocprofv3 --pmc $group --kernel-include-regex "k_search" --output-format csv -d $OUT/g$i -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline "$@" > $OUT/g$i.log 2>&1 || echo "group $i failed: $group"
+  # (every group below fits one pass on gfx950 -- each was collected in rounds 1 and 2 -- so a pass that fails is an error: stop;
+  # the timeout only bounds a pass that no longer finishes.  The interpreter itself follows `--`: no env / shell hop.)
+  timeout -k 5 200 rocprofv3 --pmc $group --kernel-include-regex "k_search" --output-format csv -d $OUT/g$i -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-also "$@" > $OUT/g$i.log 2>&1 || { echo "group $i FAILED: $group (see $OUT/g$i.log)"; tail -5 $OUT/g$i.log; exit 1; }
   echo "group $i done: $group"
 done
 python - <<'PY'
