@@ -443,8 +443,14 @@ def net_error(game, dtype):
 
 
 def git_head():
+    """The commit of this tree: from git where there is a checkout, else from the stamp __graft_entry__.build() leaves beside the
+    library (the snapshot on a GPU box carries no .git)."""
     try:
         return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL, text=True).strip()
+    except Exception:
+        pass
+    try:
+        return open(os.path.join(ROOT, "hanabizero_amd", "libhanabizero_hip.commit.txt")).read().strip() or None
     except Exception:
         return None
 

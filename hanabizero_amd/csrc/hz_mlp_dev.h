@@ -136,7 +136,14 @@ extern "C" int hz_mlp_profile_read_passes(unsigned long long* host) {
 __device__ __forceinline__ void hz_bias_start_values(const float* uniform_row, f32x4& t0, f32x4& t1) {
   float a0, a1, a2, a3, b0, b1, b2, b3;
   asm volatile(
+#ifndef HZ_MLP_X_NOSLOAD  // experiment (tools/mlp_loop_bench.py): what the scalar loads' latency costs; results are garbage
       "s_load_dwordx16 s[68:83], %[p], 0x0\n\ts_load_dwordx16 s[84:99], %[p], 0x40\n\ts_waitcnt lgkmcnt(0)\n\t"
+#endif
+#ifdef HZ_MLP_X_FEWMOV  // experiment: what the 24 moves of the other three lane groups cost; results are garbage
+      "v_mov_b32 %[a0], s68\n\tv_mov_b32 %[a1], s69\n\tv_mov_b32 %[a2], s70\n\tv_mov_b32 %[a3], s71\n\t"
+      "v_mov_b32 %[b0], s84\n\tv_mov_b32 %[b1], s85\n\tv_mov_b32 %[b2], s86\n\tv_mov_b32 %[b3], s87\n\t"
+      "s_branch 9f\n\t"
+#endif
       "s_mov_b32 exec_hi, 0\n\ts_mov_b32 exec_lo, 0xffff\n\t"
       "v_mov_b32 %[a0], s68\n\tv_mov_b32 %[a1], s69\n\tv_mov_b32 %[a2], s70\n\tv_mov_b32 %[a3], s71\n\t"
       "v_mov_b32 %[b0], s84\n\tv_mov_b32 %[b1], s85\n\tv_mov_b32 %[b2], s86\n\tv_mov_b32 %[b3], s87\n\t"
@@ -149,7 +156,8 @@ __device__ __forceinline__ void hz_bias_start_values(const float* uniform_row, f
       "s_mov_b32 exec_hi, 0xffff0000\n\t"
       "v_mov_b32 %[a0], s80\n\tv_mov_b32 %[a1], s81\n\tv_mov_b32 %[a2], s82\n\tv_mov_b32 %[a3], s83\n\t"
       "v_mov_b32 %[b0], s96\n\tv_mov_b32 %[b1], s97\n\tv_mov_b32 %[b2], s98\n\tv_mov_b32 %[b3], s99\n\t"
-      "s_mov_b64 exec, -1"
+      "s_mov_b64 exec, -1\n\t"
+      "9:"
       : [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3), [b0] "=&v"(b0), [b1] "=&v"(b1), [b2] "=&v"(b2), [b3] "=&v"(b3)
       : [p] "s"(uniform_row)
       : "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85",
@@ -185,6 +193,9 @@ __device__ __forceinline__ void hz_bias_start_values(const float* uniform_row, f
 // (A/B on one box, tools/ab_bench.sh; every 2 or 8 k-steps and fixed youngest-first are worse), -1.1 % with 32 rows, where it
 // is therefore off.  (s_setprio takes an immediate.)
 __device__ __forceinline__ void hz_rotate_prio(int group_plus_phase) {
+#ifdef HZ_MLP_X_NOPRIO  // experiment (tools/mlp_chain_probe.py)
+  return;
+#endif
   switch (group_plus_phase & 3) {
     case 0: __builtin_amdgcn_s_setprio(0); break;
     case 1: __builtin_amdgcn_s_setprio(1); break;
@@ -363,12 +374,20 @@ __device__ __forceinline__ void mlp_body(
     if (j > 0) J = job_of(j);
     f32x4 acc[NT][RT];
     if (J.ks != 0) {
-#ifdef HZ_MLP_X_NOAV  // experiment (tools/mlp_variants.py): what the start values cost; results are garbage
+#if defined(HZ_MLP_X_NOAV) && HZ_MLP_X_NOAV + 0 == 0  // experiment (tools/mlp_variants.py): what the start values cost; results are garbage
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) acc[t][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #else
+#if defined(HZ_MLP_X_NOAV)  // 1: zeros instead of the bias start values only; 2: zeros instead of the action rows only
+      if (HZ_MLP_X_NOAV == 1 ? !(J.flags & HZ_MLP_ACTION_ROW) : (J.flags & HZ_MLP_ACTION_ROW)) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) acc[t][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      } else
+#endif
       if (J.flags & HZ_MLP_ACTION_ROW) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)

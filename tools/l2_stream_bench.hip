@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s -> %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
@@ -59,6 +60,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_stream_mfma(const bf16x8* __rest
   const bf16x8* base = w + (long long)wave * NT * 64 + lane;
   for (int i = threadIdx.x; i < 16 * RT * RS; i += 64 * NW) lds[i] = 0x3c00;
   __syncthreads();
+  const unsigned long long st0 = __builtin_amdgcn_s_memtime(), sr0 = __builtin_amdgcn_s_memrealtime();
   bf16x8 ring[DEPTH][NT];
   bf16x8 bq[4][RT];
   f32x4 acc[NT][RT];
@@ -129,6 +131,10 @@ __global__ __launch_bounds__(64 * NW, 1) void k_stream_mfma(const bf16x8* __rest
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) x += acc[t][rt][0] + acc[t][rt][1] + acc[t][rt][2] + acc[t][rt][3];
   if (x == 12345.678f) sink[threadIdx.x] = 1;
+  if (blockIdx.x == 100 && threadIdx.x == 0) {  // shader cycles (s_memtime) and 100 MHz ticks (s_memrealtime) of this workgroup
+    reinterpret_cast<unsigned long long*>(sink)[256] = __builtin_amdgcn_s_memtime() - st0;
+    reinterpret_cast<unsigned long long*>(sink)[257] = __builtin_amdgcn_s_memrealtime() - sr0;
+  }
 }
 
 template <int NW, int NT, int DEPTH, int MODE, int PF = DEPTH - 1, int BA = 3>
@@ -152,7 +158,10 @@ static void run_mfma(const char* name, const void* w, size_t bytes, int grid, un
   }
   CHECK(hipGetLastError());
   const double per_wg = (double)ksteps * NW * NT * 1024 * iters;
-  printf("%-52s %7.3f ms  %6.1f GB/s per CU  %6.2f TB/s chip\n", name, best, per_wg / best / 1e6, per_wg * grid / best / 1e9);
+  unsigned long long st[2] = {0, 0};
+  CHECK(hipMemcpy(st, reinterpret_cast<unsigned long long*>(sink) + 256, 16, hipMemcpyDeviceToHost));
+  printf("%-52s %7.3f ms  %6.1f GB/s per CU  %6.2f TB/s chip | %5.1f B / shader cycle, shader clock %.2f GHz\n", name, best, per_wg / best / 1e6,
+         per_wg * grid / best / 1e9, per_wg / (double)st[0], (double)st[0] / (double)st[1] * 0.1);
 }
 
 template <int NW, int NT, int DEPTH, bool SYNC>
@@ -187,6 +196,21 @@ int main(int argc, char** argv) {
   unsigned int* sink;
   CHECK(hipMalloc(&w, bytes + (1 << 20)));
   CHECK(hipMemset(w, 1, bytes + (1 << 20)));
+  if (argc > 3 && argv[3][0] == 'r') {  // random bf16 weights ~ U(-1/16, 1/16) instead of one repeated byte: does the data (power) matter?
+    const size_t n = (bytes + (1 << 20)) / 2;
+    unsigned short* h = (unsigned short*)malloc(n * 2);
+    unsigned int x = 12345u;
+    for (size_t i = 0; i < n; ++i) {
+      x = x * 1664525u + 1013904223u;
+      const float f = ((int)(x >> 8) - (1 << 23)) * (1.0f / (1 << 27));
+      unsigned int u;
+      memcpy(&u, &f, 4);
+      h[i] = (unsigned short)(u >> 16);
+    }
+    CHECK(hipMemcpy(w, h, n * 2, hipMemcpyHostToDevice));
+    free(h);
+    printf("(random weights)\n");
+  }
   CHECK(hipMalloc(&sink, 4096));
   printf("L2 -> CU stream of a %.2f MB buffer shared by %d workgroups (%d CUs)\n", bytes / 1e6, grid, cus);
   run<16, 2, 4, false>("16 waves x 2 KiB/k-step, 4 k-steps in flight", w, bytes, grid, sink, 1);

@@ -13,6 +13,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def uniform_chain(eng, waves, tiles, n, seed=0):
+    """n layers of H x H (every wave busy, one barrier per layer), ping-pong between two image regions."""
+    from hanabizero_amd.model import _FusedChain
+    H = eng.H
+    g = torch.Generator().manual_seed(seed)
+    ch = _FusedChain(eng, waves, tiles)
+    X, Y = 0, H
+    for k in range(n):
+        w, b = torch.randn(H, H, generator=g) / H ** 0.5, torch.randn(H, generator=g) * 0.1
+        ch.add_dense(w, b, H, X if k % 2 == 0 else Y, Y if k % 2 == 0 else X, relu=True, barrier=k > 0, store_hidden=(k == n - 1))
+    ch._finish(3 * H, in_width=H, hidden=H, state_off=0, hidden_off=Y if n % 2 == 0 else X, off_r=2 * H, off_v=2 * H + 256, off_p=2 * H + 512)
+    return ch
+
+
 def main():
     import bench
     from hanabizero_amd._lib import check, lib
@@ -26,15 +40,7 @@ def main():
     g = torch.Generator().manual_seed(0)
     rnd = lambda o, i: (torch.randn(o, i, generator=g) / i ** 0.5, torch.randn(o, generator=g) * 0.1)
 
-    class Uniform(_FusedChain):  # n layers of 512 x 512, ping-pong between two image regions
-        def __init__(self, engine, waves, tiles, n):
-            super().__init__(engine, waves, tiles)
-            X, Y = 0, H
-            for k in range(n):
-                w, b = rnd(H, H)
-                self.add_dense(w, b, H, X if k % 2 == 0 else Y, Y if k % 2 == 0 else X, relu=True, barrier=k > 0,
-                               store_hidden=(k == n - 1))
-            self._finish(3 * H, in_width=H, hidden=H, state_off=0, hidden_off=Y if n % 2 == 0 else X, off_r=2 * H, off_v=2 * H + 256, off_p=2 * H + 512)
+    Uniform = lambda engine, waves, tiles, n: uniform_chain(engine, waves, tiles, n)
 
     class Dynamics(_FusedChain):  # the three dynamics layers of the real net (action row + residual) + hidden store
         def __init__(self, engine, waves, tiles):
@@ -49,7 +55,7 @@ def main():
             self.add_dense(w, b, H, Y0, X, relu=True, store_hidden=True)
             self._finish(3 * H + h, in_width=H, hidden=H, state_off=0, hidden_off=Y0, off_r=0, off_v=256, off_p=512)
 
-    def time(chain, mt):
+    def time(chain, mt, lib=lib):
         S = 8
         pool = torch.rand(S, N, H, device="cuda").to(torch.bfloat16)
         ix = torch.randint(0, S, (N,), device="cuda", dtype=torch.int32)
@@ -80,6 +86,29 @@ def main():
             torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e3 / 100
 
+    if os.environ.get("HZ_PROBE_VARIANTS"):  # the same chains through scratch builds with parts compiled out (results garbage)
+        import subprocess
+        from hanabizero_amd._lib import MlpHeader
+        src = os.path.join(ROOT, "hanabizero_amd", "csrc")
+        V, I, I64 = C.c_void_p, C.c_int, C.c_int64
+        NOAV, NOEPI = ["-DHZ_MLP_X_NOAV"], ["-DHZ_MLP_X_NOEPI"]
+        mt = N // 256
+        chains = [("real recurrent inference", FusedRecurrent(net, eng, 16, 2)), ("6 uniform 512x512 layers", Uniform(eng, 16, 2, 6)),
+                  ("12 uniform 512x512 layers", Uniform(eng, 16, 2, 12))]
+        for vname, flags in (("baseline", []), ("no start values", NOAV), ("no epilogues", NOEPI), ("no start values, no epilogues", NOAV + NOEPI),
+                             ("no start / epi / final / staging", NOAV + NOEPI + ["-DHZ_MLP_X_NOFINAL", "-DHZ_MLP_X_NOSTAGE"]),
+                             ("no priorities", ["-DHZ_MLP_X_NOPRIO"])):
+            out = os.path.join(ROOT, "gpurun_out", "libmlp_probe_%s.so" % "".join(c for c in vname if c.isalnum()))
+            subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+                                   "-w", "-I" + src, "-I" + os.path.join(ROOT, "include"), "-o", out, os.path.join(src, "hz_mlp.hip"),
+                                   os.path.join(src, "hz_tree.hip")] + flags)
+            vl = C.CDLL(out)
+            vl.hz_mlp_recurrent.argtypes = [C.POINTER(MlpHeader), V, V, V, V, V, I64, V, I64, V, V, V, V, V, I, I, V]
+            vl.hz_mlp_recurrent.restype = I
+            for name, ch in chains:
+                us = time(ch, mt, vl)
+                print("%-34s %-28s %7.2f us/launch  %6.1f GB/s per CU" % (vname, name, us, ch.weight_bytes_per_wg / us / 1e3), flush=True)
+        return
     for waves, tiles in ((16, 2), (8, 4)):
         for mt in (16, 32):
             if N // mt != 256:

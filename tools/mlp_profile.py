@@ -12,6 +12,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
 def main():
@@ -30,6 +31,9 @@ def main():
     cfg = make_config(game, simulations=50, stack=4)
     eng = bench.build_engine(cfg, torch.bfloat16, "cuda")
     f = eng.fused_shape(waves, tiles)
+    if os.environ.get("HZ_PROFILE_UNIFORM"):  # n uniform 512 x 512 layers instead of the real chain (tools/mlp_chain_probe.py)
+        from mlp_chain_probe import uniform_chain
+        f = uniform_chain(eng, waves, tiles, int(os.environ["HZ_PROFILE_UNIFORM"]))
     hid = torch.rand(N, eng.H, device="cuda").to(torch.bfloat16)
     act = torch.randint(0, eng.A, (N,), device="cuda", dtype=torch.int32)
     h = torch.empty(N, eng.H, dtype=torch.bfloat16, device="cuda")
