@@ -15,7 +15,7 @@ class HzError(RuntimeError):
 
 class MlpJob(C.Structure):  # include/hz_mlp.h hz_mlp_job_t
     _fields_ = [("ks", C.c_int32), ("src_off", C.c_int32), ("dst_off", C.c_int32), ("res_off", C.c_int32),
-                ("bias_off", C.c_int32), ("flags", C.c_int32), ("reserved0", C.c_int32), ("reserved1", C.c_int32)]
+                ("bias_off", C.c_int32), ("flags", C.c_int32), ("reserved0", C.c_int32), ("producer", C.c_int32)]
 
 
 class MlpHeader(C.Structure):  # include/hz_mlp.h hz_mlp_header_t

@@ -108,6 +108,11 @@ __device__ __forceinline__ float row32_support_to_scalar(const uint16_t* row, in
 #ifdef HZ_MLP_PROFILE
 __device__ unsigned long long hz_mlp_prof[16 * 8];
 __device__ unsigned long long hz_mlp_prof_pass[34];  // wave 0 of workgroup 100: s_memtime when it leaves job j's prologue
+__device__ unsigned int hz_mlp_prof_tl[16 * 8 * 4];  // per wave, first 8 jobs: s_memtime (low word) past the barrier / k-loop start / k-loop end / epilogue end
+extern "C" int hz_mlp_profile_read_timeline(unsigned int* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(hz_mlp_prof_tl), sizeof(hz_mlp_prof_tl));
+}
+#define PROF_TL(J, K) do { if (blockIdx.x == 100 && lane == 0 && (J) < 8) prof_tl[(wave * 8 + (J)) * 4 + (K)] = (unsigned int)__builtin_amdgcn_s_memtime(); } while (0)
 extern "C" int hz_mlp_profile_read(unsigned long long* host) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(hz_mlp_prof), sizeof(hz_mlp_prof));
 }
@@ -119,6 +124,7 @@ extern "C" int hz_mlp_profile_read_passes(unsigned long long* host) {
 #else
 #define PROF_NOW() 0ull
 #define PROF_ADD(var, t0) (void)(t0)
+#define PROF_TL(J, K) (void)0
 #endif
 
 // Weight-fragment ring: RING slots of one k-step each.  16 waves per workgroup (128 registers per lane): 4 slots.  Workgroups of
@@ -136,14 +142,7 @@ extern "C" int hz_mlp_profile_read_passes(unsigned long long* host) {
 __device__ __forceinline__ void hz_bias_start_values(const float* uniform_row, f32x4& t0, f32x4& t1) {
   float a0, a1, a2, a3, b0, b1, b2, b3;
   asm volatile(
-#ifndef HZ_MLP_X_NOSLOAD  // experiment (tools/mlp_loop_bench.py): what the scalar loads' latency costs; results are garbage
       "s_load_dwordx16 s[68:83], %[p], 0x0\n\ts_load_dwordx16 s[84:99], %[p], 0x40\n\ts_waitcnt lgkmcnt(0)\n\t"
-#endif
-#ifdef HZ_MLP_X_FEWMOV  // experiment: what the 24 moves of the other three lane groups cost; results are garbage
-      "v_mov_b32 %[a0], s68\n\tv_mov_b32 %[a1], s69\n\tv_mov_b32 %[a2], s70\n\tv_mov_b32 %[a3], s71\n\t"
-      "v_mov_b32 %[b0], s84\n\tv_mov_b32 %[b1], s85\n\tv_mov_b32 %[b2], s86\n\tv_mov_b32 %[b3], s87\n\t"
-      "s_branch 9f\n\t"
-#endif
       "s_mov_b32 exec_hi, 0\n\ts_mov_b32 exec_lo, 0xffff\n\t"
       "v_mov_b32 %[a0], s68\n\tv_mov_b32 %[a1], s69\n\tv_mov_b32 %[a2], s70\n\tv_mov_b32 %[a3], s71\n\t"
       "v_mov_b32 %[b0], s84\n\tv_mov_b32 %[b1], s85\n\tv_mov_b32 %[b2], s86\n\tv_mov_b32 %[b3], s87\n\t"
@@ -156,8 +155,7 @@ __device__ __forceinline__ void hz_bias_start_values(const float* uniform_row, f
       "s_mov_b32 exec_hi, 0xffff0000\n\t"
       "v_mov_b32 %[a0], s80\n\tv_mov_b32 %[a1], s81\n\tv_mov_b32 %[a2], s82\n\tv_mov_b32 %[a3], s83\n\t"
       "v_mov_b32 %[b0], s96\n\tv_mov_b32 %[b1], s97\n\tv_mov_b32 %[b2], s98\n\tv_mov_b32 %[b3], s99\n\t"
-      "s_mov_b64 exec, -1\n\t"
-      "9:"
+      "s_mov_b64 exec, -1"
       : [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3), [b0] "=&v"(b0), [b1] "=&v"(b1), [b2] "=&v"(b2), [b3] "=&v"(b3)
       : [p] "s"(uniform_row)
       : "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85",
@@ -193,9 +191,6 @@ __device__ __forceinline__ void hz_bias_start_values(const float* uniform_row, f
 // (A/B on one box, tools/ab_bench.sh; every 2 or 8 k-steps and fixed youngest-first are worse), -1.1 % with 32 rows, where it
 // is therefore off.  (s_setprio takes an immediate.)
 __device__ __forceinline__ void hz_rotate_prio(int group_plus_phase) {
-#ifdef HZ_MLP_X_NOPRIO  // experiment (tools/mlp_chain_probe.py)
-  return;
-#endif
   switch (group_plus_phase & 3) {
     case 0: __builtin_amdgcn_s_setprio(0); break;
     case 1: __builtin_amdgcn_s_setprio(1); break;
@@ -215,7 +210,9 @@ struct RowFrag {
   uint4 v[2];
 };
 // FINAL = false: stop after the last layer (logits stay in the image; the caller's waves read them there).
-template <class EL, int RT, int NW, int NT, int STAGE = STAGE_GATHER, bool FINAL = true>
+// BW = false: HZ_MLP_BLOCKWISE jobs wait at a workgroup barrier instead (the stronger condition; for the kernel that has no
+// registers to spare for the counters' address).
+template <class EL, int RT, int NW, int NT, int STAGE = STAGE_GATHER, bool FINAL = true, bool BW = true>
 __device__ __forceinline__ void mlp_body(
     const hz_mlp_header_t& H, const hz_mlp_job_t* __restrict__ jobs, const uint16_t* __restrict__ wstream,
     const float* __restrict__ bias, const float* __restrict__ act_tab, const uint16_t* __restrict__ state_src,
@@ -237,6 +234,9 @@ __device__ __forceinline__ void mlp_body(
   const int rs = H.row_stride;
   (void)NTHR;
 
+#ifdef HZ_MLP_PROFILE
+  unsigned int* prof_tl = reinterpret_cast<unsigned int*>(lds + (size_t)MT * H.row_stride);  // (the launcher adds 2 KiB behind the image)
+#endif
   unsigned long long p_loop = 0, p_epi = 0, p_bar = 0, p_pre = 0;
   const unsigned long long p_t0 = PROF_NOW();
   (void)p_loop; (void)p_epi; (void)p_bar; (void)p_pre; (void)p_t0;
@@ -334,6 +334,8 @@ __device__ __forceinline__ void mlp_body(
       if (wave < 8 * RT && hl + 32 * u < chunks)
         *reinterpret_cast<uint4*>(lds + (size_t)hrow * rs + H.state_off + (hl + 32 * u) * 8) = row_frag[0].v[u];
   }
+  // arrival counters of the HZ_MLP_SIGNAL jobs (include/hz_mlp.h): four per job, in the padding behind image row `job`
+  if (ASMK && tid < 64) reinterpret_cast<unsigned int*>(lds + (size_t)(tid >> 2) * rs + (rs - 8))[tid & 3] = 0u;
   __syncthreads();
   int act[RT];  // (read after the barrier: in STAGE_REGS mode the caller's waves have only just written them)
 #pragma unroll
@@ -355,6 +357,7 @@ __device__ __forceinline__ void mlp_body(
     J.res_off = __builtin_amdgcn_readlane(jr, jb + 3);
     J.bias_off = __builtin_amdgcn_readlane(jr, jb + 4);
     J.flags = __builtin_amdgcn_readlane(jr, jb + 5);
+    J.producer = __builtin_amdgcn_readlane(jr, jb + 7);
     return J;
   };
   // The accumulators start from the epilogue's additive term -- bias (+ the action's column of the first dynamics layer): one
@@ -374,20 +377,12 @@ __device__ __forceinline__ void mlp_body(
     if (j > 0) J = job_of(j);
     f32x4 acc[NT][RT];
     if (J.ks != 0) {
-#if defined(HZ_MLP_X_NOAV) && HZ_MLP_X_NOAV + 0 == 0  // experiment (tools/mlp_variants.py): what the start values cost; results are garbage
+#ifdef HZ_MLP_X_NOAV  // experiment (tools/mlp_variants.py): what the start values cost; results are garbage
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) acc[t][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #else
-#if defined(HZ_MLP_X_NOAV)  // 1: zeros instead of the bias start values only; 2: zeros instead of the action rows only
-      if (HZ_MLP_X_NOAV == 1 ? !(J.flags & HZ_MLP_ACTION_ROW) : (J.flags & HZ_MLP_ACTION_ROW)) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-          for (int rt = 0; rt < RT; ++rt) acc[t][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      } else
-#endif
       if (J.flags & HZ_MLP_ACTION_ROW) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -424,7 +419,8 @@ __device__ __forceinline__ void mlp_body(
 #endif
     }
     const unsigned long long p_j0 = PROF_NOW();
-    if (J.flags & HZ_MLP_BARRIER) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // LDS only: loads stay in flight
+    if ((J.flags & HZ_MLP_BARRIER) || (!(BW && ASMK) && (J.flags & HZ_MLP_BLOCKWISE)))
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // LDS only: loads stay in flight
     if (J.flags & HZ_MLP_STORE_HIDDEN) {
       const int chunks = H.hidden / 8;
       for (int i = tid; i < MT * chunks; i += NTHR) {
@@ -438,11 +434,13 @@ __device__ __forceinline__ void mlp_body(
 #ifdef HZ_MLP_PROFILE
     if (blockIdx.x == 100 && wave == 0 && lane == 0 && j < 32) hz_mlp_prof_pass[j] = PROF_NOW();  // past job j's barrier
 #endif
+    PROF_TL(j, 0);
     if (J.ks == 0) continue;
     const unsigned long long p_j1 = PROF_NOW();
     const uint16_t* src = lds + (size_t)r0 * rs + J.src_off + kq;
     PROF_ADD(p_pre, p_j1);
     const unsigned long long p_j2 = PROF_NOW();
+    PROF_TL(j, 1);
     if constexpr (ASMK) {
       // ---- the k-loop, hand-scheduled (the compiler's own schedule of the same loop drained the weight ring at the start
       // of every job and of every 8 k-steps: it packs address arithmetic into ring registers and serialises the refills
@@ -455,7 +453,14 @@ __device__ __forceinline__ void mlp_body(
       // The ring lives in the fixed registers v[96:127] (see HZ_W00 ..): in flight across everything the compiler generates.
       unsigned int cnt = (unsigned int)J.ks >> 2;
       unsigned int la0 = (unsigned int)(uintptr_t)(__attribute__((address_space(3))) const uint16_t*)src;
-      if (RT == 1) hz_rotate_prio((wave >> 2) + j);  // issue priority rotates over the workgroup's four age groups, job by job
+      // issue priority: rotates over the workgroup's four age groups, job by job -- except where the groups should finish in
+      // the order of their columns (HZ_MLP_SIGNAL / HZ_MLP_BLOCKWISE: the consumers want block 0 first): oldest group first
+      if (J.flags & (HZ_MLP_SIGNAL | HZ_MLP_BLOCKWISE)) hz_rotate_prio(3 - (wave >> 2));
+      else if (RT == 1) hz_rotate_prio((wave >> 2) + j);
+      const bool blockwise = BW && (J.flags & HZ_MLP_BLOCKWISE);
+      unsigned int pc = 1u << 22;  // polls before a wave gives up on a counter (a job table that breaks the contract must not hang the GPU)
+      unsigned int fa = (unsigned int)(uintptr_t)(__attribute__((address_space(3))) const uint16_t*)(lds + (size_t)J.producer * rs + (rs - 8));
+      unsigned int pt, ps;
       if constexpr (RT == 1) {
         // one row tile: weights 3 k-steps ahead (4 ring slots), activation fragments 3 k-steps ahead in 4 slots
         v8 b0, b1, b2, b3;
@@ -483,15 +488,38 @@ __device__ __forceinline__ void mlp_body(
               [voff] "+v"(voff), [la0] "+v"(la0), [cnt] "+s"(cnt)                                                  \
             : [sa] "s"(wbase), [kss] "s"(kss)                                                                     \
             : "memory", "scc", HZ_RING_CLOBBER)
+        // blockwise: per block of 4 k-steps wait for the producers of its 128 input columns, then prime the activation
+        // fragments and run the block without reading past it
+#define HZ_POLL()                                                                                                       \
+            "2:\n\tds_read_b32 %[pt], %[fa]\n\ts_waitcnt lgkmcnt(0)\n\tv_readfirstlane_b32 %[ps], %[pt]\n\ts_nop 3\n\t"        \
+            "s_cmp_ge_u32 %[ps], 4\n\ts_cbranch_scc1 3f\n\ts_sleep 1\n\ts_sub_u32 %[pc], %[pc], 1\n\ts_cmp_lg_u32 %[pc], 0\n\t"   \
+            "s_cbranch_scc1 2b\n\t3:\n\t"
+#define HZ_K1B_BODY()                                                                                           \
+        asm volatile(                                                                                           \
+            "1:\n\t" HZ_POLL()                                                                                   \
+            HZ_RD1("b0", 0) HZ_RD1("b1", 64) HZ_RD1("b2", 128)                                                    \
+            HZ_K1(HZ_W00, HZ_W01, HZ_W30, HZ_W31, "b0", HZ_RD1("b3", 192), "3")                                    \
+            HZ_K1(HZ_W10, HZ_W11, HZ_W00, HZ_W01, "b1", "", "2")                                                   \
+            HZ_K1(HZ_W20, HZ_W21, HZ_W10, HZ_W11, "b2", "", "1")                                                   \
+            HZ_K1(HZ_W30, HZ_W31, HZ_W20, HZ_W21, "b3", "", "0")                                                   \
+            "v_add_u32 %[la0], 0x100, %[la0]\n\tv_add_u32 %[fa], 4, %[fa]\n\t"                                   \
+            "s_sub_u32 %[cnt], %[cnt], 1\n\ts_cmp_lg_u32 %[cnt], 0\n\ts_cbranch_scc1 1b\n\t"                     \
+            "s_nop 7\n\ts_nop 7\n\ts_nop 7"                                                                      \
+            : [b0] "=&v"(b0), [b1] "=&v"(b1), [b2] "=&v"(b2), [b3] "=&v"(b3), [a0] "+v"(acc[0][0]), [a1] "+v"(acc[1][0]), \
+              [voff] "+v"(voff), [la0] "+v"(la0), [cnt] "+s"(cnt), [fa] "+v"(fa), [pt] "=&v"(pt), [ps] "=&s"(ps),   \
+              [pc] "+s"(pc)                                                                                       \
+            : [sa] "s"(wbase), [kss] "s"(kss)                                                                     \
+            : "memory", "scc", HZ_RING_CLOBBER)
         if constexpr (EL::code == HZ_BF16) {
 #define HZ_EL_ASM "bf16"
-          HZ_K1_BODY();
+          if constexpr (BW) { if (blockwise) HZ_K1B_BODY(); else HZ_K1_BODY(); } else HZ_K1_BODY();
 #undef HZ_EL_ASM
         } else {
 #define HZ_EL_ASM "f16"
-          HZ_K1_BODY();
+          if constexpr (BW) { if (blockwise) HZ_K1B_BODY(); else HZ_K1_BODY(); } else HZ_K1_BODY();
 #undef HZ_EL_ASM
         }
+#undef HZ_K1B_BODY
 #undef HZ_K1_BODY
 #undef HZ_K1
 #undef HZ_RD1
@@ -526,15 +554,34 @@ __device__ __forceinline__ void mlp_body(
               [voff] "+v"(voff), [la0] "+v"(la0), [la1] "+v"(la1), [cnt] "+s"(cnt)                                 \
             : [sa] "s"(wbase), [kss] "s"(kss)                                                                     \
             : "memory", "scc", HZ_RING_CLOBBER)
+#define HZ_K2B_BODY()                                                                                           \
+        asm volatile(                                                                                           \
+            "1:\n\t" HZ_POLL()                                                                                   \
+            HZ_RD2("b00", "b01", 0)                                                                               \
+            HZ_K2(HZ_W00, HZ_W01, HZ_W20, HZ_W21, "b00", "b01", HZ_RD2("b10", "b11", 64), "2")                     \
+            HZ_K2(HZ_W10, HZ_W11, HZ_W30, HZ_W31, "b10", "b11", HZ_RD2("b00", "b01", 128), "2")                    \
+            HZ_K2(HZ_W20, HZ_W21, HZ_W00, HZ_W01, "b00", "b01", HZ_RD2("b10", "b11", 192), "2")                    \
+            HZ_K2(HZ_W30, HZ_W31, HZ_W10, HZ_W11, "b10", "b11", "", "0")                                           \
+            "v_add_u32 %[la0], 0x100, %[la0]\n\tv_add_u32 %[la1], 0x100, %[la1]\n\tv_add_u32 %[fa], 4, %[fa]\n\t"  \
+            "s_sub_u32 %[cnt], %[cnt], 1\n\ts_cmp_lg_u32 %[cnt], 0\n\ts_cbranch_scc1 1b\n\t"                     \
+            "s_nop 7\n\ts_nop 7\n\ts_nop 7"                                                                      \
+            : [b00] "=&v"(b00), [b01] "=&v"(b01), [b10] "=&v"(b10), [b11] "=&v"(b11),                              \
+              [a00] "+v"(acc[0][0]), [a01] "+v"(acc[0][1]), [a10] "+v"(acc[1][0]), [a11] "+v"(acc[1][1]),          \
+              [voff] "+v"(voff), [la0] "+v"(la0), [la1] "+v"(la1), [cnt] "+s"(cnt), [fa] "+v"(fa), [pt] "=&v"(pt), \
+              [ps] "=&s"(ps), [pc] "+s"(pc)                                                                       \
+            : [sa] "s"(wbase), [kss] "s"(kss)                                                                     \
+            : "memory", "scc", HZ_RING_CLOBBER)
         if constexpr (EL::code == HZ_BF16) {
 #define HZ_EL_ASM "bf16"
-          HZ_K2_BODY();
+          if constexpr (BW) { if (blockwise) HZ_K2B_BODY(); else HZ_K2_BODY(); } else HZ_K2_BODY();
 #undef HZ_EL_ASM
         } else {
 #define HZ_EL_ASM "f16"
-          HZ_K2_BODY();
+          if constexpr (BW) { if (blockwise) HZ_K2B_BODY(); else HZ_K2_BODY(); } else HZ_K2_BODY();
 #undef HZ_EL_ASM
         }
+#undef HZ_K2B_BODY
+#undef HZ_POLL
 #undef HZ_K2_BODY
 #undef HZ_K2
 #undef HZ_RD2
@@ -595,6 +642,7 @@ __device__ __forceinline__ void mlp_body(
       gstep += J.ks;
     }
     PROF_ADD(p_loop, p_j2);
+    PROF_TL(j, 2);
     const unsigned long long p_j3 = PROF_NOW();
 
 #ifdef HZ_MLP_X_NOEPI  // experiment (tools/mlp_variants.py): what the epilogues cost; results are garbage
@@ -643,7 +691,12 @@ __device__ __forceinline__ void mlp_body(
         *reinterpret_cast<uint2*>(lds + rowbase + J.dst_off + col) = o;
       }
     }
+    if (ASMK && (J.flags & HZ_MLP_SIGNAL)) {  // this wave's columns are in the image (LDS executes a wave's operations in order)
+      unsigned int* ready = reinterpret_cast<unsigned int*>(lds + (size_t)j * rs + (rs - 8)) + (wave >> 2);
+      if (lane == 0) __hip_atomic_fetch_add(ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
     PROF_ADD(p_epi, p_j3);
+    PROF_TL(j, 3);
   }
   if constexpr (ASMK)  // the last requests ran into the padding behind the stream: nobody waits for them, so wait here
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory", HZ_RING_CLOBBER);
@@ -680,6 +733,7 @@ __device__ __forceinline__ void mlp_body(
     unsigned long long* o = hz_mlp_prof + wave * 8;
     o[0] = p_staged - p_t0; o[1] = p_bar; o[2] = p_pre; o[3] = p_loop; o[4] = p_epi;
     o[5] = PROF_NOW() - p_jobs_done; o[6] = PROF_NOW() - p_t0; o[7] = (unsigned long long)gstep;
+    for (int i = 0; i < 32; ++i) hz_mlp_prof_tl[wave * 32 + i] = prof_tl[wave * 32 + i];
     if (wave == 0) {
       hz_mlp_prof_pass[32] = p_t0;
       hz_mlp_prof_pass[33] = PROF_NOW();

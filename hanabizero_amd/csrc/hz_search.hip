@@ -132,7 +132,7 @@ __device__ __forceinline__ RowFrag search_backup_descent(const TreeView& tv, con
 template <class EL, int RT>
 __device__ __forceinline__ void search_inference(const hz_mlp_header_t& H, const SearchArgs& a, const SearchLds& L, int sim,
                                                  int n_rows, int row0, const RowFrag* rows) {
-  mlp_body<EL, RT, 16, 2, STAGE_REGS, false>(H, a.jobs, a.wstream, a.bias, a.act_tab, a.pool, a.row_stride, nullptr, a.plane_stride,
+  mlp_body<EL, RT, 16, 2, STAGE_REGS, false, RT == 1>(H, a.jobs, a.wstream, a.bias, a.act_tab, a.pool, a.row_stride, nullptr, a.plane_stride,
                                  L.act_s - row0, a.pool + (size_t)(sim + 1) * a.plane_stride, nullptr, nullptr, nullptr,
                                  n_rows, L.image, row0, rows);
 }

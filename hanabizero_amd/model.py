@@ -12,6 +12,7 @@ tensors (the reference returns numpy on the host: core/model.py:65-71,78-82).  T
 (MFMA); nothing else on the hot path touches the matrix cores.
 """
 import math
+import os
 from typing import NamedTuple
 
 import torch
@@ -482,7 +483,7 @@ class InferenceEngine:
 
 
 # ------------------------------------------------------------------------------------------------ fused MFMA kernel
-MLP_RELU, MLP_ACTION_ROW, MLP_BARRIER, MLP_STORE_HIDDEN = 1, 2, 4, 8  # include/hz_mlp.h flags
+MLP_RELU, MLP_ACTION_ROW, MLP_BARRIER, MLP_STORE_HIDDEN, MLP_SIGNAL, MLP_BLOCKWISE = 1, 2, 4, 8, 16, 32  # include/hz_mlp.h flags
 
 
 def _pack_fragments(wblk, ks, tiles=4):
@@ -515,12 +516,19 @@ class _FusedChain:
         self.host_only = host_only
         self.cw = 16 * tiles   # output columns of one job
         self._jobs = []        # [pass] -> dict(entries [wave] -> dict or None, barrier, store_hidden)
+        self.blockwise = (waves, tiles) == (16, 2) and os.environ.get("HANABIZERO_MLP_BLOCKWISE", "1") != "0"
 
     def add_dense(self, w, b, K, src_off, dst_off, relu, res_off=None, barrier=True, store_hidden=False, act_w=None):
         """out[:, dst_off:dst_off+nout] = act(in[:, src_off:src_off+K] @ w^T + b ...), nout split into cw-column
-        wave jobs, `waves` per pass."""
+        wave jobs, `waves` per pass.
+        16 x 2 shape: where a full-width layer (one pass, every wave 32 columns of a 512-column output) feeds the next
+        layer's 512 inputs, the boundary between them is not a workgroup barrier but include/hz_mlp.h's per-block arrival
+        counters (HZ_MLP_SIGNAL on the producer, HZ_MLP_BLOCKWISE on the consumer): decided here, from the chain alone."""
         cw, waves = self.cw, self.waves
         nout = w.shape[0]
+        prev = self._jobs[-1] if self._jobs else None
+        blockwise = bool(self.blockwise and barrier and not store_hidden and prev is not None and prev.get("full") is not None
+                         and prev["full"] == src_off and K == cw * waves and len(self._jobs) - 1 < 16)
         chunks = [(c, min(cw, nout - c)) for c in range(0, nout, cw)]
         for p0 in range(0, len(chunks), waves):
             row = []
@@ -532,9 +540,13 @@ class _FusedChain:
                 row.append(dict(w=w[c:c + n], b=b[c:c + n], ks=K // 32, src=src_off, dst=dst_off + c,
                                 res=None if res_off is None else res_off + c, relu=relu,
                                 act=None if act_w is None else act_w[c:c + n]))
-            self._jobs.append(dict(entries=row, barrier=barrier and p0 == 0, store_hidden=store_hidden and p0 == 0))
+            self._jobs.append(dict(entries=row, barrier=barrier and p0 == 0 and not blockwise, store_hidden=store_hidden and p0 == 0,
+                                   blockwise=blockwise and p0 == 0,
+                                   full=dst_off if (nout == cw * waves and waves == 16) else None))
+        if blockwise:
+            prev["signal"] = True
 
-    def add_group(self, items, K, barrier=True):
+    def add_group(self, items, K, barrier=True, store_hidden=False):
         """independent small layers (w, b, src, dst, res, relu) side by side: cut into cw-column jobs, `waves`
         per pass."""
         cw, waves = self.cw, self.waves
@@ -545,9 +557,9 @@ class _FusedChain:
                                 res=None if res is None else res + c, relu=relu, act=None))
         for p0 in range(0, len(cut), waves):
             row = cut[p0:p0 + waves] + [None] * (waves - len(cut[p0:p0 + waves]))
-            self._jobs.append(dict(entries=row, barrier=barrier and p0 == 0, store_hidden=False))
+            self._jobs.append(dict(entries=row, barrier=barrier and p0 == 0, store_hidden=store_hidden and p0 == 0))
 
-    def add_stage(self, lanes, barrier=True):
+    def add_stage(self, lanes, barrier=True, store_hidden=False):
         """Independent chains side by side between two workgroup barriers: `lanes` = [[(w, b, K, src, dst, relu, res), ...],
         ...]; lane i owns the waves [i * waves / len(lanes), (i + 1) * waves / len(lanes)) and runs its layers one after
         the other on them while the other lanes stream their own: no wave idles through a barrier because the layer at
@@ -569,7 +581,7 @@ class _FusedChain:
                                                         res=None if res is None else res + c, relu=relu, act=None)
                 r += (len(chunks) + cap - 1) // cap
         for k, row in enumerate(rows):
-            self._jobs.append(dict(entries=row, barrier=barrier and k == 0, store_hidden=False, fixed=True))
+            self._jobs.append(dict(entries=row, barrier=barrier and k == 0, store_hidden=store_hidden and k == 0, fixed=True))
 
     def _finish(self, width, in_width, hidden, state_off, hidden_off, off_r, off_v, off_p):
         from ._lib import MlpHeader, MlpJob
@@ -598,8 +610,17 @@ class _FusedChain:
                     row[w] = e
                     load[w] += e["ks"]
                 assert all(e["ks"] == pass_ks for e in ents), "jobs of one pass share their K"
+            ji = len(table) // waves
+            if job.get("signal"):
+                assert all(e is not None for e in row) and [e["dst"] for e in row] == [row[0]["dst"] + cw * w for w in range(waves)], \
+                    "arrival counters: wave w produces columns [32 w, 32 w + 32)"
+                assert rs - width >= 8 and ji < 16, "the counters of job j live in the padding behind image row j"
+            if job.get("blockwise"):
+                assert jobs[ji - 1].get("signal") and all(e is None or e["ks"] == 16 for e in row)
             for wave, e in enumerate(row):
-                flags = (MLP_BARRIER if job["barrier"] else 0) | (MLP_STORE_HIDDEN if job["store_hidden"] else 0)
+                flags = (MLP_BARRIER if job["barrier"] else 0) | (MLP_STORE_HIDDEN if job["store_hidden"] else 0) | \
+                        (MLP_SIGNAL if job.get("signal") else 0) | (MLP_BLOCKWISE if job.get("blockwise") else 0)
+                producer = ji - 1 if job.get("blockwise") else 0
                 if e is None:
                     table.append(MlpJob(ks=0, src_off=0, dst_off=0, res_off=-1, bias_off=0, flags=flags, reserved0=pass_ks))
                     continue
@@ -616,7 +637,7 @@ class _FusedChain:
                     flags |= MLP_RELU
                 table.append(MlpJob(ks=e["ks"], src_off=e["src"], dst_off=e["dst"],
                                     res_off=-1 if e["res"] is None else e["res"], bias_off=bias_off, flags=flags,
-                                    reserved0=pass_ks))
+                                    reserved0=pass_ks, producer=producer))
         biases = torch.cat(bias_chunks)
         # the additive term of every output column, by action: the accumulators of the kernel START from a row of this table
         # (row A = the bias alone: what jobs without an action row take; row a < A = bias + the action's column of the first
@@ -723,7 +744,9 @@ class FusedRecurrent(_FusedChain):
             add_dense(w1s, b1, H, X, Y0, relu=True, barrier=False, act_w=w1a)
             add_dense(w2, b2, H, Y0, Y1, relu=True)
             add_dense(w3, b3, H, Y1, Y0, relu=True, res_off=X)
-            add_dense(torch.cat([wr1, wa1], 0), torch.cat([br1, ba1], 0), H, Y0, Z, relu=True, store_hidden=True)
+            # (the next hidden state, Y0, leaves for the pool behind the NEXT barrier -- S1's, Y0 is intact until S2 -- so that
+            # this layer's boundary, too, can be the blockwise one)
+            add_dense(torch.cat([wr1, wa1], 0), torch.cat([br1, ba1], 0), H, Y0, Z, relu=True)
             Tr, Ta, Tv = Z + 3 * h, E, Y0
             wr2, br2 = _fold(rw[3], rw[4])
             wa2, ba2 = _fold(ac[3].fc1, ac[3].bn1)
@@ -734,7 +757,7 @@ class FusedRecurrent(_FusedChain):
             wp4, bp4 = _fold(ac[4])
             R3, U, V3 = Z, Z + h, Z + 2 * h                 # reward logits | actor hidden | value logits
             self.add_stage([[(wv1, bv1, H, Y0, Z + 2 * h, True, None)],
-                            [(wr2, br2, h, Z, Tr, True, None), (wa2, ba2, h, Z + h, Ta, True, None)]])
+                            [(wr2, br2, h, Z, Tr, True, None), (wa2, ba2, h, Z + h, Ta, True, None)]], store_hidden=True)
             self.add_stage([[(wv2, bv2, h, Z + 2 * h, Tv, True, None), (wr3, br3, h, Tr, R3, False, None)],
                             [(wa3, ba3, h, Ta, U, True, Z + h)]])  # (in place: a lane reads the residual element it then overwrites)
             self.add_stage([[(wv3, bv3, h, Tv, V3, False, None)],
@@ -745,11 +768,11 @@ class FusedRecurrent(_FusedChain):
             add_dense(w1s, b1, H, X, Y0, relu=True, res_off=X, barrier=False, act_w=w1a)
             add_dense(w2, b2, H, Y0, Y1, relu=True)
             add_dense(w3, b3, H, Y1, Y0, relu=True)
-            add_dense(wh, bh, H, Y0, Z, relu=True, store_hidden=True)
+            add_dense(wh, bh, H, Y0, Z, relu=True)
             assert V <= 64 and A <= 64 and 2 * h <= 256
             kpad = 256                                      # K = h padded to 8 k-steps with zero weights
             outs = [(_fold(rw[3]), Z, X), (_fold(ac[3]), Z + h, X + 64), (_fold(va[3]), Z + 2 * h, X + 128)]
-            add_group([(w, b, src, dst, None, False) for (w, b), src, dst in outs], kpad)
+            add_group([(w, b, src, dst, None, False) for (w, b), src, dst in outs], kpad, store_hidden=True)  # (Y0 is still intact)
             off_r, off_p, off_v, width = X, X + 64, X + 128, 3 * H
         self._finish(width, in_width=H, hidden=H, state_off=X, hidden_off=Y0, off_r=off_r, off_v=off_v, off_p=off_p)
 

@@ -33,7 +33,17 @@ enum {
   HZ_MLP_RELU = 1,          /* ReLU in the epilogue */
   HZ_MLP_ACTION_ROW = 2,    /* start from action_table[action[row]] instead of action_table[num_actions] (first dynamics layer) */
   HZ_MLP_BARRIER = 4,       /* workgroup barrier before the job (layer boundary); same for the 4 waves of a job */
-  HZ_MLP_STORE_HIDDEN = 8   /* after that barrier copy LDS columns [hidden_off, hidden_off+hidden) to hidden_out */
+  HZ_MLP_STORE_HIDDEN = 8,  /* after that barrier copy LDS columns [hidden_off, hidden_off+hidden) to hidden_out */
+  /* 16 waves x 2 tiles only -- a layer boundary without a workgroup barrier.  A full-width layer (16 waves, wave w
+   * producing columns [32 w, 32 w + 32) of a 512-column output) whose jobs carry HZ_MLP_SIGNAL counts, per group of four
+   * waves, the waves that have written their columns: counter g of job j = the four waves 4 g .. 4 g + 3 = columns
+   * [128 g, 128 g + 128).  A job with HZ_MLP_BLOCKWISE (instead of HZ_MLP_BARRIER) reads exactly that output (16
+   * k-steps) and waits in front of every block of four k-steps until counter (block) of job `producer` says 4: a wave
+   * that is done with a layer starts the next one on the columns that exist already while the slower waves finish, so
+   * the weight stream does not stop at the boundary.  The counters live in the 16 B of padding behind image row j (row_stride
+   * - used width >= 8 elements, j < 16) and are cleared at the start of every inference. */
+  HZ_MLP_SIGNAL = 16,
+  HZ_MLP_BLOCKWISE = 32
 };
 
 /* One (job, wave) entry; all offsets are bf16-element columns of the LDS row image.  ks == 0: this wave idles.
@@ -45,7 +55,8 @@ typedef struct {
   int32_t res_off;   /* first residual column (added before the ReLU) or -1 */
   int32_t bias_off;  /* first of this job's columns in action_table rows (and in biases) */
   int32_t flags;
-  int32_t reserved0, reserved1;
+  int32_t reserved0;
+  int32_t producer;  /* HZ_MLP_BLOCKWISE: index of the job whose counters guard this job's input blocks */
 } hz_mlp_job_t;
 
 typedef struct {

@@ -80,5 +80,19 @@ def main():
     print("  end: %7d (last pass %.1f KB + final stage)" % (pp[33] - t_prev, prev_kb))
 
 
+    # per job: when each wave got past the barrier / started its k-loop / ended it / ended its epilogue (relative to the first wave past the barrier)
+    lib.hz_mlp_profile_read_timeline.argtypes = [V]
+    tl = np.zeros(16 * 8 * 4, np.uint32)
+    lib.hz_mlp_profile_read_timeline(tl.ctypes.data_as(V))
+    tl = tl.reshape(16, 8, 4).astype(np.int64)[:waves]
+    print("  per job (cycles after the first wave passed the job's barrier): barrier passed min..max | k-loop start min..max | k-loop end min..max | epilogue end min..max | next barrier released - last k-loop end")
+    for j in range(min(8, f.n_jobs)):
+        t0 = tl[:, j, 0].min()
+        nxt = tl[:, j + 1, 0].min() - tl[:, j, 2].max() if j + 1 < min(8, f.n_jobs) else -1
+        print("  job %d: %5d..%5d | %5d..%5d | %5d..%5d | %5d..%5d | %5d   k-loop per wave: %s" % (
+            j, tl[:, j, 0].min() - t0, tl[:, j, 0].max() - t0, tl[:, j, 1].min() - t0, tl[:, j, 1].max() - t0, tl[:, j, 2].min() - t0,
+            tl[:, j, 2].max() - t0, tl[:, j, 3].min() - t0, tl[:, j, 3].max() - t0, nxt, " ".join("%d" % x for x in (tl[:, j, 2] - tl[:, j, 1]))))
+
+
 if __name__ == "__main__":
     main()
