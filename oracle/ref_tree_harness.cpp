@@ -14,8 +14,9 @@
 //           returns hz_tiebreak_rand(seed, tree, sim, depth).  Trees are
 //           independent in the reference (the only loop-carried value,
 //           parent_q at cnode.cpp:414-423, is 0 whenever it is read), which
-//           tests/test_ref_equivalence.py checks by comparing mode 0 with a
-//           mode-1 run under the same rand()==0 stream (seed_mode_zero).
+//           tools/gen_golden.py::check_tree_equivalence asserts whenever the
+//           goldens are generated: mode 0 against mode 2 (= mode 1's N
+//           single-root CRoots under the rand()==0 stream of mode 0).
 //
 // Only tests/, tools/gen_golden.py and bench.py's cpu_baseline leg load this.
 #include <cstdint>
