@@ -199,6 +199,7 @@ __global__ __launch_bounds__(1024, 1) __attribute__((amdgpu_num_vgpr(HZ_ASMK_VGP
     unsigned long long t3 = SP_NOW();
     __syncthreads();  // leaf outputs visible; the row image is free again
     unsigned long long t4 = SP_NOW();
+    hz_tree_phase_prio();
     int lane_t = lane;  // (opaque: lane-derived values of the tree phase are recomputed per simulation, not spilled)
     asm volatile("" : "+v"(lane_t));
 #pragma unroll
@@ -291,6 +292,7 @@ __global__ __launch_bounds__(1024, 1) __attribute__((amdgpu_num_vgpr(HZ_ASMK_VGP
     const unsigned long long t3 = SP_NOW();
     __syncthreads();  // leaf outputs visible; the row image is free again
     const unsigned long long t4 = SP_NOW();
+    hz_tree_phase_prio();
     p_tree += t2 - t0; p_mlp += t3 - t2; p_wait2 += t4 - t3;
     t0 = t4;
     if (!any_mine) continue;

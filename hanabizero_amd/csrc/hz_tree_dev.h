@@ -126,6 +126,24 @@ struct TreeLocal {
   float leaf_logit;
 };
 
+// Issue priority of the tree phases inside the persistent search kernels.  The four waves of a SIMD share its issue port and
+// the sequencer serves the oldest first: with equal priorities the youngest wave of each SIMD needs 21 k cycles for a tree
+// phase the oldest gets through in 12 k (tools/search_profile.py), and the inference waits for the slowest tree.  Youngest
+// first is worth +0.5 % moves/s at 4096 envs (A/B on one box, tools/ab_multi.sh); priorities that grow with the depth of the
+// descent, alone or on top, are not (+0.1 % .. -0.3 %).
+#ifndef HZ_TREE_YOUNGEST_FIRST
+#define HZ_TREE_YOUNGEST_FIRST 1
+#endif
+__device__ __forceinline__ void hz_tree_phase_prio() {
+  if (!HZ_TREE_YOUNGEST_FIRST) return;
+  switch (__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8)) {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(3); break;
+  }
+}
+
 template <bool LOCAL = false>
 __device__ __forceinline__ void traverse_body(const TreeView& tv, int tree, int lane, int sim, float mn, float mx,
                                               int root_visit, const TraverseOut& to, bool have_root, float4 root_row,
