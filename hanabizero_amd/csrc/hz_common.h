@@ -82,14 +82,25 @@ __device__ __forceinline__ float hz_ordered_sum(float x, int n, float init) {
   return hz_readlane_f(acc, n - 1);
 }
 
-// max / min over the 64 lanes (callers mask with +-inf): 16-lane DPP butterflies, then the four row results
+// max / min over the 64 lanes (callers mask with +-inf; no NaNs): the classic GCN reduction, one DPP-modified v_max / v_min per
+// step -- four butterflies inside the 16-lane rows, row_bcast:15 and row_bcast:31 across them; lane 63 ends up with the result.
+// Hand-written because the compiler turns fmaxf(v, dpp(v)) into mov_dpp + a canonicalising max + the max (the tree phases of
+// the persistent search kernel are bound by instruction issue: four waves share a SIMD's port).  All 64 lanes must be active.
+#define HZ_WAVE_REDUCE(OP)                                                                                            \
+  asm volatile("s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"              \
+               OP " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"                            \
+               OP " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"                                \
+               OP " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"                                     \
+               OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"                                   \
+               OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"                                                   \
+               : "+v"(v))
 __device__ __forceinline__ float hz_wave_max(float v) {
-  v = hz_row16_max(v);
-  return fmaxf(fmaxf(hz_readlane_f(v, 0), hz_readlane_f(v, 16)), fmaxf(hz_readlane_f(v, 32), hz_readlane_f(v, 48)));
+  HZ_WAVE_REDUCE("v_max_f32_dpp");
+  return hz_readlane_f(v, 63);
 }
 __device__ __forceinline__ float hz_wave_min(float v) {
-  v = hz_row16_min(v);
-  return fminf(fminf(hz_readlane_f(v, 0), hz_readlane_f(v, 16)), fminf(hz_readlane_f(v, 32), hz_readlane_f(v, 48)));
+  HZ_WAVE_REDUCE("v_min_f32_dpp");
+  return hz_readlane_f(v, 63);
 }
 
 // ---- expf, bit-identical to glibc >= 2.27 expf (sysdeps/ieee754/flt-32/e_expf.c, the x86-64 FMA ifunc

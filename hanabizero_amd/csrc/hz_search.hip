@@ -28,6 +28,7 @@ struct SearchArgs {
   float* val;
   float* pol;
   int sims;                // simulations to run (S - 1, as the reference)
+  int ptab;                // 1: the launch reserved (S + 1)^2 floats of LDS behind the other arrays for SearchLds::ptab
 };
 
 // (The phases must be inlined into the kernel: through a real call the compiler loses the address space of every
@@ -46,6 +47,7 @@ struct SearchLds {
   float* lds_q;     // [16][S]    q cache, per tree, for the whole search
   int32_t* act_s;   // [16]
   uint64_t* exp_s;  // [32] hz_exp2f_tab
+  float* ptab;      // [S + 1][S + 1] (TreeLocal::ptab) where the workgroup's LDS has room for it (SearchArgs::ptab), else null
 };
 
 __device__ __forceinline__ TraverseOut search_traverse_out(const hz_mlp_header_t& H, const SearchArgs& a, const SearchLds& L,
@@ -166,7 +168,16 @@ __global__ __launch_bounds__(1024, 1) __attribute__((amdgpu_num_vgpr(HZ_ASMK_VGP
   L.path_s = reinterpret_cast<int32_t*>(L.prec_s + MT * (tv.S + 1));
   L.lds_q = reinterpret_cast<float*>(L.path_s + MT * (tv.S + 1));
   L.act_s = reinterpret_cast<int32_t*>(L.lds_q + MT * tv.S);
+  L.ptab = (a.ptab && tv.S < 64) ? reinterpret_cast<float*>(L.act_s + MT + 2) : nullptr;
   if (threadIdx.x < 32) L.exp_s[threadIdx.x] = hz_exp2f_tab[threadIdx.x];
+  if (L.ptab != nullptr) {  // (the operations, operand for operand, of traverse_body's own computation of this factor)
+    const int n1 = tv.S + 1;
+    for (int i = threadIdx.x; i < n1 * n1; i += 1024) {
+      const int pvc = i / n1, visit = i % n1;
+      const float sq = sqrtf((float)pvc + 1.0f);
+      L.ptab[i] = tv.pbc_tab[pvc] * (sq / (float)(visit + 1));
+    }
+  }
   TreeLocal tl[RT];
   bool mine[RT];
   RowFrag rows[RT];
@@ -176,6 +187,7 @@ __global__ __launch_bounds__(1024, 1) __attribute__((amdgpu_num_vgpr(HZ_ASMK_VGP
     const int srow = 16 * s + wave;
     mine[s] = row0 + srow < tv.N;
     tl[s].exp_tab = L.exp_s;
+    tl[s].ptab = L.ptab;
     tl[s].pbc_reg = (tv.S < 64 && lane <= tv.S) ? tv.pbc_tab[lane] : 0.0f;
     tl[s].sqrt_reg = sqrtf((float)lane + 1.0f);
     tl[s].path = L.path_s + srow * (tv.S + 1);
@@ -390,8 +402,12 @@ extern "C" int hz_search_run(hz_tree_t* t, int num_simulations, const hz_mlp_hea
            (size_t)(mt + 2) * sizeof(float) + 32 * 8 + 128 * sizeof(float) + 256;  // (+256: slack behind the last array)
   };
   if (rows_wg == 32 && lds_for(32) > 160 * 1024 && rows_per_workgroup == 0) rows_wg = 16;
-  const size_t lds_bytes = lds_for(rows_wg);
+  size_t lds_bytes = lds_for(rows_wg);
   HZ_REQUIRE(lds_bytes <= 160 * 1024, "hz_search_run: %zu B of LDS per workgroup exceed 160 KiB", lds_bytes);
+  // the table of exploration factors (TreeLocal::ptab) where it fits: the one-tree-per-wave kernels at 16 trees per workgroup
+  const size_t ptab_bytes = (size_t)(t->S + 1) * (t->S + 1) * sizeof(float);
+  const bool use_ptab = t->S < 64 && lds_bytes + ptab_bytes <= 160 * 1024;
+  if (use_ptab) lds_bytes += ptab_bytes;
   // two trees per tree-owning wave, side by side: the default with 32 trees per workgroup; with 16 only on request (-16) --
   // measured at 4096 envs: +1.4 % moves/s with random-init nets (mean path 2.2 edges), -12 % with a sharp policy (5.3 edges: a
   // half that has reached its leaf idles through the other's remaining levels)
@@ -400,6 +416,7 @@ extern "C" int hz_search_run(hz_tree_t* t, int num_simulations, const hz_mlp_hea
   a.jobs = jobs; a.wstream = (const uint16_t*)wstream; a.bias = biases; a.act_tab = action_table;
   a.pool = (uint16_t*)pool; a.plane_stride = plane_stride; a.row_stride = row_stride;
   a.ix = ix; a.iy = iy; a.la = la; a.rew = rewards; a.val = values; a.pol = policy; a.sims = num_simulations;
+  a.ptab = use_ptab ? 1 : 0;
 #define HZ_SEARCH_LAUNCH(VARIANT, KERNEL, GRID)                                                                       \
   do {                                                                                                                \
     if (lds_bytes > dev.configured[VARIANT]) {                                                                        \

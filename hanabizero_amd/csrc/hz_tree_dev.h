@@ -121,6 +121,10 @@ struct TreeLocal {
   bool publish;     // store this call's bookkeeping scalars (leaf entry, path length, root sums, min / max) to HBM: only
                     // the last descent's and the last backup's are ever read (the read-outs after the search)
   float pbc_reg, sqrt_reg;  // per-lane tables of the descent (pb_c's log factor, sqrt(n + 1)), loaded / computed once
+  const float* ptab;        // LDS, or null: [S + 1][S + 1] pb_c(parent visits) * (sqrt(parent visits + 1) / (visits + 1)), the
+                            // exploration factor of cnode.cpp:386 for every pair of counts a search can meet -- built once per
+                            // launch with the very operations the descent would use, so a level reads one word instead of
+                            // issuing two lane reads, a conversion, a correctly rounded division and a product
   const uint64_t* exp_tab;  // hz_exp2f_tab in LDS
   float leaf_reward, leaf_value;  // the leaf's outputs for the coming backup (uniform), and lane a's policy logit
   float leaf_logit;
@@ -196,9 +200,14 @@ __device__ __forceinline__ void traverse_body(const TreeView& tv, int tree, int 
     is_root = false;
     parent_q = mean_q;
     // cucb_score
-    float pb_c = tab_in_regs ? hz_readlane_f(pbc_reg, pvc) : tv.pbc_tab[pvc];  // logf((n+base+1)/base) + pb_c_init
-    const float sq = tab_in_regs ? hz_readlane_f(sqrt_reg, pvc) : sqrtf((float)pvc + 1.0f);
-    pb_c = pb_c * (sq / (float)(visit + 1));  // cnode.cpp:386
+    float pb_c;
+    if (LOCAL && tl->ptab != nullptr) {
+      pb_c = tl->ptab[pvc * (S + 1) + visit];
+    } else {
+      pb_c = tab_in_regs ? hz_readlane_f(pbc_reg, pvc) : tv.pbc_tab[pvc];  // logf((n+base+1)/base) + pb_c_init
+      const float sq = tab_in_regs ? hz_readlane_f(sqrt_reg, pvc) : sqrtf((float)pvc + 1.0f);
+      pb_c = pb_c * (sq / (float)(visit + 1));  // cnode.cpp:386
+    }
     const float prior_score = pb_c * prior;
     float vs = (visit == 0) ? mean_q : qsa;
     if (delta > 0.0f) vs = (vs - mn) / (delta < tv.delta ? tv.delta : delta);  // CMinMaxStats::normalize
