@@ -120,7 +120,7 @@ __device__ __forceinline__ RowFrag search_backup_descent(const TreeView& tv, con
   f.v[0] = f.v[1] = make_uint4(0u, 0u, 0u, 0u);
   if (lane == a0) root_row = first;  // the one record of the root's row this backup changed
   if (more) {
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // (measured: costs nothing)
+    // (the fence between this backup's stores and the descent's loads sits inside traverse_body, behind the root level)
     int entry;
     TP(5);
     tl.publish = sim + 2 == a.sims;  // the last descent
@@ -188,6 +188,7 @@ __global__ __launch_bounds__(1024, 1) __attribute__((amdgpu_num_vgpr(HZ_ASMK_VGP
     mine[s] = row0 + srow < tv.N;
     tl[s].exp_tab = L.exp_s;
     tl[s].ptab = L.ptab;
+    tl[s].lq = L.lds_q + srow * tv.S;
     tl[s].pbc_reg = (tv.S < 64 && lane <= tv.S) ? tv.pbc_tab[lane] : 0.0f;
     tl[s].sqrt_reg = sqrtf((float)lane + 1.0f);
     tl[s].path = L.path_s + srow * (tv.S + 1);

@@ -121,6 +121,7 @@ struct TreeLocal {
   bool publish;     // store this call's bookkeeping scalars (leaf entry, path length, root sums, min / max) to HBM: only
                     // the last descent's and the last backup's are ever read (the read-outs after the search)
   float pbc_reg, sqrt_reg;  // per-lane tables of the descent (pb_c's log factor, sqrt(n + 1)), loaded / computed once
+  const float* lq;          // LDS: this tree's q cache (backprop_body), [S]
   const float* ptab;        // LDS, or null: [S + 1][S + 1] pb_c(parent visits) * (sqrt(parent visits + 1) / (visits + 1)), the
                             // exploration factor of cnode.cpp:386 for every pair of counts a search can meet -- built once per
                             // launch with the very operations the descent would use, so a level reads one word instead of
@@ -171,17 +172,27 @@ __device__ __forceinline__ void traverse_body(const TreeView& tv, int tree, int 
   float parent_q = 0.0f;  // cnode.cpp:414 (0 whenever it is read, see oracle/ref_tree_harness.cpp)
   int depth = 0;
   int action = 0;
+  // the level's child records: the root's come in registers from the fused backup (have_root), a node's are requested at the
+  // end of the level above
+  float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (have_root) r = root_row;
+  else if (on) r = rec[lane];
   while (true) {
-    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (depth == 0 && have_root) r = root_row;  // already in registers (fused backup + descent)
-    else if (on) r = rec[(size_t)e * A + lane];
     const uint32_t w = __float_as_uint(r.w);
     const int visit = (int)(w >> 16);
     const int child = (int)(w & 0xffffu) - 1;
     float prior = r.x;
     if (prior != prior) prior = 0.0f;  // cnode.cpp:379-381
-    const float val = (visit == 0) ? 0.0f : r.y / (float)visit;  // CNode::value cnode.cpp:180-189
-    const float qsa = r.z + discount * val;
+    float qsa;
+    if (LOCAL) {
+      // reward + discount * value_sum / visits of a visited child is what the last backup over that edge left in the q cache
+      // (backprop_body: lq[child], same expression, same operands): one LDS word instead of a correctly rounded division
+      qsa = r.z + discount * 0.0f;
+      if (visit > 0) qsa = tl->lq[child];
+    } else {
+      const float val = (visit == 0) ? 0.0f : r.y / (float)visit;  // CNode::value cnode.cpp:180-189
+      qsa = r.z + discount * val;
+    }
     // get_mean_q: sum over visited children in action order
     uint64_t vm = __ballot(on && visit > 0);
     const int nvis = __popcll((unsigned long long)vm);
@@ -233,6 +244,10 @@ __device__ __forceinline__ void traverse_body(const TreeView& tv, int tree, int 
       action = __ffsll((unsigned long long)cand) - 1;
     }
     action = hz_uniform(action);
+    // LOCAL (persistent search kernel): the backup that ran just before this descent stored child records the next levels may
+    // load.  Its stores are waited for HERE -- a level's worth of work after they were issued, so the wait is over before it
+    // begins -- and before this level's own store goes out, which nothing below depends on.
+    if (LOCAL && depth == 0) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     if (lane == 0) {
       tv.best_action[(size_t)tree * S + e] = (int8_t)action;  // node->best_action (cnode.cpp:426)
       path[depth] = (e << 8) | action;
@@ -245,6 +260,8 @@ __device__ __forceinline__ void traverse_body(const TreeView& tv, int tree, int 
     if (child_e < 0 || depth >= S) break;  // leaf reached (second clause: defensive bound, never true)
     e = child_e;
     pvc = child_visit;
+    r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (on) r = rec[(size_t)e * A + lane];
   }
   if (lane == 0) {
     to.la[tree] = action;
