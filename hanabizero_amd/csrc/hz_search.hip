@@ -28,7 +28,7 @@ struct SearchArgs {
   float* val;
   float* pol;
   int sims;                // simulations to run (S - 1, as the reference)
-  int ptab;                // 1: the launch reserved (S + 1)^2 floats of LDS behind the other arrays for SearchLds::ptab
+  int ptab;                // 1: the launch reserved hz_ptab_words(S) floats of LDS behind the other arrays for SearchLds::ptab
 };
 
 // (The phases must be inlined into the kernel: through a real call the compiler loses the address space of every
@@ -47,7 +47,7 @@ struct SearchLds {
   float* lds_q;     // [16][S]    q cache, per tree, for the whole search
   int32_t* act_s;   // [16]
   uint64_t* exp_s;  // [32] hz_exp2f_tab
-  float* ptab;      // [S + 1][S + 1] (TreeLocal::ptab) where the workgroup's LDS has room for it (SearchArgs::ptab), else null
+  float* ptab;      // TreeLocal::ptab where the workgroup's LDS has room for it (SearchArgs::ptab), else null
 };
 
 __device__ __forceinline__ TraverseOut search_traverse_out(const hz_mlp_header_t& H, const SearchArgs& a, const SearchLds& L,
@@ -168,16 +168,9 @@ __global__ __launch_bounds__(1024, 1) __attribute__((amdgpu_num_vgpr(HZ_ASMK_VGP
   L.path_s = reinterpret_cast<int32_t*>(L.prec_s + MT * (tv.S + 1));
   L.lds_q = reinterpret_cast<float*>(L.path_s + MT * (tv.S + 1));
   L.act_s = reinterpret_cast<int32_t*>(L.lds_q + MT * tv.S);
-  L.ptab = (a.ptab && tv.S < 64) ? reinterpret_cast<float*>(L.act_s + MT + 2) : nullptr;
+  L.ptab = (a.ptab && tv.S < 64) ? reinterpret_cast<float*>(L.act_s + MT + 2) + 128 : nullptr;  // (behind the half kernels' tab_s)
   if (threadIdx.x < 32) L.exp_s[threadIdx.x] = hz_exp2f_tab[threadIdx.x];
-  if (L.ptab != nullptr) {  // (the operations, operand for operand, of traverse_body's own computation of this factor)
-    const int n1 = tv.S + 1;
-    for (int i = threadIdx.x; i < n1 * n1; i += 1024) {
-      const int pvc = i / n1, visit = i % n1;
-      const float sq = sqrtf((float)pvc + 1.0f);
-      L.ptab[i] = tv.pbc_tab[pvc] * (sq / (float)(visit + 1));
-    }
-  }
+  if (L.ptab != nullptr) hz_ptab_fill(L.ptab, tv.pbc_tab, tv.S, (int)threadIdx.x, 1024);
   TreeLocal tl[RT];
   bool mine[RT];
   RowFrag rows[RT];
@@ -251,6 +244,8 @@ __global__ __launch_bounds__(1024, 1) __attribute__((amdgpu_num_vgpr(HZ_ASMK_VGP
   L.lds_q = reinterpret_cast<float*>(L.path_s + MT * (tv.S + 1));
   L.act_s = reinterpret_cast<int32_t*>(L.lds_q + MT * tv.S);
   float* tab_s = reinterpret_cast<float*>(L.act_s + MT);  // the descent's tables: pb_c's log factor and sqrt(n + 1), n < 64
+  L.ptab = (a.ptab && tv.S < 64) ? reinterpret_cast<float*>(L.act_s + MT + 2) + 128 : nullptr;
+  if (L.ptab != nullptr) hz_ptab_fill(L.ptab, tv.pbc_tab, tv.S, (int)threadIdx.x, 1024);
   if (threadIdx.x < 32) L.exp_s[threadIdx.x] = hz_exp2f_tab[threadIdx.x];
   if (threadIdx.x < 64) {
     tab_s[threadIdx.x] = (tv.S < 64 && (int)threadIdx.x <= tv.S) ? tv.pbc_tab[threadIdx.x] : 0.0f;
@@ -286,7 +281,7 @@ __global__ __launch_bounds__(1024, 1) __attribute__((amdgpu_num_vgpr(HZ_ASMK_VGP
       mx = tv.mm_max[t.tree];
       if (q.l < tv.A) root_row = tv.rec[(size_t)t.tree * tv.S * tv.A + q.l];
     }
-    const int entry = traverse_half(tv, q, t, 0, mn, mx, root_row, tab_s, L.act_s + TW * q.h + wave, a.ix, a.iy,
+    const int entry = traverse_half(tv, q, t, 0, mn, mx, root_row, tab_s, L.ptab, L.act_s + TW * q.h + wave, a.ix, a.iy,
                                     a.sims == 1);
     if (t.mine) {
       const uint4* src = reinterpret_cast<const uint4*>(a.pool + ((size_t)entry * tv.N + t.tree) * (size_t)H.hidden);
@@ -332,7 +327,7 @@ __global__ __launch_bounds__(1024, 1) __attribute__((amdgpu_num_vgpr(HZ_ASMK_VGP
     rows.v[0] = rows.v[1] = make_uint4(0u, 0u, 0u, 0u);
     if (more) {
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-      const int entry = traverse_half(tv, q, t, sim + 1, mn, mx, root_row, tab_s, L.act_s + TW * q.h + wave, a.ix,
+      const int entry = traverse_half(tv, q, t, sim + 1, mn, mx, root_row, tab_s, L.ptab, L.act_s + TW * q.h + wave, a.ix,
                                       a.iy, sim + 2 == a.sims);
       if (t.mine) {
         const uint4* src = reinterpret_cast<const uint4*>(a.pool + ((size_t)entry * tv.N + t.tree) * (size_t)H.hidden);
@@ -405,8 +400,8 @@ extern "C" int hz_search_run(hz_tree_t* t, int num_simulations, const hz_mlp_hea
   if (rows_wg == 32 && lds_for(32) > 160 * 1024 && rows_per_workgroup == 0) rows_wg = 16;
   size_t lds_bytes = lds_for(rows_wg);
   HZ_REQUIRE(lds_bytes <= 160 * 1024, "hz_search_run: %zu B of LDS per workgroup exceed 160 KiB", lds_bytes);
-  // the table of exploration factors (TreeLocal::ptab) where it fits: the one-tree-per-wave kernels at 16 trees per workgroup
-  const size_t ptab_bytes = (size_t)(t->S + 1) * (t->S + 1) * sizeof(float);
+  // the table of exploration factors (TreeLocal::ptab, triangular: 5.3 KB at S = 50) where the workgroup's LDS has room for it
+  const size_t ptab_bytes = (size_t)(t->S + 1) * (t->S + 2) / 2 * sizeof(float);
   const bool use_ptab = t->S < 64 && lds_bytes + ptab_bytes <= 160 * 1024;
   if (use_ptab) lds_bytes += ptab_bytes;
   // two trees per tree-owning wave, side by side: the default with 32 trees per workgroup; with 16 only on request (-16) --

@@ -122,14 +122,30 @@ struct TreeLocal {
                     // the last descent's and the last backup's are ever read (the read-outs after the search)
   float pbc_reg, sqrt_reg;  // per-lane tables of the descent (pb_c's log factor, sqrt(n + 1)), loaded / computed once
   const float* lq;          // LDS: this tree's q cache (backprop_body), [S]
-  const float* ptab;        // LDS, or null: [S + 1][S + 1] pb_c(parent visits) * (sqrt(parent visits + 1) / (visits + 1)), the
-                            // exploration factor of cnode.cpp:386 for every pair of counts a search can meet -- built once per
-                            // launch with the very operations the descent would use, so a level reads one word instead of
+  const float* ptab;        // LDS, or null: pb_c(parent visits) * (sqrt(parent visits + 1) / (visits + 1)), the exploration
+                            // factor of cnode.cpp:386, for every pair of counts a search can meet (hz_ptab_index) -- built once
+                            // per launch with the very operations the descent would use, so a level reads one word instead of
                             // issuing two lane reads, a conversion, a correctly rounded division and a product
   const uint64_t* exp_tab;  // hz_exp2f_tab in LDS
   float leaf_reward, leaf_value;  // the leaf's outputs for the coming backup (uniform), and lane a's policy logit
   float leaf_logit;
 };
+
+// The table of exploration factors (TreeLocal::ptab) is triangular: a child has been visited at most as often as its parent
+// (every visit of the child is one of the parent; inactive lanes read visit 0), (S + 1)(S + 2) / 2 words.  (An index past a row's
+// end -- impossible while the counts are what the backups made them -- would read a neighbouring LDS word, not fault.)
+__device__ __forceinline__ int hz_ptab_index(int parent_visits, int visits) {
+  return ((parent_visits * (parent_visits + 1)) >> 1) + visits;
+}
+__device__ __forceinline__ int hz_ptab_words(int S) { return ((S + 1) * (S + 2)) >> 1; }
+__device__ __forceinline__ void hz_ptab_fill(float* ptab, const float* pbc_tab, int S, int tid, int nthreads) {
+  // (the operations, operand for operand, of traverse_body's own computation of this factor)
+  for (int pvc = 0; pvc <= S; ++pvc) {
+    const float sq = sqrtf((float)pvc + 1.0f);
+    const float pb = pbc_tab[pvc];
+    for (int visit = tid; visit <= pvc; visit += nthreads) ptab[hz_ptab_index(pvc, visit)] = pb * (sq / (float)(visit + 1));
+  }
+}
 
 // Issue priority of the tree phases inside the persistent search kernels.  The four waves of a SIMD share its issue port and
 // the sequencer serves the oldest first: with equal priorities the youngest wave of each SIMD needs 21 k cycles for a tree
@@ -213,7 +229,7 @@ __device__ __forceinline__ void traverse_body(const TreeView& tv, int tree, int 
     // cucb_score
     float pb_c;
     if (LOCAL && tl->ptab != nullptr) {
-      pb_c = tl->ptab[pvc * (S + 1) + visit];
+      pb_c = tl->ptab[hz_ptab_index(pvc, visit)];
     } else {
       pb_c = tab_in_regs ? hz_readlane_f(pbc_reg, pvc) : tv.pbc_tab[pvc];  // logf((n+base+1)/base) + pb_c_init
       const float sq = tab_in_regs ? hz_readlane_f(sqrt_reg, pvc) : sqrtf((float)pvc + 1.0f);

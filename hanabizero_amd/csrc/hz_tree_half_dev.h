@@ -30,14 +30,24 @@ __device__ __forceinline__ uint32_t hh_ballot(bool p, const HalfLane& q) {
   const uint64_t b = __ballot(p);
   return q.h ? (uint32_t)(b >> 32) : (uint32_t)b;
 }
+// max / min over the 32 lanes of each half (callers mask with +-inf; no NaNs): DPP-modified v_max / v_min -- four butterflies
+// inside the 16-lane rows, row_bcast:15 into the odd rows -- after which lanes 31 and 63 hold the halves' results
+// (hz_common.h::hz_wave_max has the reasons for writing it by hand).  All 64 lanes must be active.
+#define HH_HALF_REDUCE(OP)                                                                                            \
+  asm volatile("s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"              \
+               OP " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"                            \
+               OP " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"                                \
+               OP " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"                                     \
+               OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf"                                                   \
+               : "+v"(v))
 __device__ __forceinline__ float hh_max(float v, const HalfLane& q) {
-  v = hz_row16_max(v);
-  const float lo = fmaxf(hz_readlane_f(v, 0), hz_readlane_f(v, 16)), hi = fmaxf(hz_readlane_f(v, 32), hz_readlane_f(v, 48));
+  HH_HALF_REDUCE("v_max_f32_dpp");
+  const float lo = hz_readlane_f(v, 31), hi = hz_readlane_f(v, 63);
   return q.h ? hi : lo;
 }
 __device__ __forceinline__ float hh_min(float v, const HalfLane& q) {
-  v = hz_row16_min(v);
-  const float lo = fminf(hz_readlane_f(v, 0), hz_readlane_f(v, 16)), hi = fminf(hz_readlane_f(v, 32), hz_readlane_f(v, 48));
+  HH_HALF_REDUCE("v_min_f32_dpp");
+  const float lo = hz_readlane_f(v, 31), hi = hz_readlane_f(v, 63);
   return q.h ? hi : lo;
 }
 __device__ __forceinline__ int hh_any_max_i(int v) {  // max of the two halves' (per-half uniform) values: wave-uniform
@@ -90,7 +100,8 @@ struct HalfTree {
 // traverse_body<true> for two trees.  `publish` (uniform): store the bookkeeping scalars the read-outs use.
 // Returns this half's leaf parent entry; its action goes to *la_slot (LDS, per half).
 __device__ __forceinline__ int traverse_half(const TreeView& tv, const HalfLane& q, HalfTree& t, int sim, float mn, float mx,
-                                             float4 root_row, const float* tab /* LDS: [64] pb_c log factors, [64] sqrt(n + 1) */, int32_t* la_slot, int32_t* ix,
+                                             float4 root_row, const float* tab /* LDS: [64] pb_c log factors, [64] sqrt(n + 1) */,
+                                             const float* ptab /* LDS or null: hz_ptab_index */, int32_t* la_slot, int32_t* ix,
                                              int32_t* iy, bool publish) {
   const int A = tv.A, S = tv.S;
   const bool on = q.l < A;
@@ -101,17 +112,17 @@ __device__ __forceinline__ int traverse_half(const TreeView& tv, const HalfLane&
   bool is_root = true, active = t.mine;
   float parent_q = 0.0f;
   int leaf_e = 0, leaf_action = 0, leaf_depth = 1;
+  float4 r = root_row;  // a level's child records: the root's in registers, a node's requested at the end of the level above
   while (true) {
-    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (depth == 0) r = root_row;
-    else if (on && active) r = rec[(size_t)e * A + q.l];
     const uint32_t w = __float_as_uint(r.w);
     const int visit = (int)(w >> 16);
     const int child = (int)(w & 0xffffu) - 1;
     float prior = r.x;
     if (prior != prior) prior = 0.0f;
-    const float val = (visit == 0) ? 0.0f : r.y / (float)visit;
-    const float qsa = r.z + discount * val;
+    // reward + discount * value_sum / visits of a visited child = what the last backup over that edge left in the q cache
+    // (backprop_half: t.lq[child], same expression, same operands): an LDS word instead of a correctly rounded division
+    float qsa = r.z + discount * 0.0f;
+    if (visit > 0) qsa = t.lq[child];
     const bool vis = on && visit > 0;
     const uint32_t vm = hh_ballot(vis, q);
     const int nvis = __popc(vm);
@@ -136,9 +147,14 @@ __device__ __forceinline__ int traverse_half(const TreeView& tv, const HalfLane&
     is_root = false;
     parent_q = mean_q;
     const bool tab_in_regs = S < 64;
-    float pb_c = tab_in_regs ? tab[pvc] : tv.pbc_tab[pvc];
-    const float sq = tab_in_regs ? tab[64 + pvc] : sqrtf((float)pvc + 1.0f);
-    pb_c = pb_c * (sq / (float)(visit + 1));
+    float pb_c;
+    if (ptab != nullptr) {
+      pb_c = ptab[hz_ptab_index(pvc, visit)];
+    } else {
+      pb_c = tab_in_regs ? tab[pvc] : tv.pbc_tab[pvc];
+      const float sq = tab_in_regs ? tab[64 + pvc] : sqrtf((float)pvc + 1.0f);
+      pb_c = pb_c * (sq / (float)(visit + 1));
+    }
     const float prior_score = pb_c * prior;
     float vs = (visit == 0) ? mean_q : qsa;
     if (delta > 0.0f) vs = (vs - mn) / (delta < tv.delta ? tv.delta : delta);
@@ -181,6 +197,8 @@ __device__ __forceinline__ int traverse_half(const TreeView& tv, const HalfLane&
       pvc = child_visit;
     }
     if (__ballot(active) == 0) break;
+    r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (on && active) r = rec[(size_t)e * A + q.l];
   }
   if (q.l == 0 && t.mine) {
     *la_slot = leaf_action;
