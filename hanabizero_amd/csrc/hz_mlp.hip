@@ -70,6 +70,7 @@ extern "C" int hz_mlp_recurrent(const hz_mlp_header_t* H, const hz_mlp_job_t* jo
   HZ_REQUIRE(H->kstep_stride >= 512 * H->tiles_per_wave && H->kstep_stride % 8 == 0,
              "hz_mlp_recurrent: kstep_stride must be a multiple of 8 and at least one k-step (512 * tiles_per_wave)");
   HZ_REQUIRE(H->in_width > 0 && H->in_width % 8 == 0, "hz_mlp_recurrent: in_width must be a positive multiple of 8");
+  HZ_REQUIRE(H->num_waves != 16 || H->hidden <= 512, "hz_mlp_recurrent: the 16 x 2 shape stores a hidden state of <= 512 columns");
 #ifdef HZ_MLP_PROFILE
   const size_t lds_bytes = (size_t)rows_per_wg * H->row_stride * sizeof(uint16_t) + 2048;  // + the per-wave timeline
 #else

@@ -49,18 +49,26 @@ struct ElF16 {
 };
 
 // inverse_scalar_transform of LDS rows of EL logits, one (row, head) pair per 32-lane half of the wave: lane l32
-// owns logits [8*l32, 8*l32 + 8) (one ds_read_b128), DPP reductions inside each 16-lane row, one cross-row exchange;
-// V <= 256.  Same maths as hz_tree.hip support_to_scalar.
-// (the cross-row step through readlane + select, not a ds_bpermute round trip: row0 op row1 for lanes 0-31, row2 op row3
-// for lanes 32-63)
+// owns logits [8*l32, 8*l32 + 8) (one ds_read_b128; Hanabi-Full's supports have 201 bins), max and sums over the half by
+// DPP-modified v_max / v_add (hz_common.h::hz_wave_max has the reasons): butterflies inside the 16-lane rows, row_bcast:15
+// into the odd rows, lanes 31 / 63 hold the halves' results.  V <= 256.  Same maths as hz_tree.hip support_to_scalar.
+// (Tried: one logit per lane and trip, ceil(V / 32) trips -- fewer instructions for small V, 1.7 % slower end to end at
+// V = 201: the loops.)
+#define HZ_HALF32_REDUCE(OP)                                                                                          \
+  asm volatile("s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"              \
+               OP " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"                            \
+               OP " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"                                \
+               OP " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"                                     \
+               OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf"                                                   \
+               : "+v"(v))
 __device__ __forceinline__ float half32_max(float v) {
-  v = hz_row16_max(v);
-  const float lo = fmaxf(hz_readlane_f(v, 0), hz_readlane_f(v, 16)), hi = fmaxf(hz_readlane_f(v, 32), hz_readlane_f(v, 48));
+  HZ_HALF32_REDUCE("v_max_f32_dpp");
+  const float lo = hz_readlane_f(v, 31), hi = hz_readlane_f(v, 63);
   return (threadIdx.x & 32) ? hi : lo;
 }
 __device__ __forceinline__ float half32_sum(float v) {
-  v = hz_row16_sum(v);
-  const float lo = hz_readlane_f(v, 0) + hz_readlane_f(v, 16), hi = hz_readlane_f(v, 32) + hz_readlane_f(v, 48);
+  HZ_HALF32_REDUCE("v_add_f32_dpp");
+  const float lo = hz_readlane_f(v, 31), hi = hz_readlane_f(v, 63);
   return (threadIdx.x & 32) ? hi : lo;
 }
 template <class EL>

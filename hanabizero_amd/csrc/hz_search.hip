@@ -400,6 +400,8 @@ extern "C" int hz_search_run(hz_tree_t* t, int num_simulations, const hz_mlp_hea
   if (rows_wg == 32 && lds_for(32) > 160 * 1024 && rows_per_workgroup == 0) rows_wg = 16;
   size_t lds_bytes = lds_for(rows_wg);
   HZ_REQUIRE(lds_bytes <= 160 * 1024, "hz_search_run: %zu B of LDS per workgroup exceed 160 KiB", lds_bytes);
+  HZ_REQUIRE(t->S < 64 && H->hidden <= 512, "hz_search_run: the persistent kernels are written for < 64 simulations and hidden <= 512 "
+                                            "(got %d, %d): run the launch-per-phase search", t->S, H->hidden);
   // the table of exploration factors (TreeLocal::ptab, triangular: 5.3 KB at S = 50) where the workgroup's LDS has room for it
   const size_t ptab_bytes = (size_t)(t->S + 1) * (t->S + 2) / 2 * sizeof(float);
   const bool use_ptab = t->S < 64 && lds_bytes + ptab_bytes <= 160 * 1024;

@@ -178,7 +178,7 @@ __device__ __forceinline__ void traverse_body(const TreeView& tv, int tree, int 
   float4* prec = LOCAL ? tl->prec : tv.prec + (size_t)tree * (S + 1);
   // pb_c's first factor for every possible parent visit count, one per lane (S + 1 <= 64: no dependent table load
   // on the critical path of a level); larger S falls back to the table in memory
-  const bool tab_in_regs = S < 64;
+  const bool tab_in_regs = LOCAL || S < 64;  // (LOCAL: S < 64 is hz_search_run's condition -- no code for more in the persistent kernel)
   const float pbc_reg = LOCAL ? tl->pbc_reg : ((tab_in_regs && lane <= S) ? tv.pbc_tab[lane] : 0.0f);
   const float sqrt_reg = LOCAL ? tl->sqrt_reg : sqrtf((float)lane + 1.0f);  // sqrt(parent visits + 1), same trick
 
@@ -446,7 +446,9 @@ __device__ __forceinline__ void backprop_body(const TreeView& tv, int tree, int 
   TP(2);
   int pr = 0;
   float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int base = ((npairs - 1) >> 6) << 6; base >= 0; base -= 64) {
+  // (LOCAL: S < 64, the path fits one chunk -- and the persistent kernel's simulation loop holds no loop that is not needed:
+  // see row32_support_to_scalar in hz_mlp_dev.h for what a loop costs there)
+  for (int base = LOCAL ? 0 : (((npairs - 1) >> 6) << 6); base >= 0; base -= 64) {
     const int k = base + lane;
     const bool act = k < npairs;
     if (base == 0) {
@@ -501,11 +503,19 @@ __device__ __forceinline__ void backprop_body(const TreeView& tv, int tree, int 
   }
   // min_max_stats.clear(); update_tree_q(root): every expanded non-root node contributes (cnode.cpp:332-334)
   float vmax = -INFINITY, vmin = INFINITY;
-  for (int e = 1 + lane; e <= e_new; e += 64) {
-    const float q = lq[e];  // same-wave LDS traffic is processed in order: sees the stores above
+  if (LOCAL) {  // (e_new <= S < 64: one entry per lane)
+    const float q = 1 + lane <= e_new ? lq[1 + lane] : __builtin_nanf("");  // same-wave LDS traffic is processed in order
     if (q == q) {
-      vmax = fmaxf(vmax, q);
-      vmin = fminf(vmin, q);
+      vmax = q;
+      vmin = q;
+    }
+  } else {
+    for (int e = 1 + lane; e <= e_new; e += 64) {
+      const float q = lq[e];  // same-wave LDS traffic is processed in order: sees the stores above
+      if (q == q) {
+        vmax = fmaxf(vmax, q);
+        vmin = fminf(vmin, q);
+      }
     }
   }
   out_mx = fmaxf(hz_wave_max(vmax), HZ_FLOAT_MIN);  // CMinMaxStats::update from the cleared state (cminimax.cpp:17-29)

@@ -46,7 +46,11 @@ class MCTS(object):
                 val = torch.empty(num, dtype=torch.float32, device=roots.device)
                 pol = torch.empty((num, roots.action_num), dtype=torch.float32, device=roots.device)
                 fused16 = model.fused_shape(16, 2) if self.persistent else None
-                if fused16 is not None and fused16.lds_bytes(16) + 16 * (24 * (S + 1) + 4 * roots.action_num + 16) + 512 <= 160 * 1024:
+                # (the persistent kernels are written for < 64 simulations -- the reference's configs have 50 -- with no loops over
+                # more in their simulation loop: include/hz_search.h; beyond that the launch-per-phase search below computes the
+                # same bits)
+                if fused16 is not None and S < 64 and \
+                        fused16.lds_bytes(16) + 16 * (24 * (S + 1) + 4 * roots.action_num + 16) + 512 <= 160 * 1024:
                     # the whole loop below as ONE persistent kernel: a workgroup keeps 16 trees for all simulations
                     roots.search_tensors(fused16, pool, S - 1, rew, val, pol, self.rows_per_workgroup)
                     return
