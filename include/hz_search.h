@@ -36,6 +36,9 @@ extern "C" {
  *                  one after the other; -16 = 16 trees per workgroup side by side on 8 of the 16 wavefronts (measured: no
  *                  faster than one per wavefront, slower on deep paths).  The results do not depend on any of it.
  * The MLP header's dtype (HZ_BF16 / HZ_F16) selects the element format of pool, weights and activations.
+ * Limits (HZ_ERR otherwise -- the launch-per-phase calls of hz_tree.h / hz_mlp.h have none of them and compute the same
+ * bits): fewer than 64 simulations per tree (t's S; the reference's configs have 50), hidden <= 512, support_size <= 256,
+ * 160 KiB of LDS for 16 (or 32) row images + search state.
  * The calling thread's current device must be the tree's. */
 int hz_search_run(hz_tree_t* t, int num_simulations, const hz_mlp_header_t* H, const hz_mlp_job_t* jobs,
                   const void* wstream, const float* biases, const float* action_table, void* pool,
