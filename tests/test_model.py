@@ -240,6 +240,43 @@ def test_fused_mfma_kernel_workgroup_shapes_give_identical_bits(game, shape, dty
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("game", ["Hanabi-Small", "Hanabi-Full"])
+@pytest.mark.parametrize("rows", [16, 32])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_blockwise_layer_boundaries_equal_barriers(game, rows, dtype, monkeypatch):
+    """16 x 2 chains with HZ_MLP_SIGNAL / HZ_MLP_BLOCKWISE jobs (per-block arrival counters instead of a workgroup barrier
+    between full-width layers, include/hz_mlp.h) against the same chain cut with barriers only: the same bits, and the
+    job table really carries the flags."""
+    import ctypes
+    from hanabizero_amd._lib import MlpJob
+    from hanabizero_amd.model import FusedRecurrent, InferenceEngine, MLP_BLOCKWISE, MLP_SIGNAL
+    net, fx, sup = build(game)
+    eng = InferenceEngine(net, sup, dtype=dtype, device="cuda")
+    N, S = 1000, 4
+    g = torch.Generator(device="cuda").manual_seed(11)
+    pool = (torch.rand(S, N, eng.H, device="cuda", generator=g) * 2).to(dtype)
+    ix = torch.randint(0, S, (N,), device="cuda", generator=g).to(torch.int32)
+    act = torch.randint(0, eng.A, (N,), device="cuda", generator=g).to(torch.int32)
+    outs, flags = [], []
+    for blockwise in ("1", "0"):
+        monkeypatch.setenv("HANABIZERO_MLP_BLOCKWISE", blockwise)
+        f = FusedRecurrent(net, eng, 16, 2)
+        raw = f.jobs.cpu().numpy().tobytes()
+        tab = (MlpJob * (len(raw) // ctypes.sizeof(MlpJob))).from_buffer_copy(raw)
+        flags.append([tab[j * 16].flags for j in range(f.n_jobs)])
+        h = torch.zeros(N, eng.H, dtype=dtype, device="cuda")
+        r, v, p = torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda"), torch.zeros(N, eng.A, device="cuda")
+        for _ in range(3):  # (the counters are cleared per launch: a second and third launch must not see stale ones)
+            f(pool, ix, act, h, r, v, p, rows_per_wg=rows)
+        outs.append((h, r, v, p))
+    torch.cuda.synchronize()
+    assert sum(1 for x in flags[0] if x & MLP_BLOCKWISE) >= 2 and any(x & MLP_SIGNAL for x in flags[0])
+    assert not any(x & (MLP_BLOCKWISE | MLP_SIGNAL) for x in flags[1])
+    for a, b in zip(*outs):
+        assert torch.equal(a.view(torch.int16) if a.dtype != torch.float32 else a, b.view(torch.int16) if b.dtype != torch.float32 else b)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("N", [100, 4096])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_fused_initial_tail_matches_gemm_path(N, dtype):

@@ -255,6 +255,34 @@ def test_persistent_search_kernel_equals_launch_per_phase(game, N, sims, peaked,
         assert int(a[4].max()) > 34, int(a[4].max())  # runs in two chunks (in fp16 the 49-deep chain of random nets turns NaN first)
 
 
+def test_persistent_search_limits_fall_back_to_launch_per_phase():
+    """hz_search_run refuses 64 or more simulations (include/hz_search.h); MCTS.run_multi then runs the launch-per-phase
+    search, whose results are what they would have been."""
+    from hanabizero_amd import cytree
+    from hanabizero_amd._lib import HzError
+    from hanabizero_amd.mcts import MCTS
+    sims, N = 70, 48
+    cfg, eng, actor = make("Hanabi-Small", N, sims, 2, torch.bfloat16, use_graph=False)
+    A = cfg.action_space_size
+    value0, logits0, hidden0 = actor.root_inference()
+    noise = torch.full((N, A), 1.0 / A, device="cuda")
+    res = []
+    for persistent in (True, False):
+        roots = cytree.Roots(N, A, sims, tie_seed=3)
+        roots.prepare(cfg.root_exploration_fraction, noise, torch.zeros(N, device="cuda"), logits0, actor.legal)
+        MCTS(cfg, persistent=persistent).run_multi(roots, eng, hidden0)
+        res.append(roots.distributions_tensor())
+    assert torch.equal(res[0], res[1]) and int(res[0].sum()) == N * (sims - 1)
+    roots = cytree.Roots(N, A, sims, tie_seed=3)
+    roots.prepare(cfg.root_exploration_fraction, noise, torch.zeros(N, device="cuda"), logits0, actor.legal)
+    roots.set_params(cfg.pb_c_base, cfg.pb_c_init, cfg.discount, cfg.value_delta_max)
+    pool = torch.zeros(sims, N, eng.H, dtype=eng.dtype, device="cuda")
+    pool[0].copy_(hidden0)
+    rew, val, pol = torch.empty(N, device="cuda"), torch.empty(N, device="cuda"), torch.empty(N, A, device="cuda")
+    with pytest.raises(HzError, match="64 simulations"):
+        roots.search_tensors(eng.fused_shape(16, 2), pool, sims - 1, rew, val, pol, 0)
+
+
 def test_packed_drain_equals_drain():
     """drain_packed (one ragged byte buffer that stays on the device, hz_actor_pack) carries exactly the games drain()
     returns, and the host-side packer (pack_records) produces the same bytes section by section."""
