@@ -427,8 +427,24 @@ __device__ __forceinline__ void mlp_body(
 #endif
     }
     const unsigned long long p_j0 = PROF_NOW();
-    if ((J.flags & HZ_MLP_BARRIER) || (!(BW && ASMK) && (J.flags & HZ_MLP_BLOCKWISE)))
+    if ((J.flags & HZ_MLP_BARRIER) || (!(BW && ASMK) && (J.flags & (HZ_MLP_BLOCKWISE | HZ_MLP_WAITS))))
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // LDS only: loads stay in flight
+    if constexpr (BW && ASMK) {
+      if (J.flags & HZ_MLP_WAITS) {  // this job's own dependencies instead of a barrier (include/hz_mlp.h; hanabizero_amd/mlp_sync.py)
+        unsigned int tok = (unsigned int)J.producer;
+        const unsigned int img = (unsigned int)(uintptr_t)(__attribute__((address_space(3))) const uint16_t*)lds;
+        for (int k = (J.flags >> 8) & 7; k > 0; --k, tok >>= 8) {
+          unsigned int fa2 = img + 2u * (((tok >> 4) & 15u) * (unsigned int)rs + (unsigned int)(rs - 8)) + 4u * ((tok >> 2) & 3u);
+          unsigned int want = (tok & 3u) + 1u, pc2 = 1u << 22, pt2, ps2;
+          asm volatile("2:\n\tds_read_b32 %[pt], %[fa]\n\ts_waitcnt lgkmcnt(0)\n\tv_readfirstlane_b32 %[ps], %[pt]\n\ts_nop 3\n\t"
+                       "s_cmp_ge_u32 %[ps], %[want]\n\ts_cbranch_scc1 3f\n\ts_sleep 1\n\ts_sub_u32 %[pc], %[pc], 1\n\t"
+                       "s_cmp_lg_u32 %[pc], 0\n\ts_cbranch_scc1 2b\n\t3:"
+                       : [pt] "=&v"(pt2), [ps] "=&s"(ps2), [pc] "+s"(pc2)
+                       : [fa] "v"(fa2), [want] "s"(want)
+                       : "memory", "scc");
+        }
+      }
+    }
     if (J.flags & HZ_MLP_STORE_HIDDEN) {
       const int chunks = H.hidden / 8;
       for (int i = tid; i < MT * chunks; i += NTHR) {

@@ -483,7 +483,7 @@ class InferenceEngine:
 
 
 # ------------------------------------------------------------------------------------------------ fused MFMA kernel
-MLP_RELU, MLP_ACTION_ROW, MLP_BARRIER, MLP_STORE_HIDDEN, MLP_SIGNAL, MLP_BLOCKWISE = 1, 2, 4, 8, 16, 32  # include/hz_mlp.h flags
+MLP_RELU, MLP_ACTION_ROW, MLP_BARRIER, MLP_STORE_HIDDEN, MLP_SIGNAL, MLP_BLOCKWISE, MLP_WAITS = 1, 2, 4, 8, 16, 32, 64  # include/hz_mlp.h flags
 
 
 def _pack_fragments(wblk, ks, tiles=4):
@@ -596,9 +596,9 @@ class _FusedChain:
         # should carry the same share of it and none should idle through whole layers)
         table = []
         load = [0] * waves
+        rows = []
         for job in jobs:
             ents = [e for e in job["entries"] if e is not None]
-            pass_ks = max(e["ks"] for e in ents)
             if job.get("fixed"):  # add_stage: the entries sit on the waves of their lane
                 row = list(job["entries"])
                 for w, e in enumerate(row):
@@ -609,20 +609,45 @@ class _FusedChain:
                 for w, e in zip(sorted(order), ents):
                     row[w] = e
                     load[w] += e["ks"]
-                assert all(e["ks"] == pass_ks for e in ents), "jobs of one pass share their K"
-            ji = len(table) // waves
+                assert all(e["ks"] == ents[0]["ks"] for e in ents), "jobs of one pass share their K"
+            rows.append(row)
+        # synchronisation between the passes: barriers, except -- 16 x 2 shape -- blockwise boundaries (decided in add_dense)
+        # and per-job waits (decided here from the jobs' column ranges, and proven race-free: mlp_sync)
+        pass_flags = [(MLP_BARRIER if job["barrier"] else 0) | (MLP_STORE_HIDDEN if job["store_hidden"] else 0) |
+                      (MLP_BLOCKWISE if job.get("blockwise") else 0) for job in jobs]
+        tokens = [[[] for _ in range(waves)] for _ in jobs]
+        signal_passes = {ji for ji, job in enumerate(jobs) if job.get("signal")}
+        if self.blockwise and os.environ.get("HANABIZERO_MLP_WAITS", "1") != "0" and len(jobs) <= 16 and rs - width >= 8:
+            from . import mlp_sync
+            sj = []
+            for ji, (job, row) in enumerate(zip(jobs, rows)):
+                hid = [(hidden_off, hidden_off + hidden)] if job["store_hidden"] else []
+                sj.append([mlp_sync.Job(reads=hid, active=False) if e is None else
+                           mlp_sync.Job(reads=[(e["src"], e["src"] + 32 * e["ks"])] + hid +
+                                        ([] if e["res"] is None else [(e["res"], e["res"] + cw)]),
+                                        writes=[(e["dst"], e["dst"] + cw)]) for e in row])
+            pass_flags, sig = mlp_sync.plan(pass_flags, sj, waves)
+            signal_passes |= set(sig)
+            tokens = [[j.tokens for j in r] for r in sj]
+        for ji, (job, row) in enumerate(zip(jobs, rows)):
+            pass_ks = max(e["ks"] for e in row if e is not None)
             if job.get("signal"):
                 assert all(e is not None for e in row) and [e["dst"] for e in row] == [row[0]["dst"] + cw * w for w in range(waves)], \
                     "arrival counters: wave w produces columns [32 w, 32 w + 32)"
+            if ji in signal_passes:
                 assert rs - width >= 8 and ji < 16, "the counters of job j live in the padding behind image row j"
             if job.get("blockwise"):
                 assert jobs[ji - 1].get("signal") and all(e is None or e["ks"] == 16 for e in row)
             for wave, e in enumerate(row):
-                flags = (MLP_BARRIER if job["barrier"] else 0) | (MLP_STORE_HIDDEN if job["store_hidden"] else 0) | \
-                        (MLP_SIGNAL if job.get("signal") else 0) | (MLP_BLOCKWISE if job.get("blockwise") else 0)
+                flags = pass_flags[ji] | (MLP_SIGNAL if ji in signal_passes else 0)
                 producer = ji - 1 if job.get("blockwise") else 0
+                if pass_flags[ji] & MLP_WAITS:
+                    from .mlp_sync import pack_tokens
+                    nt, producer = pack_tokens(tokens[ji][wave])
+                    flags |= nt << 8
                 if e is None:
-                    table.append(MlpJob(ks=0, src_off=0, dst_off=0, res_off=-1, bias_off=0, flags=flags, reserved0=pass_ks))
+                    table.append(MlpJob(ks=0, src_off=0, dst_off=0, res_off=-1, bias_off=0, flags=flags, reserved0=pass_ks,
+                                        producer=producer))
                     continue
                 assert e["ks"] % 8 == 0, "K must be a multiple of 256 (8 k-steps)"
                 streams[wave].append(_pack_fragments(e["w"], e["ks"], tiles))

@@ -43,7 +43,16 @@ enum {
    * the weight stream does not stop at the boundary.  The counters live in the 16 B of padding behind image row j (row_stride
    * - used width >= 8 elements, j < 16) and are cleared at the start of every inference. */
   HZ_MLP_SIGNAL = 16,
-  HZ_MLP_BLOCKWISE = 32
+  HZ_MLP_BLOCKWISE = 32,
+  /* 16 waves x 2 tiles only -- a pass that begins with neither: before it starts, a job waits for up to four arrival counters
+   * (tokens), the ones of the jobs its own columns depend on: writers of what it reads, readers and writers of what it
+   * writes.  Token count = bits 8..10 of flags; token k = byte k of `producer`: pass << 4 | group << 2 | (count - 1) -- wait
+   * until counter `group` of job `pass` says `count` (the jobs of that pass carry HZ_MLP_SIGNAL; an idle entry signals
+   * nothing, so count = the group's entries with ks != 0).  The flag is the same for the 16 entries of a pass (a kernel
+   * without the counters runs a workgroup barrier there instead); tokens are per entry, idle entries may have some (the
+   * hidden-state store reads columns too).  hanabizero_amd/mlp_sync.py derives the tokens from the jobs' column ranges and
+   * proves the table race-free. */
+  HZ_MLP_WAITS = 64
 };
 
 /* One (job, wave) entry; all offsets are bf16-element columns of the LDS row image.  ks == 0: this wave idles.
@@ -56,7 +65,7 @@ typedef struct {
   int32_t bias_off;  /* first of this job's columns in action_table rows (and in biases) */
   int32_t flags;
   int32_t reserved0;
-  int32_t producer;  /* HZ_MLP_BLOCKWISE: index of the job whose counters guard this job's input blocks */
+  int32_t producer;  /* HZ_MLP_BLOCKWISE: index of the job whose counters guard this job's input blocks; HZ_MLP_WAITS: tokens */
 } hz_mlp_job_t;
 
 typedef struct {

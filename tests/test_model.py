@@ -239,6 +239,56 @@ def test_fused_mfma_kernel_workgroup_shapes_give_identical_bits(game, shape, dty
         assert torch.equal(a, b)
 
 
+def _job_table(chain):
+    import ctypes
+    from hanabizero_amd._lib import MlpJob
+    raw = (chain._host["jobs"] if chain._host is not None else chain.jobs.cpu()).numpy().tobytes()
+    return (MlpJob * (len(raw) // ctypes.sizeof(MlpJob))).from_buffer_copy(raw)
+
+
+@pytest.mark.parametrize("game", ["Hanabi-Small", "Hanabi-Full"])
+def test_job_table_synchronisation_is_proven_and_the_proof_notices_a_missing_wait(game):
+    """hanabizero_amd/mlp_sync.py: the 16 x 2 chain of the recurrent inference ends up with no workgroup barrier between its
+    passes (blockwise boundaries + per-job waits); the checker accepts the table as built, and rejects it as soon as one
+    token is taken away or a blockwise pass is declared to need nothing."""
+    from hanabizero_amd import mlp_sync
+    from hanabizero_amd.model import FusedRecurrent, InferenceEngine, MLP_BARRIER, MLP_BLOCKWISE, MLP_STORE_HIDDEN, MLP_WAITS
+    net, fx, sup = build(game)
+    eng = InferenceEngine(net, sup, dtype=torch.bfloat16, device="cpu", fused=False)
+    f = FusedRecurrent(net, eng, 16, 2, host_only=True)
+    tab, P = _job_table(f), f.n_jobs
+    flags = [tab[p * 16].flags for p in range(P)]
+    assert not any(x & MLP_BARRIER for x in flags), flags
+    assert sum(1 for x in flags if x & MLP_BLOCKWISE) == 3 and any(x & MLP_WAITS for x in flags)
+    cw, H = 32, eng.H
+    jobs = []
+    for p in range(P):
+        hid = [(f.header.hidden_off, f.header.hidden_off + H)] if flags[p] & MLP_STORE_HIDDEN else []
+        row = []
+        for w in range(16):
+            e = tab[p * 16 + w]
+            j = mlp_sync.Job(reads=hid, active=False) if e.ks == 0 else mlp_sync.Job(
+                reads=[(e.src_off, e.src_off + 32 * e.ks)] + hid + ([] if e.res_off < 0 else [(e.res_off, e.res_off + cw)]),
+                writes=[(e.dst_off, e.dst_off + cw)])
+            if flags[p] & MLP_WAITS:
+                nt = (e.flags >> 8) & 7
+                j.tokens = [(((e.producer >> (8 * k)) >> 4) & 15, ((e.producer >> (8 * k)) >> 2) & 3, ((e.producer >> (8 * k)) & 3) + 1)
+                            for k in range(nt)]
+            row.append(j)
+        jobs.append(row)
+    pf = [x & (MLP_BARRIER | MLP_BLOCKWISE | MLP_WAITS) for x in flags]
+    assert mlp_sync.verify(pf, jobs)
+    p, w = next((p, w) for p in range(P) for w in range(16) if jobs[p][w].tokens)
+    kept = jobs[p][w].tokens
+    jobs[p][w].tokens = kept[1:]
+    with pytest.raises(AssertionError, match="may run before"):
+        mlp_sync.verify(pf, jobs)
+    jobs[p][w].tokens = kept
+    q = next(i for i, x in enumerate(pf) if x & MLP_BLOCKWISE)
+    with pytest.raises(AssertionError, match="may run before"):
+        mlp_sync.verify(pf[:q] + [0] + pf[q + 1:], jobs)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("game", ["Hanabi-Small", "Hanabi-Full"])
 @pytest.mark.parametrize("rows", [16, 32])
@@ -258,11 +308,11 @@ def test_blockwise_layer_boundaries_equal_barriers(game, rows, dtype, monkeypatc
     ix = torch.randint(0, S, (N,), device="cuda", generator=g).to(torch.int32)
     act = torch.randint(0, eng.A, (N,), device="cuda", generator=g).to(torch.int32)
     outs, flags = [], []
-    for blockwise in ("1", "0"):
+    for blockwise, waits in (("1", "1"), ("1", "0"), ("0", "0")):  # counters everywhere | blockwise boundaries only | barriers only
         monkeypatch.setenv("HANABIZERO_MLP_BLOCKWISE", blockwise)
+        monkeypatch.setenv("HANABIZERO_MLP_WAITS", waits)
         f = FusedRecurrent(net, eng, 16, 2)
-        raw = f.jobs.cpu().numpy().tobytes()
-        tab = (MlpJob * (len(raw) // ctypes.sizeof(MlpJob))).from_buffer_copy(raw)
+        tab = _job_table(f)
         flags.append([tab[j * 16].flags for j in range(f.n_jobs)])
         h = torch.zeros(N, eng.H, dtype=dtype, device="cuda")
         r, v, p = torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda"), torch.zeros(N, eng.A, device="cuda")
@@ -270,10 +320,15 @@ def test_blockwise_layer_boundaries_equal_barriers(game, rows, dtype, monkeypatc
             f(pool, ix, act, h, r, v, p, rows_per_wg=rows)
         outs.append((h, r, v, p))
     torch.cuda.synchronize()
+    from hanabizero_amd.model import MLP_BARRIER, MLP_WAITS
     assert sum(1 for x in flags[0] if x & MLP_BLOCKWISE) >= 2 and any(x & MLP_SIGNAL for x in flags[0])
-    assert not any(x & (MLP_BLOCKWISE | MLP_SIGNAL) for x in flags[1])
-    for a, b in zip(*outs):
-        assert torch.equal(a.view(torch.int16) if a.dtype != torch.float32 else a, b.view(torch.int16) if b.dtype != torch.float32 else b)
+    assert any(x & MLP_WAITS for x in flags[0]) and not any(x & MLP_BARRIER for x in flags[0])
+    assert not any(x & MLP_WAITS for x in flags[1]) and any(x & MLP_BARRIER for x in flags[1])
+    assert not any(x & (MLP_BLOCKWISE | MLP_SIGNAL | MLP_WAITS) for x in flags[2])
+    bits = lambda t: t.view(torch.int16) if t.dtype != torch.float32 else t
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert torch.equal(bits(a), bits(b))
 
 
 @pytest.mark.gpu
