@@ -563,23 +563,28 @@ class _FusedChain:
         """Independent chains side by side between two workgroup barriers: `lanes` = [[(w, b, K, src, dst, relu, res), ...],
         ...]; lane i owns the waves [i * waves / len(lanes), (i + 1) * waves / len(lanes)) and runs its layers one after
         the other on them while the other lanes stream their own: no wave idles through a barrier because the layer at
-        hand is narrow.  No layer of a stage may read what another layer of the same stage writes (there is no barrier
-        inside a stage); layers may have different K."""
+        hand is narrow.  An element of a lane may also be a LIST of layers: independent of one another, they share the lane's
+        waves in the same pass(es).  No layer of a stage may read what another layer of the same stage writes (there is no
+        barrier inside a stage; mlp_sync.verify checks the table that comes out); layers may have different K."""
         cw, waves = self.cw, self.waves
         cap = waves // len(lanes)
         assert cap >= 1
         rows = []
         for i, lane in enumerate(lanes):
             r = 0
-            for li, (w, b, K, src, dst, relu, res) in enumerate(lane):
-                chunks = [(c, min(cw, w.shape[0] - c)) for c in range(0, w.shape[0], cw)]
-                for j, (c, n) in enumerate(chunks):
+            for item in lane:
+                cut = []
+                for (w, b, K, src, dst, relu, res) in (item if isinstance(item, list) else [item]):
+                    for c in range(0, w.shape[0], cw):
+                        n = min(cw, w.shape[0] - c)
+                        cut.append(dict(w=w[c:c + n], b=b[c:c + n], ks=K // 32, src=src, dst=dst + c,
+                                        res=None if res is None else res + c, relu=relu, act=None))
+                for j, e in enumerate(cut):
                     row = r + j // cap
                     while len(rows) <= row:
                         rows.append([None] * waves)
-                    rows[row][i * cap + j % cap] = dict(w=w[c:c + n], b=b[c:c + n], ks=K // 32, src=src, dst=dst + c,
-                                                        res=None if res is None else res + c, relu=relu, act=None)
-                r += (len(chunks) + cap - 1) // cap
+                    rows[row][i * cap + j % cap] = e
+                r += (len(cut) + cap - 1) // cap
         for k, row in enumerate(rows):
             self._jobs.append(dict(entries=row, barrier=barrier and k == 0, store_hidden=store_hidden and k == 0, fixed=True))
 
@@ -617,18 +622,20 @@ class _FusedChain:
                       (MLP_BLOCKWISE if job.get("blockwise") else 0) for job in jobs]
         tokens = [[[] for _ in range(waves)] for _ in jobs]
         signal_passes = {ji for ji, job in enumerate(jobs) if job.get("signal")}
+        from . import mlp_sync
+        sj = []
+        for ji, (job, row) in enumerate(zip(jobs, rows)):
+            hid = [(hidden_off, hidden_off + hidden)] if job["store_hidden"] else []
+            sj.append([mlp_sync.Job(reads=hid, active=False) if e is None else
+                       mlp_sync.Job(reads=[(e["src"], e["src"] + 32 * e["ks"])] + hid +
+                                    ([] if e["res"] is None else [(e["res"], e["res"] + cw)]),
+                                    writes=[(e["dst"], e["dst"] + cw)]) for e in row])
         if self.blockwise and os.environ.get("HANABIZERO_MLP_WAITS", "1") != "0" and len(jobs) <= 16 and rs - width >= 8:
-            from . import mlp_sync
-            sj = []
-            for ji, (job, row) in enumerate(zip(jobs, rows)):
-                hid = [(hidden_off, hidden_off + hidden)] if job["store_hidden"] else []
-                sj.append([mlp_sync.Job(reads=hid, active=False) if e is None else
-                           mlp_sync.Job(reads=[(e["src"], e["src"] + 32 * e["ks"])] + hid +
-                                        ([] if e["res"] is None else [(e["res"], e["res"] + cw)]),
-                                        writes=[(e["dst"], e["dst"] + cw)]) for e in row])
             pass_flags, sig = mlp_sync.plan(pass_flags, sj, waves)
             signal_passes |= set(sig)
             tokens = [[j.tokens for j in r] for r in sj]
+        else:
+            mlp_sync.verify(pass_flags, sj, waves)  # (every shape's table is checked, whatever synchronises it)
         for ji, (job, row) in enumerate(zip(jobs, rows)):
             pass_ks = max(e["ks"] for e in row if e is not None)
             if job.get("signal"):
@@ -758,8 +765,8 @@ class FusedRecurrent(_FusedChain):
             # per barrier the chains are staggered so that between two barriers both halves stream --
             #   pass   h1R | h1A                      Y0 -> Z = [0, 2h)        (all waves; stores the hidden state)
             #   S1     h1V            || h2R, h2A     Y0 -> [2h, 3h);  Z thirds -> Tr = [3h, 4h), Ta = E
-            #   S2     h2V, h3R       || h3A          [2h, 3h) -> Tv = Y0's first h;  Tr -> [0, h);  Ta -> [h, 2h) in place (+ residual)
-            #   S3     h3V            || policy       Tv -> [2h, 3h);  [h, 2h) -> Tr
+            #   S2     h2V            || h3A          [2h, 3h) -> Tv = Y0's first h;  Ta -> [h, 2h) in place (+ residual)
+            #   S3     h3V            || h3R | policy Tv -> [2h, 3h);  Tr -> [0, h);  [h, 2h) -> E
             assert 3 * h <= 2 * H and 4 * h <= 2 * H and 2 * H + h <= 3 * H
             Y1, Y0, E = H, 2 * H, 3 * H
             Z = X
@@ -783,11 +790,14 @@ class FusedRecurrent(_FusedChain):
             R3, U, V3 = Z, Z + h, Z + 2 * h                 # reward logits | actor hidden | value logits
             self.add_stage([[(wv1, bv1, H, Y0, Z + 2 * h, True, None)],
                             [(wr2, br2, h, Z, Tr, True, None), (wa2, ba2, h, Z + h, Ta, True, None)]], store_hidden=True)
-            self.add_stage([[(wv2, bv2, h, Z + 2 * h, Tv, True, None), (wr3, br3, h, Tr, R3, False, None)],
+            self.add_stage([[(wv2, bv2, h, Z + 2 * h, Tv, True, None)],
                             [(wa3, ba3, h, Ta, U, True, Z + h)]])  # (in place: a lane reads the residual element it then overwrites)
+            # the three output layers in ONE last pass: value logits on lane 0, reward logits and policy side by side on lane 1 (the
+            # passes with a few jobs each are bound by a wave's own latency, not by the stream: h3R used to follow h2V on lane 0
+            # and the policy had a pass of its own; the policy's logits go to E, dead since h3A has read it)
             self.add_stage([[(wv3, bv3, h, Tv, V3, False, None)],
-                            [(wp4, bp4, h, U, Tr, False, None)]])
-            off_r, off_v, off_p, width = R3, V3, Tr, max(3 * H + h, Z + 6 * h)
+                            [[(wr3, br3, h, Tr, R3, False, None), (wp4, bp4, h, U, E, False, None)]]])
+            off_r, off_v, off_p, width = R3, V3, E, max(3 * H + h, Z + 6 * h)
         else:      # DynamicNet + 2-layer heads (model.py:61-91, 138-149)
             Z = Y1
             add_dense(w1s, b1, H, X, Y0, relu=True, res_off=X, barrier=False, act_w=w1a)
