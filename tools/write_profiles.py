@@ -114,9 +114,9 @@ r01_k_search_half_pmc.md) in brackets.
 
 Reading.  The request count is what it was (the weight stream: every workgroup pulls all 3.18 MB per simulation); the launches got shorter in
 cycles because fewer of them pass with the stream standing still (DESIGN.md section 4: hand-scheduled k-loop, start values through the scalar
-cache, layer boundaries without a workgroup barrier).  Two things bound what is left.  (1) tools/l2_stream_bench.hip: a kernel that does nothing but
+cache, no workgroup barrier between the inference's passes, fewer instructions in the tree phases).  Two things bound what is left.  (1) tools/l2_stream_bench.hip: a kernel that does nothing but
 this stream, with the product's MFMAs and layer boundaries, reaches 54-55 B per shader cycle per CU (of the L1's 64); the product's inference
-phases run at 46-48 (16 rows) / 41 (32 rows) -- tools/mlp_loop_bench.py -- and the tree phases (latency-bound) stream nothing.  (2) The shader clock:
+phases run at 47 (16 rows) / 44 (32 rows) -- tools/mlp_loop_bench.py -- and the tree phases (bound by instruction issue) stream nothing.  (2) The shader clock:
 under these kernels the chip runs at the clock in row 2, not at 2.4 GHz (the synthetic stream holds 2.39 GHz at 16 rows and 2.2 GHz at 32; random
 rather than constant weights alone cost it 11 %% of its rate at 32 rows): L1 and L2 are clocked with the shaders, so every GB/s figure of this
 kernel scales with it.  The MFMA pipes are busy 14 %% / 24 %% of the time: with 16 / 32 rows per weight fragment the matrix cores cannot be the bound.
