@@ -5,6 +5,9 @@ There is NO CPU fallback: if the HIP library is missing or fails to load, import
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- FIRST: PyTorch-ROCm brings its own HIP runtime (torch/lib); loaded after this library's, the
+#                             process has two and this library's sees no device ("no ROCm-capable device is detected")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HANABIZERO_HIP_LIB") or os.path.join(_HERE, "libhanabizero_hip.so")  # override: diagnostic builds (tools/)
 
