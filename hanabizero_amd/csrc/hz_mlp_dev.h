@@ -135,12 +135,8 @@ extern "C" int hz_mlp_profile_read_passes(unsigned long long* host) {
 #define PROF_TL(J, K) (void)0
 #endif
 
-// Weight-fragment ring: RING slots of one k-step each.  16 waves per workgroup (128 registers per lane): 4 slots.  Workgroups of
-// <= 8 waves may hold 256 registers per lane: HZ_RING_WIDE slots, so that the loads in flight cover a layer boundary
-// (epilogue + barrier) and the weight stream does not stop there.
-#ifndef HZ_RING_WIDE
-#define HZ_RING_WIDE 4
-#endif
+// Weight-fragment ring: 4 slots of one k-step each in every shape (8 slots for the workgroups of <= 8 waves, which have the
+// registers for it, measured no faster: what in-flight depth can cover at a layer boundary is not what a boundary costs).
 
 // The bias of two 16-column tiles (32 consecutive floats at a wave-uniform address) as the start values of two accumulators:
 // lane L gets floats [4 (L >> 4), 4 (L >> 4) + 4) of each tile -- the four output columns its accumulator holds.  The 128 B
@@ -276,7 +272,7 @@ __device__ __forceinline__ void mlp_body(
   // Prefetch distance in k-steps.  16-row shapes: RING - 1 (2 costs 1.7 % moves/s at 4096 envs).  32-row shape: 2 -- one
   // ring slot stays spare, so the refill of a slot does not have to wait for the four MFMAs that have just read it
   // (3: -2.1 % moves/s at 8192 envs, 1: -1.6 %; A/B on one box, tools/ab_bench.sh).
-  constexpr int RING = NW <= 8 ? HZ_RING_WIDE : 4;
+  constexpr int RING = 4;
   constexpr int PF = RT == 1 ? RING - 1 : RING - 2;
   // NT == 2 (the 16 x 2 shape of the persistent search kernel): the k-loop is hand-scheduled assembly (below) and its
   // loads are invisible to the compiler; the other shapes keep the compiler-scheduled loop.
@@ -304,7 +300,6 @@ __device__ __forceinline__ void mlp_body(
   __builtin_amdgcn_sched_barrier(0);
 
   // stage the states into the image; rows past N read as zero
-#ifndef HZ_MLP_X_NOSTAGE  // (experiment switch, tools/mlp_variants.py)
   for (int base = 0; !PRESTAGED && base < n_stage; base += NTHR * SU) {
     uint4 v[SU];
 #pragma unroll
@@ -324,7 +319,6 @@ __device__ __forceinline__ void mlp_body(
       if (i < n_stage) *reinterpret_cast<uint4*>(lds + (size_t)(i / chunks) * rs + H.state_off + (i % chunks) * 8) = v[u];
     }
   }
-#endif
   if (STAGE == STAGE_REGS) {
     static_assert(STAGE != STAGE_REGS || NW == 16, "wave w holds rows w, 16 + w, ...");
 #pragma unroll
@@ -385,12 +379,6 @@ __device__ __forceinline__ void mlp_body(
     if (j > 0) J = job_of(j);
     f32x4 acc[NT][RT];
     if (J.ks != 0) {
-#ifdef HZ_MLP_X_NOAV  // experiment (tools/mlp_variants.py): what the start values cost; results are garbage
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) acc[t][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#else
       if (J.flags & HZ_MLP_ACTION_ROW) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -424,7 +412,6 @@ __device__ __forceinline__ void mlp_body(
             for (int rt = 0; rt < RT; ++rt) acc[t][rt] = *reinterpret_cast<const f32x4*>(brow + 16 * t + c4);
         }
       }
-#endif
     }
     const unsigned long long p_j0 = PROF_NOW();
     if ((J.flags & HZ_MLP_BARRIER) || (!(BW && ASMK) && (J.flags & (HZ_MLP_BLOCKWISE | HZ_MLP_WAITS))))
@@ -669,17 +656,6 @@ __device__ __forceinline__ void mlp_body(
     PROF_TL(j, 2);
     const unsigned long long p_j3 = PROF_NOW();
 
-#ifdef HZ_MLP_X_NOEPI  // experiment (tools/mlp_variants.py): what the epilogues cost; results are garbage
-    {
-      float x = 0.f;
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) x += acc[t][rt][0] + acc[t][rt][1] + acc[t][rt][2] + acc[t][rt][3];  // (every MFMA stays alive)
-      if (x == 12345.678f) lds[tid] = 1;
-    }
-    continue;
-#endif
     // epilogue: (+ residual) (+ ReLU) in fp32, round to EL, 4 consecutive columns per lane
     const bool relu = J.flags & HZ_MLP_RELU;
     // all residual fragments in one batch of LDS reads (one wait), not one round trip per column tile
@@ -731,7 +707,6 @@ __device__ __forceinline__ void mlp_body(
   __builtin_amdgcn_s_setprio(0);
   if (FINAL) __syncthreads();  // (without the final stage the caller's own barrier follows)
   // heads -> scalars / policy logits: 32 lanes per (row, head) pair
-#ifndef HZ_MLP_X_NOFINAL
   if (FINAL) {
     const int l32 = tid & 31, slot = tid >> 5;
     for (int pair = slot; pair < 2 * MT; pair += NTHR / 32) {
@@ -751,7 +726,6 @@ __device__ __forceinline__ void mlp_body(
       }
     }
   }
-#endif
 #ifdef HZ_MLP_PROFILE
   if (blockIdx.x == 100 && lane == 0) {
     unsigned long long* o = hz_mlp_prof + wave * 8;

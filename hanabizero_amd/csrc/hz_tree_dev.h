@@ -152,11 +152,7 @@ __device__ __forceinline__ void hz_ptab_fill(float* ptab, const float* pbc_tab, 
 // phase the oldest gets through in 12 k (tools/search_profile.py), and the inference waits for the slowest tree.  Youngest
 // first is worth +0.5 % moves/s at 4096 envs (A/B on one box, tools/ab_multi.sh); priorities that grow with the depth of the
 // descent, alone or on top, are not (+0.1 % .. -0.3 %).
-#ifndef HZ_TREE_YOUNGEST_FIRST
-#define HZ_TREE_YOUNGEST_FIRST 1
-#endif
 __device__ __forceinline__ void hz_tree_phase_prio() {
-  if (!HZ_TREE_YOUNGEST_FIRST) return;
   switch (__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8)) {
     case 0: __builtin_amdgcn_s_setprio(0); break;
     case 1: __builtin_amdgcn_s_setprio(1); break;

@@ -55,7 +55,7 @@ def main():
             self.add_dense(w, b, H, Y0, X, relu=True, store_hidden=True)
             self._finish(3 * H + h, in_width=H, hidden=H, state_off=0, hidden_off=Y0, off_r=0, off_v=256, off_p=512)
 
-    def time(chain, mt, lib=lib):
+    def time(chain, mt):
         S = 8
         pool = torch.rand(S, N, H, device="cuda").to(torch.bfloat16)
         ix = torch.randint(0, S, (N,), device="cuda", dtype=torch.int32)
@@ -86,29 +86,6 @@ def main():
             torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e3 / 100
 
-    if os.environ.get("HZ_PROBE_VARIANTS"):  # the same chains through scratch builds with parts compiled out (results garbage)
-        import subprocess
-        from hanabizero_amd._lib import MlpHeader
-        src = os.path.join(ROOT, "hanabizero_amd", "csrc")
-        V, I, I64 = C.c_void_p, C.c_int, C.c_int64
-        NOAV, NOEPI = ["-DHZ_MLP_X_NOAV"], ["-DHZ_MLP_X_NOEPI"]
-        mt = N // 256
-        chains = [("real recurrent inference", FusedRecurrent(net, eng, 16, 2)), ("6 uniform 512x512 layers", Uniform(eng, 16, 2, 6)),
-                  ("12 uniform 512x512 layers", Uniform(eng, 16, 2, 12))]
-        for vname, flags in (("baseline", []), ("no start values", NOAV), ("no epilogues", NOEPI), ("no start values, no epilogues", NOAV + NOEPI),
-                             ("no start / epi / final / staging", NOAV + NOEPI + ["-DHZ_MLP_X_NOFINAL", "-DHZ_MLP_X_NOSTAGE"]),
-                             ("no priorities", ["-DHZ_MLP_X_NOPRIO"])):
-            out = os.path.join(ROOT, "gpurun_out", "libmlp_probe_%s.so" % "".join(c for c in vname if c.isalnum()))
-            subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-                                   "-w", "-I" + src, "-I" + os.path.join(ROOT, "include"), "-o", out, os.path.join(src, "hz_mlp.hip"),
-                                   os.path.join(src, "hz_tree.hip")] + flags)
-            vl = C.CDLL(out)
-            vl.hz_mlp_recurrent.argtypes = [C.POINTER(MlpHeader), V, V, V, V, V, I64, V, I64, V, V, V, V, V, I, I, V]
-            vl.hz_mlp_recurrent.restype = I
-            for name, ch in chains:
-                us = time(ch, mt, vl)
-                print("%-34s %-28s %7.2f us/launch  %6.1f GB/s per CU" % (vname, name, us, ch.weight_bytes_per_wg / us / 1e3), flush=True)
-        return
     for waves, tiles in ((16, 2), (8, 4)):
         for mt in (16, 32):
             if N // mt != 256:

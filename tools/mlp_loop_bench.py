@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """tools/mlp_loop_bench.py -- the product's fused inference in a loop inside ONE launch (tools/mlp_loop.hip): bytes of the
 weight stream per shader cycle and per second, for the real chain and for synthetic chains, next to tools/l2_stream_bench.hip's
-ceiling for the same stream.  Extra -D flags on the command line build experiment variants (results garbage, timing only).
-  python tools/mlp_loop_bench.py [N=4096] [-DHZ_MLP_X_...]"""
+ceiling for the same stream.  Extra -D flags on the command line go to hipcc (a scratch build with a switch of one's own).
+  python tools/mlp_loop_bench.py [N=4096] [-D...]"""
 import ctypes as C
 import os
 import subprocess
