@@ -210,6 +210,11 @@ __device__ __forceinline__ void hz_rotate_prio(int group_plus_phase) {
 // registers (STAGE_REGS: wave w holds rows w, 16 + w, ..; lane l its l-th 16-B chunk in row_frag[rt].v[l / 64]; NW == 16) and
 // written into the image here, after the weight ring has been started -- the rows' load latency hides under it.
 enum { STAGE_GATHER = 0, STAGE_REGS = 1, STAGE_REGS_HALF = 2 };
+// register i (of 4) of a wave's copy of its job entries: lane 8 * (j % 8) + f holds field f of job j = 8 i + j % 8
+__device__ __forceinline__ int hz_mlp_job_entries(const hz_mlp_job_t* jobs, int n_jobs, int num_waves, int wave, int lane, int i) {
+  const int jl = 8 * i + (lane >> 3);
+  return jl < n_jobs ? reinterpret_cast<const int*>(jobs)[((size_t)jl * num_waves + wave) * 8 + (lane & 7)] : 0;
+}
 struct RowFrag {
   uint4 v[2];
 };
@@ -223,7 +228,7 @@ __device__ __forceinline__ void mlp_body(
     long long state_row_stride, const int32_t* __restrict__ plane_index, long long plane_stride,
     const int32_t* __restrict__ actions, uint16_t* __restrict__ hidden_out, float* __restrict__ out_reward,
     float* __restrict__ out_value, float* __restrict__ out_policy, int n_rows, uint16_t* lds, int row0,
-    const RowFrag* row_frag) {
+    const RowFrag* row_frag, const int* jv_cached = nullptr) {
   typedef typename EL::v8 v8;
   constexpr int NTHR = 64 * NW;
   constexpr bool PRESTAGED = STAGE != STAGE_GATHER;
@@ -249,12 +254,10 @@ __device__ __forceinline__ void mlp_body(
   // memory pipe busy meanwhile), then all row loads of this thread at once: two latencies in total, not two per trip.
   // this wave's job entries: 8 dwords per job, lane 8*(j % 8) + f of register j / 8 holds field f of job j.  One vector
   // load now instead of one scalar load (a dependent L2 round trip in front of every job) inside the job loop.
+  // (the persistent search kernel loads them once per launch -- hz_mlp_job_entries -- and hands them in: jv_cached)
   int jv[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int jl = 8 * i + (lane >> 3);
-    jv[i] = jl < H.n_jobs ? reinterpret_cast<const int*>(jobs)[((size_t)jl * NW + wave) * 8 + (lane & 7)] : 0;
-  }
+  for (int i = 0; i < 4; ++i) jv[i] = jv_cached ? jv_cached[i] : hz_mlp_job_entries(jobs, H.n_jobs, NW, wave, lane, i);
   const int chunks = H.in_width / 8;
   const int n_stage = MT * chunks;
   constexpr int SU = 4;  // rows-chunks per thread per trip (hidden = 512, 16 rows: exactly one trip)

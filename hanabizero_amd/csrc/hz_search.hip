@@ -133,10 +133,10 @@ __device__ __forceinline__ RowFrag search_backup_descent(const TreeView& tv, con
 
 template <class EL, int RT>
 __device__ __forceinline__ void search_inference(const hz_mlp_header_t& H, const SearchArgs& a, const SearchLds& L, int sim,
-                                                 int n_rows, int row0, const RowFrag* rows) {
+                                                 int n_rows, int row0, const RowFrag* rows, const int* jv) {
   mlp_body<EL, RT, 16, 2, STAGE_REGS, false, RT == 1>(H, a.jobs, a.wstream, a.bias, a.act_tab, a.pool, a.row_stride, nullptr, a.plane_stride,
                                  L.act_s - row0, a.pool + (size_t)(sim + 1) * a.plane_stride, nullptr, nullptr, nullptr,
-                                 n_rows, L.image, row0, rows);
+                                 n_rows, L.image, row0, rows, jv);
 }
 
 // Diagnostic build only (-DHZ_SEARCH_PROFILE, tools/search_profile.py): per-phase s_memtime sums of workgroup 100.
@@ -197,11 +197,18 @@ __global__ __launch_bounds__(1024, 1) __attribute__((amdgpu_num_vgpr(HZ_ASMK_VGP
 #pragma unroll
   for (int s = 0; s < RT; ++s)
     if (mine[s]) rows[s] = search_first_descent(tv, H, a, L, row0, row0 + 16 * s + wave, lane, tl[s], root_row[s]);
+  // this wave's job entries of the inference: the same for every simulation, loaded once (two registers hold 16 jobs; the in-turn
+  // 32-row kernel has none to spare and reloads them per inference)
+  int jvc[4] = {0, 0, 0, 0};
+  if (RT == 1) {
+    jvc[0] = hz_mlp_job_entries(a.jobs, H.n_jobs, 16, wave, lane, 0);
+    jvc[1] = hz_mlp_job_entries(a.jobs, H.n_jobs, 16, wave, lane, 1);
+  }
   for (int sim = 0; sim < a.sims; ++sim) {
     unsigned long long t1 = SP_NOW();
     // (no barrier here: the inference's own barrier after staging orders the waves' rows and actions)
     unsigned long long t2 = SP_NOW();
-    search_inference<EL, RT>(H, a, L, sim, tv.N, row0, rows);
+    search_inference<EL, RT>(H, a, L, sim, tv.N, row0, rows, RT == 1 ? jvc : nullptr);
     unsigned long long t3 = SP_NOW();
     __syncthreads();  // leaf outputs visible; the row image is free again
     unsigned long long t4 = SP_NOW();
@@ -292,11 +299,12 @@ __global__ __launch_bounds__(1024, 1) __attribute__((amdgpu_num_vgpr(HZ_ASMK_VGP
   unsigned long long p_tree = 0, p_mlp = 0, p_wait2 = 0;
   (void)p_tree; (void)p_mlp; (void)p_wait2;
   unsigned long long t0 = SP_NOW();
+  int jvc[4] = {hz_mlp_job_entries(a.jobs, H.n_jobs, 16, wave, lane, 0), hz_mlp_job_entries(a.jobs, H.n_jobs, 16, wave, lane, 1), 0, 0};
   for (int sim = 0; sim < a.sims; ++sim) {
     const unsigned long long t2 = SP_NOW();
     mlp_body<EL, TW / 8, 16, 2, STAGE_REGS_HALF, false>(H, a.jobs, a.wstream, a.bias, a.act_tab, a.pool, a.row_stride, nullptr,
                                                a.plane_stride, L.act_s - row0, a.pool + (size_t)(sim + 1) * a.plane_stride,
-                                               nullptr, nullptr, nullptr, tv.N, L.image, row0, &rows);
+                                               nullptr, nullptr, nullptr, tv.N, L.image, row0, &rows, jvc);
     const unsigned long long t3 = SP_NOW();
     __syncthreads();  // leaf outputs visible; the row image is free again
     const unsigned long long t4 = SP_NOW();
@@ -400,6 +408,7 @@ extern "C" int hz_search_run(hz_tree_t* t, int num_simulations, const hz_mlp_hea
   if (rows_wg == 32 && lds_for(32) > 160 * 1024 && rows_per_workgroup == 0) rows_wg = 16;
   size_t lds_bytes = lds_for(rows_wg);
   HZ_REQUIRE(lds_bytes <= 160 * 1024, "hz_search_run: %zu B of LDS per workgroup exceed 160 KiB", lds_bytes);
+  HZ_REQUIRE(H->n_jobs <= 16, "hz_search_run: %d passes in the job table (the persistent kernels keep 16 in registers)", H->n_jobs);
   HZ_REQUIRE(t->S < 64 && H->hidden <= 512, "hz_search_run: the persistent kernels are written for < 64 simulations and hidden <= 512 "
                                             "(got %d, %d): run the launch-per-phase search", t->S, H->hidden);
   // the table of exploration factors (TreeLocal::ptab, triangular: 5.3 KB at S = 50) where the workgroup's LDS has room for it
