@@ -472,6 +472,7 @@ __device__ __forceinline__ void mlp_body(
       if (J.flags & (HZ_MLP_SIGNAL | HZ_MLP_BLOCKWISE)) hz_rotate_prio(3 - (wave >> 2));
       else if (RT == 1) hz_rotate_prio((wave >> 2) + j);
       const bool blockwise = BW && (J.flags & HZ_MLP_BLOCKWISE);
+      const unsigned int last = (unsigned int)J.flags & HZ_MLP_LAST;
       unsigned int pc = 1u << 22;  // polls before a wave gives up on a counter (a job table that breaks the contract must not hang the GPU)
       unsigned int fa = (unsigned int)(uintptr_t)(__attribute__((address_space(3))) const uint16_t*)(lds + (size_t)J.producer * rs + (rs - 8));
       unsigned int pt, ps;
@@ -481,6 +482,10 @@ __device__ __forceinline__ void mlp_body(
 #define HZ_RD1(B, OFF) "ds_read_b128 %[" B "], %[la0] offset:" #OFF "\n\t"
 #define HZ_K1(W0, W1, WN0, WN1, B, RD, LGKM)                                               \
   HZ_LD(WN0, WN1) RD "s_waitcnt vmcnt(6) lgkmcnt(" LGKM ")\n\t"                            \
+  "v_mfma_f32_16x16x32_" HZ_EL_ASM " %[a0], " W0 ", %[" B "], %[a0]\n\t"                   \
+  "v_mfma_f32_16x16x32_" HZ_EL_ASM " %[a1], " W1 ", %[" B "], %[a1]\n\t"
+#define HZ_K1N(W0, W1, B, VM, LGKM)                                                       \
+  "s_waitcnt vmcnt(" VM ") lgkmcnt(" LGKM ")\n\t"                                          \
   "v_mfma_f32_16x16x32_" HZ_EL_ASM " %[a0], " W0 ", %[" B "], %[a0]\n\t"                   \
   "v_mfma_f32_16x16x32_" HZ_EL_ASM " %[a1], " W1 ", %[" B "], %[a1]\n\t"
 #define HZ_K1_BODY()                                                                                            \
@@ -494,13 +499,16 @@ __device__ __forceinline__ void mlp_body(
             "v_add_u32 %[la0], 0x100, %[la0]\n\t"                                                                \
             "s_sub_u32 %[cnt], %[cnt], 1\n\ts_cmp_lg_u32 %[cnt], 1\n\ts_cbranch_scc1 1b\n\t"                     \
             HZ_K1(HZ_W00, HZ_W01, HZ_W30, HZ_W31, "b0", HZ_RD1("b3", 192), "3")                                    \
+            "s_cmp_lg_u32 %[last], 0\n\ts_cbranch_scc1 4f\n\t"                                                  \
             HZ_K1(HZ_W10, HZ_W11, HZ_W00, HZ_W01, "b1", "", "2")                                                   \
             HZ_K1(HZ_W20, HZ_W21, HZ_W10, HZ_W11, "b2", "", "1")                                                   \
             HZ_K1(HZ_W30, HZ_W31, HZ_W20, HZ_W21, "b3", "", "0")                                                   \
-            "s_nop 7\n\ts_nop 7\n\ts_nop 7"                                                                      \
+            "s_branch 5f\n\t4:\n\t"  /* this wave's last job of the inference: nothing to request ahead, nothing left in flight */ \
+            HZ_K1N(HZ_W10, HZ_W11, "b1", "4", "2") HZ_K1N(HZ_W20, HZ_W21, "b2", "2", "1") HZ_K1N(HZ_W30, HZ_W31, "b3", "0", "0") \
+            "5:\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"                                                                \
             : [b0] "=&v"(b0), [b1] "=&v"(b1), [b2] "=&v"(b2), [b3] "=&v"(b3), [a0] "+v"(acc[0][0]), [a1] "+v"(acc[1][0]), \
               [voff] "+v"(voff), [la0] "+v"(la0), [cnt] "+s"(cnt)                                                  \
-            : [sa] "s"(wbase), [kss] "s"(kss)                                                                     \
+            : [sa] "s"(wbase), [kss] "s"(kss), [last] "s"(last)                                                   \
             : "memory", "scc", HZ_RING_CLOBBER)
         // blockwise: per block of 4 k-steps wait for the producers of its 128 input columns, then prime the activation
         // fragments and run the block without reading past it
@@ -535,6 +543,7 @@ __device__ __forceinline__ void mlp_body(
         }
 #undef HZ_K1B_BODY
 #undef HZ_K1_BODY
+#undef HZ_K1N
 #undef HZ_K1
 #undef HZ_RD1
       } else {
@@ -544,6 +553,12 @@ __device__ __forceinline__ void mlp_body(
 #define HZ_RD2(B0, B1, OFF) "ds_read_b128 %[" B0 "], %[la0] offset:" #OFF "\n\tds_read_b128 %[" B1 "], %[la1] offset:" #OFF "\n\t"
 #define HZ_K2(W0, W1, WN0, WN1, B0, B1, RD, LGKM)                                             \
   HZ_LD(WN0, WN1) RD "s_waitcnt vmcnt(4) lgkmcnt(" LGKM ")\n\t"                               \
+  "v_mfma_f32_16x16x32_" HZ_EL_ASM " %[a00], " W0 ", %[" B0 "], %[a00]\n\t"                   \
+  "v_mfma_f32_16x16x32_" HZ_EL_ASM " %[a01], " W0 ", %[" B1 "], %[a01]\n\t"                   \
+  "v_mfma_f32_16x16x32_" HZ_EL_ASM " %[a10], " W1 ", %[" B0 "], %[a10]\n\t"                   \
+  "v_mfma_f32_16x16x32_" HZ_EL_ASM " %[a11], " W1 ", %[" B1 "], %[a11]\n\t"
+#define HZ_K2N(W0, W1, B0, B1, RD, VM, LGKM)                                                  \
+  RD "s_waitcnt vmcnt(" VM ") lgkmcnt(" LGKM ")\n\t"                                          \
   "v_mfma_f32_16x16x32_" HZ_EL_ASM " %[a00], " W0 ", %[" B0 "], %[a00]\n\t"                   \
   "v_mfma_f32_16x16x32_" HZ_EL_ASM " %[a01], " W0 ", %[" B1 "], %[a01]\n\t"                   \
   "v_mfma_f32_16x16x32_" HZ_EL_ASM " %[a10], " W1 ", %[" B0 "], %[a10]\n\t"                   \
@@ -560,13 +575,16 @@ __device__ __forceinline__ void mlp_body(
             "s_sub_u32 %[cnt], %[cnt], 1\n\ts_cmp_lg_u32 %[cnt], 1\n\ts_cbranch_scc1 1b\n\t"                     \
             HZ_K2(HZ_W00, HZ_W01, HZ_W20, HZ_W21, "b00", "b01", HZ_RD2("b10", "b11", 64), "2")                     \
             HZ_K2(HZ_W10, HZ_W11, HZ_W30, HZ_W31, "b10", "b11", HZ_RD2("b00", "b01", 128), "2")                    \
+            "s_cmp_lg_u32 %[last], 0\n\ts_cbranch_scc1 4f\n\t"                                                  \
             HZ_K2(HZ_W20, HZ_W21, HZ_W00, HZ_W01, "b00", "b01", HZ_RD2("b10", "b11", 192), "2")                    \
             HZ_K2(HZ_W30, HZ_W31, HZ_W10, HZ_W11, "b10", "b11", "", "0")                                           \
-            "s_nop 7\n\ts_nop 7\n\ts_nop 7"                                                                      \
+            "s_branch 5f\n\t4:\n\t"  /* this wave's last job of the inference: nothing to request ahead, nothing left in flight */ \
+            HZ_K2N(HZ_W20, HZ_W21, "b00", "b01", HZ_RD2("b10", "b11", 192), "2", "2") HZ_K2N(HZ_W30, HZ_W31, "b10", "b11", "", "0", "0") \
+            "5:\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"                                                                \
             : [b00] "=&v"(b00), [b01] "=&v"(b01), [b10] "=&v"(b10), [b11] "=&v"(b11),                              \
               [a00] "+v"(acc[0][0]), [a01] "+v"(acc[0][1]), [a10] "+v"(acc[1][0]), [a11] "+v"(acc[1][1]),          \
               [voff] "+v"(voff), [la0] "+v"(la0), [la1] "+v"(la1), [cnt] "+s"(cnt)                                 \
-            : [sa] "s"(wbase), [kss] "s"(kss)                                                                     \
+            : [sa] "s"(wbase), [kss] "s"(kss), [last] "s"(last)                                                   \
             : "memory", "scc", HZ_RING_CLOBBER)
 #define HZ_K2B_BODY()                                                                                           \
         asm volatile(                                                                                           \
@@ -597,6 +615,7 @@ __device__ __forceinline__ void mlp_body(
 #undef HZ_K2B_BODY
 #undef HZ_POLL
 #undef HZ_K2_BODY
+#undef HZ_K2N
 #undef HZ_K2
 #undef HZ_RD2
       }

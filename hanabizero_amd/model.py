@@ -483,7 +483,7 @@ class InferenceEngine:
 
 
 # ------------------------------------------------------------------------------------------------ fused MFMA kernel
-MLP_RELU, MLP_ACTION_ROW, MLP_BARRIER, MLP_STORE_HIDDEN, MLP_SIGNAL, MLP_BLOCKWISE, MLP_WAITS = 1, 2, 4, 8, 16, 32, 64  # include/hz_mlp.h flags
+MLP_RELU, MLP_ACTION_ROW, MLP_BARRIER, MLP_STORE_HIDDEN, MLP_SIGNAL, MLP_BLOCKWISE, MLP_WAITS, MLP_LAST = 1, 2, 4, 8, 16, 32, 64, 128  # include/hz_mlp.h flags
 
 
 def _pack_fragments(wblk, ks, tiles=4):
@@ -636,6 +636,7 @@ class _FusedChain:
             tokens = [[j.tokens for j in r] for r in sj]
         else:
             mlp_sync.verify(pass_flags, sj, waves)  # (every shape's table is checked, whatever synchronises it)
+        last_job = [max((ji for ji, row in enumerate(rows) if row[w] is not None), default=-1) for w in range(waves)]
         for ji, (job, row) in enumerate(zip(jobs, rows)):
             pass_ks = max(e["ks"] for e in row if e is not None)
             if job.get("signal"):
@@ -667,6 +668,8 @@ class _FusedChain:
                     flags |= MLP_ACTION_ROW
                 if e["relu"]:
                     flags |= MLP_RELU
+                if self.blockwise and last_job[wave] == ji and not job.get("blockwise"):
+                    flags |= MLP_LAST
                 table.append(MlpJob(ks=e["ks"], src_off=e["src"], dst_off=e["dst"],
                                     res_off=-1 if e["res"] is None else e["res"], bias_off=bias_off, flags=flags,
                                     reserved0=pass_ks, producer=producer))

@@ -52,7 +52,11 @@ enum {
    * without the counters runs a workgroup barrier there instead); tokens are per entry, idle entries may have some (the
    * hidden-state store reads columns too).  hanabizero_amd/mlp_sync.py derives the tokens from the jobs' column ranges and
    * proves the table race-free. */
-  HZ_MLP_WAITS = 64
+  HZ_MLP_WAITS = 64,
+  /* 16 waves x 2 tiles only, per entry: this is the wave's last job of the inference -- its k-loop requests no weight
+   * fragments past its own (the other jobs' loops run 3 k-steps ahead into the next job's), so nothing is in flight when
+   * the wave leaves the chain. */
+  HZ_MLP_LAST = 128
 };
 
 /* One (job, wave) entry; all offsets are bf16-element columns of the LDS row image.  ks == 0: this wave idles.
