@@ -187,13 +187,11 @@ __device__ __forceinline__ void hz_bias_start_values(const float* uniform_row, f
   "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", \
       "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127"
 
-// Issue priority of this wave for the next few k-steps.  The sequencer serves the oldest wave of a SIMD first, so with a
-// fixed priority wave w < 4 of a workgroup (the oldest on its SIMD) streams its share of a layer in half the time the
-// youngest needs and then idles at the layer's barrier while the stragglers finish on a memory pipe they cannot fill alone
-// (tools/mlp_profile.py: k-loops 22 k cycles for waves 0-3, 48 k for waves 12-15 of 81 k).  Rotating the priority among
-// the four age groups every four k-steps gives each group every rank equally often: +1.2 % moves/s at 16 rows per workgroup
-// (A/B on one box, tools/ab_bench.sh; every 2 or 8 k-steps and fixed youngest-first are worse), -1.1 % with 32 rows, where it
-// is therefore off.  (s_setprio takes an immediate.)
+// Issue priority of this wave for the next few k-steps (s_setprio takes an immediate).  The sequencer serves the oldest wave of
+// a SIMD first; behind a workgroup barrier per layer that made the oldest waves idle at the barrier while the youngest finished
+// on a memory pipe they could not fill alone, and rotating the priority over the four age groups every four k-steps was worth
+// +1.2 % moves/s at 16 rows per workgroup (r01; the compiler-scheduled shapes still do that).  The 16 x 2 shape has no barrier
+// between its passes any more and runs with the natural order made explicit (oldest group first, see the job loop).
 __device__ __forceinline__ void hz_rotate_prio(int group_plus_phase) {
   switch (group_plus_phase & 3) {
     case 0: __builtin_amdgcn_s_setprio(0); break;
@@ -209,6 +207,12 @@ __device__ __forceinline__ void hz_rotate_prio(int group_plus_phase) {
 // The input rows of a workgroup: gathered here from state_src (STAGE_GATHER), or handed over by the caller's waves in
 // registers (STAGE_REGS: wave w holds rows w, 16 + w, ..; lane l its l-th 16-B chunk in row_frag[rt].v[l / 64]; NW == 16) and
 // written into the image here, after the weight ring has been started -- the rows' load latency hides under it.
+// A wave that finds a counter short sleeps HZ_POLL_SLEEP x 64 cycles before it looks again.  Long on purpose: 1 (look again at
+// once) costs 3.5 % moves/s at 4096 envs against 31..48, 63 is worse again; s_wakeup from every signalling wave (sleepers look
+// again immediately) is worse than not waking them (2.13 M against 2.16 M moves/s): what the waiting waves issue -- LDS reads,
+// branches -- is taken from the waves everybody is waiting for, and the chip runs this kernel at the power limit.
+#define HZ_POLL_SLEEP "40"
+#define HZ_POLL_TRIES (1u << 16)  // (then a wave gives up on a counter: a job table that breaks the contract must not hang the GPU)
 enum { STAGE_GATHER = 0, STAGE_REGS = 1, STAGE_REGS_HALF = 2 };
 // register i (of 4) of a wave's copy of its job entries: lane 8 * (j % 8) + f holds field f of job j = 8 i + j % 8
 __device__ __forceinline__ int hz_mlp_job_entries(const hz_mlp_job_t* jobs, int n_jobs, int num_waves, int wave, int lane, int i) {
@@ -425,9 +429,9 @@ __device__ __forceinline__ void mlp_body(
         const unsigned int img = (unsigned int)(uintptr_t)(__attribute__((address_space(3))) const uint16_t*)lds;
         for (int k = (J.flags >> 8) & 7; k > 0; --k, tok >>= 8) {
           unsigned int fa2 = img + 2u * (((tok >> 4) & 15u) * (unsigned int)rs + (unsigned int)(rs - 8)) + 4u * ((tok >> 2) & 3u);
-          unsigned int want = (tok & 3u) + 1u, pc2 = 1u << 22, pt2, ps2;
+          unsigned int want = (tok & 3u) + 1u, pc2 = HZ_POLL_TRIES, pt2, ps2;
           asm volatile("2:\n\tds_read_b32 %[pt], %[fa]\n\ts_waitcnt lgkmcnt(0)\n\tv_readfirstlane_b32 %[ps], %[pt]\n\ts_nop 3\n\t"
-                       "s_cmp_ge_u32 %[ps], %[want]\n\ts_cbranch_scc1 3f\n\ts_sleep 1\n\ts_sub_u32 %[pc], %[pc], 1\n\t"
+                       "s_cmp_ge_u32 %[ps], %[want]\n\ts_cbranch_scc1 3f\n\ts_sleep " HZ_POLL_SLEEP "\n\ts_sub_u32 %[pc], %[pc], 1\n\t"
                        "s_cmp_lg_u32 %[pc], 0\n\ts_cbranch_scc1 2b\n\t3:"
                        : [pt] "=&v"(pt2), [ps] "=&s"(ps2), [pc] "+s"(pc2)
                        : [fa] "v"(fa2), [want] "s"(want)
@@ -467,13 +471,13 @@ __device__ __forceinline__ void mlp_body(
       // The ring lives in the fixed registers v[96:127] (see HZ_W00 ..): in flight across everything the compiler generates.
       unsigned int cnt = (unsigned int)J.ks >> 2;
       unsigned int la0 = (unsigned int)(uintptr_t)(__attribute__((address_space(3))) const uint16_t*)src;
-      // issue priority: rotates over the workgroup's four age groups, job by job -- except where the groups should finish in
-      // the order of their columns (HZ_MLP_SIGNAL / HZ_MLP_BLOCKWISE: the consumers want block 0 first): oldest group first
-      if (J.flags & (HZ_MLP_SIGNAL | HZ_MLP_BLOCKWISE)) hz_rotate_prio(3 - (wave >> 2));
-      else if (RT == 1) hz_rotate_prio((wave >> 2) + j);
+      // issue priority: oldest age group first -- the groups then finish a layer in the order of their columns, which is the order
+      // in which a blockwise consumer wants the blocks (with a barrier behind every layer the priorities rotated over the groups,
+      // job by job; with the counters a fixed order measures the same or better)
+      hz_rotate_prio(3 - (wave >> 2));
       const bool blockwise = BW && (J.flags & HZ_MLP_BLOCKWISE);
       const unsigned int last = (unsigned int)J.flags & HZ_MLP_LAST;
-      unsigned int pc = 1u << 22;  // polls before a wave gives up on a counter (a job table that breaks the contract must not hang the GPU)
+      unsigned int pc = HZ_POLL_TRIES;
       unsigned int fa = (unsigned int)(uintptr_t)(__attribute__((address_space(3))) const uint16_t*)(lds + (size_t)J.producer * rs + (rs - 8));
       unsigned int pt, ps;
       if constexpr (RT == 1) {
@@ -514,7 +518,7 @@ __device__ __forceinline__ void mlp_body(
         // fragments and run the block without reading past it
 #define HZ_POLL()                                                                                                       \
             "2:\n\tds_read_b32 %[pt], %[fa]\n\ts_waitcnt lgkmcnt(0)\n\tv_readfirstlane_b32 %[ps], %[pt]\n\ts_nop 3\n\t"        \
-            "s_cmp_ge_u32 %[ps], 4\n\ts_cbranch_scc1 3f\n\ts_sleep 1\n\ts_sub_u32 %[pc], %[pc], 1\n\ts_cmp_lg_u32 %[pc], 0\n\t"   \
+            "s_cmp_ge_u32 %[ps], 4\n\ts_cbranch_scc1 3f\n\ts_sleep " HZ_POLL_SLEEP "\n\ts_sub_u32 %[pc], %[pc], 1\n\ts_cmp_lg_u32 %[pc], 0\n\t"   \
             "s_cbranch_scc1 2b\n\t3:\n\t"
 #define HZ_K1B_BODY()                                                                                           \
         asm volatile(                                                                                           \
