@@ -767,7 +767,7 @@ class FusedRecurrent(_FusedChain):
             # independent, and a 256-column layer occupies only half the waves of a 16 x 2 workgroup: instead of one layer
             # per barrier the chains are staggered so that between two barriers both halves stream --
             #   pass   h1R | h1A                      Y0 -> Z = [0, 2h)        (all waves; stores the hidden state)
-            #   S1     h1V            || h2R, h2A     Y0 -> [2h, 3h);  Z thirds -> Tr = [3h, 4h), Ta = E
+            #   S1     h1V            || h2A, h2R     Y0 -> [2h, 3h);  Z thirds -> Ta = E, Tr = [3h, 4h)
             #   S2     h2V            || h3A          [2h, 3h) -> Tv = Y0's first h;  Ta -> [h, 2h) in place (+ residual)
             #   S3     h3V            || h3R | policy Tv -> [2h, 3h);  Tr -> [0, h);  [h, 2h) -> E
             assert 3 * h <= 2 * H and 4 * h <= 2 * H and 2 * H + h <= 3 * H
@@ -792,7 +792,8 @@ class FusedRecurrent(_FusedChain):
             wp4, bp4 = _fold(ac[4])
             R3, U, V3 = Z, Z + h, Z + 2 * h                 # reward logits | actor hidden | value logits
             self.add_stage([[(wv1, bv1, H, Y0, Z + 2 * h, True, None)],
-                            [(wr2, br2, h, Z, Tr, True, None), (wa2, ba2, h, Z + h, Ta, True, None)]], store_hidden=True)
+                            [(wa2, ba2, h, Z + h, Ta, True, None), (wr2, br2, h, Z, Tr, True, None)]], store_hidden=True)
+            # (h2A before h2R: the actor head is the longest chain of dependent layers behind the dynamics net)
             self.add_stage([[(wv2, bv2, h, Z + 2 * h, Tv, True, None)],
                             [(wa3, ba3, h, Ta, U, True, Z + h)]])  # (in place: a lane reads the residual element it then overwrites)
             # the three output layers in ONE last pass: value logits on lane 0, reward logits and policy side by side on lane 1 (the
