@@ -121,6 +121,7 @@ __device__ __forceinline__ RowFrag search_backup_descent(const TreeView& tv, con
   if (lane == a0) root_row = first;  // the one record of the root's row this backup changed
   if (more) {
     // (the fence between this backup's stores and the descent's loads sits inside traverse_body, behind the root level)
+    hz_tree_descent_prio();
     int entry;
     TP(5);
     tl.publish = sim + 2 == a.sims;  // the last descent
@@ -335,6 +336,7 @@ __global__ __launch_bounds__(1024, 1) __attribute__((amdgpu_num_vgpr(HZ_ASMK_VGP
     rows.v[0] = rows.v[1] = make_uint4(0u, 0u, 0u, 0u);
     if (more) {
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      hz_tree_descent_prio();
       const int entry = traverse_half(tv, q, t, sim + 1, mn, mx, root_row, tab_s, L.ptab, L.act_s + TW * q.h + wave, a.ix,
                                       a.iy, sim + 2 == a.sims);
       if (t.mine) {

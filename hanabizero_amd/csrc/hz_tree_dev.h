@@ -150,8 +150,13 @@ __device__ __forceinline__ void hz_ptab_fill(float* ptab, const float* pbc_tab, 
 // Issue priority of the tree phases inside the persistent search kernels.  The four waves of a SIMD share its issue port and
 // the sequencer serves the oldest first: with equal priorities the youngest wave of each SIMD needs 21 k cycles for a tree
 // phase the oldest gets through in 12 k (tools/search_profile.py), and the inference waits for the slowest tree.  Youngest
-// first is worth +0.5 % moves/s at 4096 envs (A/B on one box, tools/ab_multi.sh); priorities that grow with the depth of the
-// descent, alone or on top, are not (+0.1 % .. -0.3 %).
+// first throughout was worth +0.9 % moves/s at 4096 envs (A/B on one box, tools/ab_multi.sh) but only moved the problem (now
+// the oldest waves needed 21 k cycles at 8192 envs); priorities that grow with the depth of the descent did nothing.  What is
+// in: youngest first for the first half of a tree phase (read-out, expansion, backup: hz_tree_phase_prio), equal priorities
+// -- the hardware's oldest first -- for the descent (hz_tree_descent_prio), so that neither age group is last in both
+// halves: another +1.0 % at 4096 envs, +1.5 % at 8192 (oldest-first made explicit in the descent, or the halves the other
+// way round, gain less).
+__device__ __forceinline__ void hz_tree_descent_prio() { __builtin_amdgcn_s_setprio(0); }
 __device__ __forceinline__ void hz_tree_phase_prio() {
   switch (__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8)) {
     case 0: __builtin_amdgcn_s_setprio(0); break;
