@@ -211,11 +211,14 @@ def kernel_timing(actor, sample_sims=(4, 16, 28, 40), clones=8, replays=5):
     fused16 = eng.fused_shape(16, 2) if (fused is not None and getattr(actor.mcts, "persistent", False)) else None
     if fused16 is not None:
         per_graph = []
+        busy = torch.randn(4096, 4096, device=actor.device).to(torch.bfloat16)
         for _ in range(6):
             snaps = [roots.clone() for _ in range(4)]
             torch.cuda.synchronize()
             g0 = timed_graph(lambda: [c.search_tensors(fused16, actor.pool, S - 1, rew, val, pol, actor.mcts.rows_per_workgroup)
                                       for c in snaps])
+            for _k in range(12):  # (cloning and capturing leave the GPU idle for milliseconds: a launch that meets it on its way up from
+                torch.mm(busy, busy)  # the idle clocks once took 30 ms instead of 2 -- keep it busy right up to the first event)
             a, b = ev(), ev()
             a.record(); g0.replay(); b.record()
             torch.cuda.synchronize()
@@ -442,6 +445,11 @@ def net_error(game, dtype):
             "worst": e["worst"], **{k: v for k, v in e.items() if isinstance(v, dict)}}
 
 
+def _poll_giveups():
+    from hanabizero_amd._lib import poll_giveups
+    return poll_giveups()
+
+
 def git_head():
     """The commit of this tree: from git where there is a checkout, else from the stamp __graft_entry__.build() leaves beside the
     library (the snapshot on a GPU box carries no .git)."""
@@ -601,6 +609,7 @@ def main():
                                "unit": "TFLOP/s", "frac": fl / t / 1e12 / MFMA_PEAK_TFLOPS,
                                "traffic": traffic_all.get("k_search"), "traffic_source": traffic_src,
                                "avg_launch_us": t * 1e6, "min_launch_us": search["min_s"] * 1e6, "launches_timed": search["launches"],
+                               "poll_giveups": _poll_giveups(),  # waits on arrival counters that timed out in this process (must be 0)
                                "flop_per_launch": fl, "simulations_per_launch": S - 1, "trees_per_workgroup": rows_wg, "workgroups": wgs,
                                "l2_stream": {"bytes_per_launch": l2_bytes, "achieved_TBps": l2_bytes / t / 1e12, "peak_TBps": L2_PEAK_TBS,
                                              "frac": l2_bytes / t / 1e12 / L2_PEAK_TBS,

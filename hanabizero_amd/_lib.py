@@ -97,6 +97,8 @@ def _load():
         "hz_mlp_recurrent": [C.POINTER(MlpHeader), V, V, V, V, V, I64, V, I64, V, V, V, V, V, I, I, V],
         # include/hz_search.h
         "hz_search_run": [V, I, C.POINTER(MlpHeader), V, V, V, V, V, I64, I64, V, V, V, V, V, V, I, V],
+        "hz_search_poll_giveups": [C.POINTER(C.c_uint)],
+        "hz_mlp_poll_giveups": [C.POINTER(C.c_uint)],
         # include/hz_netglue.h
         "hz_add_relu": [V, I64, V, I64, I, I, I, V],
         "hz_test_expf": [V, V, I64, V],
@@ -121,6 +123,13 @@ lib = _load()
 def check(rc, what=""):
     if rc != 0:
         raise HzError("%s failed (%d): %s" % (what, rc, lib.hz_last_error().decode()))
+
+
+def poll_giveups():
+    """include/hz_mlp.h::hz_mlp_poll_giveups: waits on arrival counters that timed out since the library was loaded (must be 0)."""
+    n = C.c_uint(0)
+    check(lib.hz_mlp_poll_giveups(C.byref(n)), "hz_mlp_poll_giveups")
+    return int(n.value)
 
 
 def declared_symbols():

@@ -41,6 +41,17 @@ __global__ __launch_bounds__(1024, 1) __attribute__((amdgpu_num_vgpr(HZ_ASMK_VGP
                           hidden_out, out_reward, out_value, out_policy, n_rows, lds, (int)blockIdx.x * 16 * RT, nullptr);
 }
 
+extern "C" int hz_search_poll_giveups(unsigned int* count);
+extern "C" int hz_mlp_poll_giveups(unsigned int* count) {
+  HZ_REQUIRE(count != nullptr, "hz_mlp_poll_giveups: NULL argument");
+  unsigned int mine = 0, theirs = 0;
+  HZ_HIP(hipMemcpyFromSymbol(&mine, HIP_SYMBOL(hz_poll_giveups_dev), sizeof(unsigned int)));
+  const int rc = hz_search_poll_giveups(&theirs);
+  if (rc != 0) return rc;
+  *count = mine + theirs;
+  return 0;
+}
+
 extern "C" int hz_mlp_recurrent(const hz_mlp_header_t* H, const hz_mlp_job_t* jobs, const void* wstream,
                                 const float* biases, const float* action_table, const void* state_src,
                                 int64_t row_stride, const int32_t* plane_index, int64_t plane_stride,

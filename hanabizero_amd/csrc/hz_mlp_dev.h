@@ -213,6 +213,10 @@ __device__ __forceinline__ void hz_rotate_prio(int group_plus_phase) {
 // branches -- is taken from the waves everybody is waiting for, and the chip runs this kernel at the power limit.
 #define HZ_POLL_SLEEP "40"
 #define HZ_POLL_TRIES (1u << 16)  // (then a wave gives up on a counter: a job table that breaks the contract must not hang the GPU)
+// ... and says so: waits given up since the library was loaded, per translation unit (hz_mlp_poll_giveups adds them up); anything
+// but 0 means results that cannot be trusted
+static __device__ unsigned int hz_poll_giveups_dev;
+#define HZ_POLL_GIVEUP(TRIES_LEFT) do { if ((TRIES_LEFT) == 0u && lane == 0) atomicAdd(&hz_poll_giveups_dev, 1u); } while (0)
 enum { STAGE_GATHER = 0, STAGE_REGS = 1, STAGE_REGS_HALF = 2 };
 // register i (of 4) of a wave's copy of its job entries: lane 8 * (j % 8) + f holds field f of job j = 8 i + j % 8
 __device__ __forceinline__ int hz_mlp_job_entries(const hz_mlp_job_t* jobs, int n_jobs, int num_waves, int wave, int lane, int i) {
@@ -436,6 +440,7 @@ __device__ __forceinline__ void mlp_body(
                        : [pt] "=&v"(pt2), [ps] "=&s"(ps2), [pc] "+s"(pc2)
                        : [fa] "v"(fa2), [want] "s"(want)
                        : "memory", "scc");
+          HZ_POLL_GIVEUP(pc2);
         }
       }
     }
@@ -459,6 +464,7 @@ __device__ __forceinline__ void mlp_body(
     PROF_ADD(p_pre, p_j1);
     const unsigned long long p_j2 = PROF_NOW();
     PROF_TL(j, 1);
+    unsigned int pc_left = 1u;  // (ASMK: tries the blockwise k-loop had left when it ended)
     if constexpr (ASMK) {
       // ---- the k-loop, hand-scheduled (the compiler's own schedule of the same loop drained the weight ring at the start
       // of every job and of every 8 k-steps: it packs address arithmetic into ring registers and serialises the refills
@@ -626,6 +632,7 @@ __device__ __forceinline__ void mlp_body(
 #undef HZ_K2
 #undef HZ_RD2
       }
+      pc_left = pc;
     } else {
       // ---- the compiler-scheduled k-loop of the other shapes
       // activation fragments, BQPF k-steps ahead of their use (RT = 2 has the registers for one step ahead only -- two
@@ -683,6 +690,7 @@ __device__ __forceinline__ void mlp_body(
     }
     PROF_ADD(p_loop, p_j2);
     PROF_TL(j, 2);
+    if constexpr (ASMK && BW) HZ_POLL_GIVEUP(pc_left);
     const unsigned long long p_j3 = PROF_NOW();
 
     // epilogue: (+ residual) (+ ReLU) in fp32, round to EL, 4 consecutive columns per lane

@@ -365,6 +365,12 @@ static SearchDevice g_search_dev[64];
 
 // rows per workgroup: 0 = choose by the tree count (two trees per wave once one per wave would need more workgroups than the
 // device has compute units), 16 / 32 = force, -32 = 32 with the two trees of a wave one after the other (tests, tools)
+extern "C" int hz_search_poll_giveups(unsigned int* count) {
+  HZ_REQUIRE(count != nullptr, "hz_search_poll_giveups: NULL argument");
+  HZ_HIP(hipMemcpyFromSymbol(count, HIP_SYMBOL(hz_poll_giveups_dev), sizeof(unsigned int)));
+  return 0;
+}
+
 extern "C" int hz_search_run(hz_tree_t* t, int num_simulations, const hz_mlp_header_t* H, const hz_mlp_job_t* jobs,
                              const void* wstream, const float* biases, const float* action_table, void* pool,
                              int64_t plane_stride, int64_t row_stride, int32_t* ix, int32_t* iy, int32_t* la,

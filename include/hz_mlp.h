@@ -114,6 +114,11 @@ int hz_mlp_recurrent(const hz_mlp_header_t* host_header, const hz_mlp_job_t* job
                      float* out_reward, float* out_value, float* out_policy, int num_rows, int rows_per_wg,
                      void* stream);
 
+/* Waits on arrival counters (HZ_MLP_BLOCKWISE / HZ_MLP_WAITS) that gave up -- after 2^16 looks, about 70 ms -- since the
+ * library was loaded, summed over hz_mlp_recurrent and hz_search_run launches on the current device (synchronises with it).  Must be 0: a
+ * wave that gave up went on with inputs that may not have been there.  (bench.py prints it; the GPU tests assert it.) */
+int hz_mlp_poll_giveups(unsigned int* count);
+
 #ifdef __cplusplus
 }
 #endif

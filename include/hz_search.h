@@ -45,6 +45,9 @@ int hz_search_run(hz_tree_t* t, int num_simulations, const hz_mlp_header_t* H, c
                   int64_t plane_stride, int64_t row_stride, int32_t* ix, int32_t* iy, int32_t* la, float* rewards,
                   float* values, float* policy, int rows_per_workgroup, void* stream);
 
+/* hz_search_run's share of hz_mlp_poll_giveups (include/hz_mlp.h), which is the one to call. */
+int hz_search_poll_giveups(unsigned int* count);
+
 #ifdef __cplusplus
 }
 #endif

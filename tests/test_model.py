@@ -325,6 +325,8 @@ def test_blockwise_layer_boundaries_equal_barriers(game, rows, dtype, monkeypatc
     assert any(x & MLP_WAITS for x in flags[0]) and not any(x & MLP_BARRIER for x in flags[0])
     assert not any(x & MLP_WAITS for x in flags[1]) and any(x & MLP_BARRIER for x in flags[1])
     assert not any(x & (MLP_BLOCKWISE | MLP_SIGNAL | MLP_WAITS) for x in flags[2])
+    from hanabizero_amd._lib import poll_giveups
+    assert poll_giveups() == 0
     bits = lambda t: t.view(torch.int16) if t.dtype != torch.float32 else t
     for other in outs[1:]:
         for a, b in zip(outs[0], other):
