@@ -211,14 +211,15 @@ def kernel_timing(actor, sample_sims=(4, 16, 28, 40), clones=8, replays=5):
     fused16 = eng.fused_shape(16, 2) if (fused is not None and getattr(actor.mcts, "persistent", False)) else None
     if fused16 is not None:
         per_graph = []
-        busy = torch.randn(4096, 4096, device=actor.device).to(torch.bfloat16)
+        busy = torch.empty(2, 1 << 27, dtype=torch.uint8, device=actor.device)  # (2 x 128 MiB: copies, not MFMA work -- a burst of
+        #                                                                             GEMMs leaves the chip throttled instead)
         for _ in range(6):
             snaps = [roots.clone() for _ in range(4)]
             torch.cuda.synchronize()
             g0 = timed_graph(lambda: [c.search_tensors(fused16, actor.pool, S - 1, rew, val, pol, actor.mcts.rows_per_workgroup)
                                       for c in snaps])
-            for _k in range(12):  # (cloning and capturing leave the GPU idle for milliseconds: a launch that meets it on its way up from
-                torch.mm(busy, busy)  # the idle clocks once took 30 ms instead of 2 -- keep it busy right up to the first event)
+            for _k in range(16):  # (cloning and capturing leave the GPU idle for milliseconds: a launch that meets it on its way up from
+                busy[_k & 1].copy_(busy[1 - (_k & 1)])  # the idle clocks once took 30 ms instead of 2 -- keep it busy up to the first event)
             a, b = ev(), ev()
             a.record(); g0.replay(); b.record()
             torch.cuda.synchronize()
