@@ -431,17 +431,18 @@ __device__ __forceinline__ void mlp_body(
       if (J.flags & HZ_MLP_WAITS) {  // this job's own dependencies instead of a barrier (include/hz_mlp.h; hanabizero_amd/mlp_sync.py)
         unsigned int tok = (unsigned int)J.producer;
         const unsigned int img = (unsigned int)(uintptr_t)(__attribute__((address_space(3))) const uint16_t*)lds;
+        unsigned int pc2 = HZ_POLL_TRIES;  // (tries for all of this job's tokens together)
         for (int k = (J.flags >> 8) & 7; k > 0; --k, tok >>= 8) {
           unsigned int fa2 = img + 2u * (((tok >> 4) & 15u) * (unsigned int)rs + (unsigned int)(rs - 8)) + 4u * ((tok >> 2) & 3u);
-          unsigned int want = (tok & 3u) + 1u, pc2 = HZ_POLL_TRIES, pt2, ps2;
+          unsigned int want = (tok & 3u) + 1u, pt2, ps2;
           asm volatile("2:\n\tds_read_b32 %[pt], %[fa]\n\ts_waitcnt lgkmcnt(0)\n\tv_readfirstlane_b32 %[ps], %[pt]\n\ts_nop 3\n\t"
-                       "s_cmp_ge_u32 %[ps], %[want]\n\ts_cbranch_scc1 3f\n\ts_sleep " HZ_POLL_SLEEP "\n\ts_sub_u32 %[pc], %[pc], 1\n\t"
-                       "s_cmp_lg_u32 %[pc], 0\n\ts_cbranch_scc1 2b\n\t3:"
+                       "s_cmp_ge_u32 %[ps], %[want]\n\ts_cbranch_scc1 3f\n\ts_cmp_eq_u32 %[pc], 0\n\ts_cbranch_scc1 3f\n\t"
+                       "s_sleep " HZ_POLL_SLEEP "\n\ts_sub_u32 %[pc], %[pc], 1\n\ts_branch 2b\n\t3:"
                        : [pt] "=&v"(pt2), [ps] "=&s"(ps2), [pc] "+s"(pc2)
                        : [fa] "v"(fa2), [want] "s"(want)
                        : "memory", "scc");
-          HZ_POLL_GIVEUP(pc2);
         }
+        HZ_POLL_GIVEUP(pc2);
       }
     }
     if (J.flags & HZ_MLP_STORE_HIDDEN) {
@@ -527,8 +528,8 @@ __device__ __forceinline__ void mlp_body(
         // fragments and run the block without reading past it
 #define HZ_POLL()                                                                                                       \
             "2:\n\tds_read_b32 %[pt], %[fa]\n\ts_waitcnt lgkmcnt(0)\n\tv_readfirstlane_b32 %[ps], %[pt]\n\ts_nop 3\n\t"        \
-            "s_cmp_ge_u32 %[ps], 4\n\ts_cbranch_scc1 3f\n\ts_sleep " HZ_POLL_SLEEP "\n\ts_sub_u32 %[pc], %[pc], 1\n\ts_cmp_lg_u32 %[pc], 0\n\t"   \
-            "s_cbranch_scc1 2b\n\t3:\n\t"
+            "s_cmp_ge_u32 %[ps], 4\n\ts_cbranch_scc1 3f\n\ts_cmp_eq_u32 %[pc], 0\n\ts_cbranch_scc1 3f\n\t"  /* (no tries left: not this block either) */ \
+            "s_sleep " HZ_POLL_SLEEP "\n\ts_sub_u32 %[pc], %[pc], 1\n\ts_branch 2b\n\t3:\n\t"
 #define HZ_K1B_BODY()                                                                                           \
         asm volatile(                                                                                           \
             "1:\n\t" HZ_POLL()                                                                                   \

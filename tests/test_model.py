@@ -307,6 +307,8 @@ def test_blockwise_layer_boundaries_equal_barriers(game, rows, dtype, monkeypatc
     pool = (torch.rand(S, N, eng.H, device="cuda", generator=g) * 2).to(dtype)
     ix = torch.randint(0, S, (N,), device="cuda", generator=g).to(torch.int32)
     act = torch.randint(0, eng.A, (N,), device="cuda", generator=g).to(torch.int32)
+    from hanabizero_amd._lib import poll_giveups
+    giveups_before = poll_giveups()
     outs, flags = [], []
     for blockwise, waits in (("1", "1"), ("1", "0"), ("0", "0")):  # counters everywhere | blockwise boundaries only | barriers only
         monkeypatch.setenv("HANABIZERO_MLP_BLOCKWISE", blockwise)
@@ -326,11 +328,40 @@ def test_blockwise_layer_boundaries_equal_barriers(game, rows, dtype, monkeypatc
     assert not any(x & MLP_WAITS for x in flags[1]) and any(x & MLP_BARRIER for x in flags[1])
     assert not any(x & (MLP_BLOCKWISE | MLP_SIGNAL | MLP_WAITS) for x in flags[2])
     from hanabizero_amd._lib import poll_giveups
-    assert poll_giveups() == 0
+    assert poll_giveups() == giveups_before
     bits = lambda t: t.view(torch.int16) if t.dtype != torch.float32 else t
     for other in outs[1:]:
         for a, b in zip(outs[0], other):
             assert torch.equal(bits(a), bits(b))
+
+
+@pytest.mark.gpu
+def test_a_job_table_that_breaks_the_counter_contract_times_out_and_says_so():
+    """A consumer that waits for a producer which never signals (the table lies) must not hang the GPU: every wait gives up
+    after 2^16 looks, the launch ends, and hz_mlp_poll_giveups counts what happened (include/hz_mlp.h)."""
+    import ctypes
+    import time
+    from hanabizero_amd._lib import MlpJob, poll_giveups
+    from hanabizero_amd.model import FusedRecurrent, InferenceEngine, MLP_BLOCKWISE, MLP_SIGNAL
+    net, fx, sup = build("Hanabi-Small")
+    eng = InferenceEngine(net, sup, dtype=torch.bfloat16, device="cuda")
+    f = FusedRecurrent(net, eng, 16, 2)
+    tab = _job_table(f)
+    first = next(p for p in range(f.n_jobs) if tab[p * 16].flags & MLP_BLOCKWISE)
+    for w in range(16):  # the producer of the first blockwise pass forgets to signal
+        tab[(first - 1) * 16 + w].flags &= ~MLP_SIGNAL
+    f.jobs = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to("cuda")
+    N = 16  # one workgroup
+    pool = torch.rand(1, N, eng.H, device="cuda").to(torch.bfloat16)
+    ix, act = torch.zeros(N, dtype=torch.int32, device="cuda"), torch.zeros(N, dtype=torch.int32, device="cuda")
+    h = torch.zeros(N, eng.H, dtype=torch.bfloat16, device="cuda")
+    r, v, p = torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda"), torch.zeros(N, eng.A, device="cuda")
+    before = poll_giveups()
+    t0 = time.time()
+    f(pool, ix, act, h, r, v, p, rows_per_wg=16)
+    torch.cuda.synchronize()
+    assert time.time() - t0 < 30.0
+    assert poll_giveups() > before
 
 
 @pytest.mark.gpu
