@@ -310,12 +310,12 @@ class InferenceEngine:
         if self.use_fused:
             if not self._fused_shapes:
                 self._fused_shapes[(4, 4)] = FusedRecurrent(net, self)
-                self.fused_tail = FusedInitialTail(net, self, 8, 4) if self.full else None  # 8 x 4: fastest stand-alone shape
+                self.fused_tail = FusedInitialTail(net, self, 16, 2) if self.full else None  # (the shape that has the arrival counters)
             else:  # same job tables, new numbers: into the tensors the kernels (and captured graphs) already point at
                 for (waves, tiles), chain in self._fused_shapes.items():
                     chain.reload(FusedRecurrent(net, self, waves, tiles, host_only=True))
                 if self.fused_tail is not None:
-                    self.fused_tail.reload(FusedInitialTail(net, self, 8, 4, host_only=True))
+                    self.fused_tail.reload(FusedInitialTail(net, self, 16, 2, host_only=True))
             self.fused = self._fused_shapes[(4, 4)]
         self.version += 1
 
