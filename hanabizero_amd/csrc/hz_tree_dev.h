@@ -154,8 +154,8 @@ __device__ __forceinline__ void hz_ptab_fill(float* ptab, const float* pbc_tab, 
 // the oldest waves needed 21 k cycles at 8192 envs); priorities that grow with the depth of the descent did nothing.  What is
 // in: youngest first for the first half of a tree phase (read-out, expansion, backup: hz_tree_phase_prio), equal priorities
 // -- the hardware's oldest first -- for the descent (hz_tree_descent_prio), so that neither age group is last in both
-// halves: another +1.0 % at 4096 envs, +1.5 % at 8192 (oldest-first made explicit in the descent, or the halves the other
-// way round, gain less).
+// halves: another +1.0 % at 4096 envs, +1.5 % at 8192 (oldest-first made explicit in the descent, the halves the other way
+// round, or the switch behind the read-out or behind the expansion instead: all less).
 __device__ __forceinline__ void hz_tree_descent_prio() { __builtin_amdgcn_s_setprio(0); }
 __device__ __forceinline__ void hz_tree_phase_prio() {
   switch (__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8)) {
