@@ -48,8 +48,8 @@ struct ElF16 {
   }
 };
 
-// inverse_scalar_transform of LDS rows of EL logits, one (row, head) pair per 32-lane half of the wave: lane l32
-// owns logits [8*l32, 8*l32 + 8) (one ds_read_b128; Hanabi-Full's supports have 201 bins), max and sums over the half by
+// inverse_scalar_transform of LDS rows of fp32 logits, one (row, head) pair per 32-lane half of the wave: lane l32
+// owns logits [8*l32, 8*l32 + 8) (two ds_read_b128; Hanabi-Full's supports have 201 bins), max and sums over the half by
 // DPP-modified v_max / v_add (hz_common.h::hz_wave_max has the reasons): butterflies inside the 16-lane rows, row_bcast:15
 // into the odd rows, lanes 31 / 63 hold the halves' results.  V <= 256.  Same maths as hz_tree.hip support_to_scalar.
 // (Tried: one logit per lane and trip, ceil(V / 32) trips -- fewer instructions for small V, 1.7 % slower end to end at
@@ -71,23 +71,22 @@ __device__ __forceinline__ float half32_sum(float v) {
   const float lo = hz_readlane_f(v, 31), hi = hz_readlane_f(v, 63);
   return (threadIdx.x & 32) ? hi : lo;
 }
-template <class EL>
-__device__ __forceinline__ float row32_support_to_scalar(const uint16_t* row, int V, int support_min, int l32) {
-  uint32_t w[4];
+// `row`: the image row; the head's fp32 logits (HZ_MLP_F32_OUT) start at 16-bit column `off`, those from logit `split` on
+// (a multiple of 32, so a lane's eight never straddle it) at column `off2`: include/hz_mlp.h::hz_mlp_header_t.
+__device__ __forceinline__ float row32_support_to_scalar(const uint16_t* row, int off, int off2, int split, int V,
+                                                         int support_min, int l32) {
   const int base = 8 * l32;
+  float x[8];
   if (base < V) {
-    const uint4 a = *reinterpret_cast<const uint4*>(row + base);
-    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
+    const float4* p = reinterpret_cast<const float4*>(row + (base < split ? off + 2 * base : off2 + 2 * (base - split)));
+    const float4 a = p[0], b = p[1];
+    x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
   } else {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) w[k] = 0;
+    for (int k = 0; k < 8; ++k) x[k] = 0.0f;
   }
-  float x[8];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    x[2 * k] = (base + 2 * k < V) ? EL::lo(w[k]) : -INFINITY;
-    x[2 * k + 1] = (base + 2 * k + 1 < V) ? EL::hi(w[k]) : -INFINITY;
-  }
+  for (int k = 0; k < 8; ++k) x[k] = (base + k < V) ? x[k] : -INFINITY;
   float m = -INFINITY;
 #pragma unroll
   for (int k = 0; k < 8; ++k) m = fmaxf(m, x[k]);
@@ -110,6 +109,11 @@ __device__ __forceinline__ float row32_support_to_scalar(const uint16_t* row, in
   if (v < 0.0f) out = -out;
   if (out != out) out = 0.0f;
   return out;
+}
+// policy logit a of an image row (fp32, HZ_MLP_F32_OUT), NaN -> 0 (core/mcts.py:48-49)
+__device__ __forceinline__ float row_policy_logit(const uint16_t* row, int off_policy, int a) {
+  const float x = reinterpret_cast<const float*>(row + off_policy)[a];
+  return x != x ? 0.0f : x;
 }
 
 // Diagnostic build only (-DHZ_MLP_PROFILE, tools/mlp_profile.py): per-phase shader-cycle sums of workgroup 100.
@@ -723,13 +727,21 @@ __device__ __forceinline__ void mlp_body(
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = (v[r] > 0.0f || v[r] != v[r]) ? v[r] : 0.0f;
         }
-        uint2 o;
-        o.x = EL::pack(v[0], v[1]);
-        o.y = EL::pack(v[2], v[3]);
-        *reinterpret_cast<uint2*>(lds + rowbase + J.dst_off + col) = o;
+        if (J.flags & HZ_MLP_F32_OUT) {  // the head's last layer: fp32 to the scalar transform / the tree (include/hz_mlp.h)
+          *reinterpret_cast<float4*>(lds + rowbase + J.dst_off + 2 * col) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+          uint2 o;
+          o.x = EL::pack(v[0], v[1]);
+          o.y = EL::pack(v[2], v[3]);
+          *reinterpret_cast<uint2*>(lds + rowbase + J.dst_off + col) = o;
+        }
       }
     }
-    if (ASMK && (J.flags & HZ_MLP_SIGNAL)) {  // this wave's columns are in the image (LDS executes a wave's operations in order)
+    if (ASMK && (J.flags & HZ_MLP_SIGNAL)) {
+      // this wave's columns are in the image before its arrival shows: the epilogue's LDS stores are not to sink below this point
+      // (compiler barrier) and have completed (lgkmcnt; an LDS-only wait: a release fence proper may also wait for vector memory,
+      // i.e. for the weight ring)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       unsigned int* ready = reinterpret_cast<unsigned int*>(lds + (size_t)j * rs + (rs - 8)) + (wave >> 2);
       if (lane == 0) __hip_atomic_fetch_add(ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
@@ -751,16 +763,15 @@ __device__ __forceinline__ void mlp_body(
       const int r = pair >> 1, head = pair & 1;
       if (row0 + r < n_rows) {  // (uniform over the 32 lanes of a pair)
         const uint16_t* row = lds + (size_t)r * rs;
-        const float x = row32_support_to_scalar<EL>(row + (head ? H.off_value : H.off_reward), H.support_size, H.support_min, l32);
+        const float x = row32_support_to_scalar(row, head ? H.off_value : H.off_reward, head ? H.off_value2 : H.off_reward2,
+                                                H.logit_split, H.support_size, H.support_min, l32);
         if (l32 == 0) (head ? out_value : out_reward)[row0 + r] = x;
       }
     }
     for (int i = tid; i < MT * H.num_actions; i += NTHR) {
       const int r = i / H.num_actions, a = i % H.num_actions;
       if (row0 + r < n_rows) {
-        float x = EL::one(lds[(size_t)r * rs + H.off_policy + a]);
-        if (x != x) x = 0.0f;  // core/mcts.py:48-49
-        out_policy[(size_t)(row0 + r) * H.num_actions + a] = x;
+        out_policy[(size_t)(row0 + r) * H.num_actions + a] = row_policy_logit(lds + (size_t)r * rs, H.off_policy, a);
       }
     }
   }

@@ -99,13 +99,10 @@ __device__ __forceinline__ RowFrag search_backup_descent(const TreeView& tv, con
   // lane a takes policy logit a
   {
     const uint16_t* row = L.image + (size_t)srow * H.row_stride;
-    const float x = row32_support_to_scalar<EL>(row + ((lane >> 5) ? H.off_value : H.off_reward), H.support_size,
-                                                H.support_min, lane & 31);
+    const float x = row32_support_to_scalar(row, (lane >> 5) ? H.off_value : H.off_reward, (lane >> 5) ? H.off_value2 : H.off_reward2,
+                                            H.logit_split, H.support_size, H.support_min, lane & 31);
     float pl = 0.0f;
-    if (lane < tv.A) {
-      pl = EL::one(row[H.off_policy + lane]);
-      if (pl != pl) pl = 0.0f;  // core/mcts.py:48-49
-    }
+    if (lane < tv.A) pl = row_policy_logit(row, H.off_policy, lane);
     tl.leaf_reward = hz_readlane_f(x, 0);
     tl.leaf_value = hz_readlane_f(x, 32);
     tl.leaf_logit = pl;
@@ -320,14 +317,9 @@ __global__ __launch_bounds__(1024, 1) __attribute__((amdgpu_num_vgpr(HZ_ASMK_VGP
     {  // the leaf's heads, from the row image into registers: each half's 32 lanes turn first its reward logits, then its
       // value logits into scalars (uniform within the half); lane l takes policy logit l
       const uint16_t* row = L.image + (size_t)(TW * q.h + wave) * H.row_stride;
-      t.leaf_reward = row32_support_to_scalar<EL>(row + H.off_reward, H.support_size, H.support_min, q.l);
-      t.leaf_value = row32_support_to_scalar<EL>(row + H.off_value, H.support_size, H.support_min, q.l);
-      float pl = 0.0f;
-      if (q.l < tv.A) {
-        pl = EL::one(row[H.off_policy + q.l]);
-        if (pl != pl) pl = 0.0f;  // core/mcts.py:48-49
-      }
-      t.leaf_logit = pl;
+      t.leaf_reward = row32_support_to_scalar(row, H.off_reward, H.off_reward2, H.logit_split, H.support_size, H.support_min, q.l);
+      t.leaf_value = row32_support_to_scalar(row, H.off_value, H.off_value2, H.logit_split, H.support_size, H.support_min, q.l);
+      t.leaf_logit = q.l < tv.A ? row_policy_logit(row, H.off_policy, q.l) : 0.0f;
     }
     int rv, a0;
     float4 first;

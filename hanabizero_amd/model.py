@@ -484,6 +484,7 @@ class InferenceEngine:
 
 # ------------------------------------------------------------------------------------------------ fused MFMA kernel
 MLP_RELU, MLP_ACTION_ROW, MLP_BARRIER, MLP_STORE_HIDDEN, MLP_SIGNAL, MLP_BLOCKWISE, MLP_WAITS, MLP_LAST = 1, 2, 4, 8, 16, 32, 64, 128  # include/hz_mlp.h flags
+MLP_F32_OUT = 2048
 
 
 def _pack_fragments(wblk, ks, tiles=4):
@@ -518,7 +519,7 @@ class _FusedChain:
         self._jobs = []        # [pass] -> dict(entries [wave] -> dict or None, barrier, store_hidden)
         self.blockwise = (waves, tiles) == (16, 2) and os.environ.get("HANABIZERO_MLP_BLOCKWISE", "1") != "0"
 
-    def add_dense(self, w, b, K, src_off, dst_off, relu, res_off=None, barrier=True, store_hidden=False, act_w=None):
+    def add_dense(self, w, b, K, src_off, dst_off, relu, res_off=None, barrier=True, store_hidden=False, act_w=None, f32=False):
         """out[:, dst_off:dst_off+nout] = act(in[:, src_off:src_off+K] @ w^T + b ...), nout split into cw-column
         wave jobs, `waves` per pass.
         16 x 2 shape: where a full-width layer (one pass, every wave 32 columns of a 512-column output) feeds the next
@@ -537,8 +538,8 @@ class _FusedChain:
                     row.append(None)
                     continue
                 c, n = chunks[p0 + wave]
-                row.append(dict(w=w[c:c + n], b=b[c:c + n], ks=K // 32, src=src_off, dst=dst_off + c,
-                                res=None if res_off is None else res_off + c, relu=relu,
+                row.append(dict(w=w[c:c + n], b=b[c:c + n], ks=K // 32, src=src_off, dst=dst_off + (2 * c if f32 else c),
+                                res=None if res_off is None else res_off + c, relu=relu, f32=f32,
                                 act=None if act_w is None else act_w[c:c + n]))
             self._jobs.append(dict(entries=row, barrier=barrier and p0 == 0 and not blockwise, store_hidden=store_hidden and p0 == 0,
                                    blockwise=blockwise and p0 == 0,
@@ -547,14 +548,15 @@ class _FusedChain:
             prev["signal"] = True
 
     def add_group(self, items, K, barrier=True, store_hidden=False):
-        """independent small layers (w, b, src, dst, res, relu) side by side: cut into cw-column jobs, `waves`
-        per pass."""
+        """independent small layers (w, b, src, dst, res, relu[, f32]) side by side: cut into cw-column jobs, `waves`
+        per pass.  f32: the layer's outputs stay fp32 (HZ_MLP_F32_OUT: output column c at image columns dst + 2 c)."""
         cw, waves = self.cw, self.waves
         cut = []
-        for w, b, src, dst, res, relu in items:
+        for w, b, src, dst, res, relu, *opt in items:
+            f32 = bool(opt and opt[0])
             for c in range(0, w.shape[0], cw):
-                cut.append(dict(w=w[c:c + cw], b=b[c:c + cw], ks=K // 32, src=src, dst=dst + c,
-                                res=None if res is None else res + c, relu=relu, act=None))
+                cut.append(dict(w=w[c:c + cw], b=b[c:c + cw], ks=K // 32, src=src, dst=dst + (2 * c if f32 else c),
+                                res=None if res is None else res + c, relu=relu, act=None, f32=f32))
         for p0 in range(0, len(cut), waves):
             row = cut[p0:p0 + waves] + [None] * (waves - len(cut[p0:p0 + waves]))
             self._jobs.append(dict(entries=row, barrier=barrier and p0 == 0, store_hidden=store_hidden and p0 == 0))
@@ -565,7 +567,9 @@ class _FusedChain:
         the other on them while the other lanes stream their own: no wave idles through a barrier because the layer at
         hand is narrow.  An element of a lane may also be a LIST of layers: independent of one another, they share the lane's
         waves in the same pass(es).  No layer of a stage may read what another layer of the same stage writes (there is no
-        barrier inside a stage; mlp_sync.verify checks the table that comes out); layers may have different K."""
+        barrier inside a stage; mlp_sync.verify checks the table that comes out); layers may have different K.  A layer may carry
+        an eighth element, f32 (HZ_MLP_F32_OUT); its `dst` is then either the first image column of 2 * nout contiguous ones or a
+        list with the first column of every job (a head's fp32 logits in more than one dead region of the image)."""
         cw, waves = self.cw, self.waves
         cap = waves // len(lanes)
         assert cap >= 1
@@ -574,11 +578,13 @@ class _FusedChain:
             r = 0
             for item in lane:
                 cut = []
-                for (w, b, K, src, dst, relu, res) in (item if isinstance(item, list) else [item]):
+                for (w, b, K, src, dst, relu, res, *opt) in (item if isinstance(item, list) else [item]):
+                    f32 = bool(opt and opt[0])
                     for c in range(0, w.shape[0], cw):
                         n = min(cw, w.shape[0] - c)
-                        cut.append(dict(w=w[c:c + n], b=b[c:c + n], ks=K // 32, src=src, dst=dst + c,
-                                        res=None if res is None else res + c, relu=relu, act=None))
+                        d = dst[c // cw] if isinstance(dst, (list, tuple)) else dst + (2 * c if f32 else c)
+                        cut.append(dict(w=w[c:c + n], b=b[c:c + n], ks=K // 32, src=src, dst=d,
+                                        res=None if res is None else res + c, relu=relu, act=None, f32=f32))
                 for j, e in enumerate(cut):
                     row = r + j // cap
                     while len(rows) <= row:
@@ -588,7 +594,7 @@ class _FusedChain:
         for k, row in enumerate(rows):
             self._jobs.append(dict(entries=row, barrier=barrier and k == 0, store_hidden=store_hidden and k == 0, fixed=True))
 
-    def _finish(self, width, in_width, hidden, state_off, hidden_off, off_r, off_v, off_p):
+    def _finish(self, width, in_width, hidden, state_off, hidden_off, off_r, off_v, off_p, logit_split=None, off_r2=0, off_v2=0):
         from ._lib import MlpHeader, MlpJob
         engine, waves, tiles, cw, jobs = self.engine, self.waves, self.tiles, self.cw, self._jobs
         A, V = engine.A, 2 * engine.support + 1
@@ -629,7 +635,7 @@ class _FusedChain:
             sj.append([mlp_sync.Job(reads=hid, active=False) if e is None else
                        mlp_sync.Job(reads=[(e["src"], e["src"] + 32 * e["ks"])] + hid +
                                     ([] if e["res"] is None else [(e["res"], e["res"] + cw)]),
-                                    writes=[(e["dst"], e["dst"] + cw)]) for e in row])
+                                    writes=[(e["dst"], e["dst"] + (2 * cw if e.get("f32") else cw))]) for e in row])
         if self.blockwise and os.environ.get("HANABIZERO_MLP_WAITS", "1") != "0" and len(jobs) <= 16 and rs - width >= 8:
             pass_flags, sig = mlp_sync.plan(pass_flags, sj, waves)
             signal_passes |= set(sig)
@@ -668,6 +674,9 @@ class _FusedChain:
                     flags |= MLP_ACTION_ROW
                 if e["relu"]:
                     flags |= MLP_RELU
+                if e.get("f32"):
+                    assert e["res"] is None and e["dst"] % 8 == 0, "an fp32 output layer has no residual and starts on a 16-B boundary"
+                    flags |= MLP_F32_OUT
                 if self.blockwise and last_job[wave] == ji and not job.get("blockwise"):
                     flags |= MLP_LAST
                 table.append(MlpJob(ks=e["ks"], src_off=e["src"], dst_off=e["dst"],
@@ -693,7 +702,9 @@ class _FusedChain:
                         off_reward=off_r, off_value=off_v, off_policy=off_p, support_size=V, support_min=-engine.support,
                         num_actions=A, action_table_stride=biases.numel(), in_width=in_width,
                         dtype={torch.bfloat16: 1, torch.float16: 2}[engine.dtype],  # HZ_BF16 / HZ_F16 (include/hz_tree.h)
-                        num_waves=waves, tiles_per_wave=tiles, kstep_stride=waves * tiles * 512)
+                        num_waves=waves, tiles_per_wave=tiles, kstep_stride=waves * tiles * 512,
+                        logit_split=256 if logit_split is None else logit_split, off_reward2=off_r2, off_value2=off_v2)
+        assert hdr.logit_split % 32 == 0 and off_r % 8 == 0 and off_v % 8 == 0 and off_p % 8 == 0 and off_r2 % 8 == 0 and off_v2 % 8 == 0
         for wave in range(waves):
             hdr.wave_stream_off[wave] = wave * frag
         self.header = hdr
@@ -798,10 +809,22 @@ class FusedRecurrent(_FusedChain):
                             [(wa3, ba3, h, Ta, U, True, Z + h)]])  # (in place: a lane reads the residual element it then overwrites)
             # the three output layers in ONE last pass: value logits on lane 0, reward logits and policy side by side on lane 1 (the
             # passes with a few jobs each are bound by a wave's own latency, not by the stream: h3R used to follow h2V on lane 0
-            # and the policy had a pass of its own; the policy's logits go to E, dead since h3A has read it)
-            self.add_stage([[(wv3, bv3, h, Tv, V3, False, None)],
-                            [[(wr3, br3, h, Tr, R3, False, None), (wp4, bp4, h, U, E, False, None)]]])
-            off_r, off_v, off_p, width = R3, V3, E, max(3 * H + h, Z + 6 * h)
+            # and the policy had a pass of its own).  All three stay fp32 (HZ_MLP_F32_OUT: 2 image columns per logit) on their way
+            # to the scalar transform and the tree; they land in what is dead by now -- [0, h) (h1R's output), [2h, 3h) (h1V's),
+            # the second half of Y0 (the hidden state has left) and E (Ta, read by h3A) -- a head's 201 logits in two pieces:
+            # logits [0, 128) and the rest (header fields logit_split / off_*2).  The 4-tile shapes (64-column jobs: their
+            # last jobs are mostly padding) get 128 more columns behind the image for the policy; they run stand-alone.
+            split, cw = 128, self.cw
+            nj1, njV = split // cw, (V + cw - 1) // cw
+            seg = lambda a, b: [a + 2 * cw * j for j in range(nj1)] + [b + 2 * cw * j for j in range(njV - nj1)]
+            off_v, off_v2, off_r = 2 * h, Y0 + h, 0
+            off_r2 = off_v2 + 2 * cw * (njV - nj1)
+            off_p = off_r2 + 2 * cw * (njV - nj1)
+            width = max(3 * H + h, off_p + 2 * cw)
+            assert off_v2 >= Tv + h and off_r2 + 2 * cw * (njV - nj1) <= off_p
+            self.add_stage([[(wv3, bv3, h, Tv, seg(off_v, off_v2), False, None, True)],
+                            [[(wr3, br3, h, Tr, seg(off_r, off_r2), False, None, True), (wp4, bp4, h, U, off_p, False, None, True)]]])
+            fin = dict(off_r=off_r, off_v=off_v, off_p=off_p, logit_split=split, off_r2=off_r2, off_v2=off_v2)
         else:      # DynamicNet + 2-layer heads (model.py:61-91, 138-149)
             Z = Y1
             add_dense(w1s, b1, H, X, Y0, relu=True, res_off=X, barrier=False, act_w=w1a)
@@ -810,10 +833,12 @@ class FusedRecurrent(_FusedChain):
             add_dense(wh, bh, H, Y0, Z, relu=True)
             assert V <= 64 and A <= 64 and 2 * h <= 256
             kpad = 256                                      # K = h padded to 8 k-steps with zero weights
-            outs = [(_fold(rw[3]), Z, X), (_fold(ac[3]), Z + h, X + 64), (_fold(va[3]), Z + 2 * h, X + 128)]
-            add_group([(w, b, src, dst, None, False) for (w, b), src, dst in outs], kpad, store_hidden=True)  # (Y0 is still intact)
-            off_r, off_p, off_v, width = X, X + 64, X + 128, 3 * H
-        self._finish(width, in_width=H, hidden=H, state_off=X, hidden_off=Y0, off_r=off_r, off_v=off_v, off_p=off_p)
+            # (fp32 logits, HZ_MLP_F32_OUT: <= 64 logits = 128 image columns per head, over the dead input state)
+            outs = [(_fold(rw[3]), Z, X), (_fold(ac[3]), Z + h, X + 256), (_fold(va[3]), Z + 2 * h, X + 128)]
+            add_group([(w, b, src, dst, None, False, True) for (w, b), src, dst in outs], kpad, store_hidden=True)  # (Y0 is still intact)
+            fin = dict(off_r=X, off_v=X + 128, off_p=X + 256)
+            width = 3 * H
+        self._finish(width, in_width=H, hidden=H, state_off=X, hidden_off=Y0, **fin)
 
     def __call__(self, pool, ix, actions, hidden_out, out_reward, out_value, out_policy, rows_per_wg=None):
         """pool [S, N, H] (or a [N, H] matrix of states with ix=None)."""
@@ -855,9 +880,9 @@ class FusedInitialTail(_FusedChain):
         bh = torch.cat([_fold(ac[0], ac[1])[1], _fold(va[0], va[1])[1]], 0)
         add_dense(wh, bh, H, S, Z, relu=True, store_hidden=True)           # actor | value first layers
         add_group([(*_fold(ac[3].fc1, ac[3].bn1), Z, Ta, None, True), (*_fold(va[3], va[4]), Z + h, Tv, None, True)], h)
-        add_group([(*_fold(ac[3].fc2, ac[3].bn2), Ta, U, Z, True), (*_fold(va[6]), Tv, V3, None, False)], h)
-        add_dense(*_fold(ac[4]), h, U, Z, relu=False, barrier=True)        # policy logits over the dead Z
-        width = V3 + ((V + 63) // 64) * 64
+        add_group([(*_fold(ac[3].fc2, ac[3].bn2), Ta, U, Z, True), (*_fold(va[6]), Tv, V3, None, False, True)], h)  # (value logits: fp32)
+        add_dense(*_fold(ac[4]), h, U, Z, relu=False, barrier=True, f32=True)  # policy logits (fp32) over the dead Z
+        width = V3 + 2 * ((V + 63) // 64) * 64
         self.in_width = IN
         self._finish(width, in_width=IN, hidden=H, state_off=0, hidden_off=S, off_r=V3, off_v=V3, off_p=Z)
         self._zeros = None

@@ -16,8 +16,10 @@
  * (its jobs' fragments in execution order; the streams are interleaved k-step by k-step), prefetched 3 k-steps ahead
  * in a register ring across job and layer boundaries.  hanabizero_amd/model.py::FusedRecurrent (recurrent inference)
  * and ::FusedInitialTail (the small-GEMM tail of the initial inference) build job tables and streams from a module.
- * Numerics: the rounding points of the bf16 PyTorch path (bf16 activations between layers, fp32 accumulation and
- * epilogue); checked against the reference's fp32 nets at the north-star tolerance (tests/test_model.py).
+ * Numerics: 16-bit (fp16 -- the reference's own autocast format, core/mcts.py:38-40 -- or bf16) weights and activations
+ * between layers, fp32 accumulation and epilogue; the last layer of every head (value / reward / policy logits) stays fp32
+ * through the scalar transform (HZ_MLP_F32_OUT).  Measured against the reference nets' fp32 outputs AND against the
+ * reference run under fp16 autocast (tests/golden/nets_*.npz, nets_*_autocast.npz; tests/test_model.py).
  * Conventions as include/hz_tree.h.
  */
 #ifndef HZ_MLP_H
@@ -56,7 +58,14 @@ enum {
   /* 16 waves x 2 tiles only, per entry: this is the wave's last job of the inference -- its k-loop requests no weight
    * fragments past its own (the other jobs' loops run 3 k-steps ahead into the next job's), so nothing is in flight when
    * the wave leaves the chain. */
-  HZ_MLP_LAST = 128
+  HZ_MLP_LAST = 128,
+  /* bits 8..10: token count of HZ_MLP_WAITS */
+  /* The job's outputs leave the epilogue as fp32, not rounded to the element format: output column c of the job goes to
+   * image columns [dst_off + 2 c, dst_off + 2 c + 2) (two 16-bit columns hold one float; dst_off % 8 == 0).  For the last
+   * layer of a head: the categorical value / reward logits and the policy logits reach the scalar transform (softmax . support
+   * through h^-1 amplifies their rounding) and the tree with the accumulators' precision.  No residual, no consumer job: only the
+   * final stage (or the search kernel's tree waves) reads them. */
+  HZ_MLP_F32_OUT = 2048
 };
 
 /* One (job, wave) entry; all offsets are bf16-element columns of the LDS row image.  ks == 0: this wave idles.
@@ -78,7 +87,9 @@ typedef struct {
   int32_t hidden;      /* width of the hidden state written by HZ_MLP_STORE_HIDDEN (multiple of 8) */
   int32_t state_off;   /* LDS column where the input hidden state is staged */
   int32_t hidden_off;  /* LDS column of the next hidden state when HZ_MLP_STORE_HIDDEN fires */
-  int32_t off_reward, off_value, off_policy; /* LDS columns of the final reward / value / policy logits */
+  int32_t off_reward, off_value, off_policy; /* LDS columns (16-bit units, multiples of 8) where the final reward / value /
+                                                policy logits start -- fp32 (HZ_MLP_F32_OUT): logit k of a head sits 2 k
+                                                columns behind its offset, except ... */
   int32_t support_size, support_min, num_actions;
   int32_t action_table_stride;   /* fp32 elements per action row */
   int32_t in_width;              /* elements of an input row staged at state_off (multiple of 8; = hidden for the
@@ -88,6 +99,11 @@ typedef struct {
                                     (include/hz_tree.h); accumulation and epilogues are fp32 in both */
   int32_t num_waves;             /* 4 (stand-alone kernel) or 16 (inside hz_search_run) */
   int32_t tiles_per_wave;        /* 16-column MFMA tiles per job: 4 with 4 waves, 2 with 16 waves */
+  int32_t logit_split;           /* ... value / reward logits k >= logit_split (a multiple of 32; >= support_size: none), which sit
+                                    2 (k - logit_split) columns behind off_value2 / off_reward2: a head's fp32 logits may
+                                    occupy two dead regions of the image instead of one contiguous range */
+  int32_t off_reward2, off_value2;
+  int32_t reserved1;
   int64_t kstep_stride;          /* elements between consecutive k-steps of one wave's stream: 512 * tiles_per_wave when
                                     each stream is contiguous, 512 * tiles_per_wave * num_waves when the streams are
                                     interleaved k-step by k-step (all waves of a workgroup then read one contiguous

@@ -116,16 +116,23 @@ def test_inference_engine_on_gpu(game):
 
 
 # Measured worst / mean errors of the product path against the reference's fp32 outputs on the golden inputs
-# (tests/netgold.py::golden_net_error; relative to max(1, |ref|)) and the bounds asserted: ~1.5x the measured worst element.
-# fp32 meets north_star's 1e-3; fp16 (the reference's own autocast format, core/mcts.py:38-40) and bf16 are at the accuracy
-# 11 / 8 significand bits allow after ~10 layers -- the value / reward scalars amplify their logits' rounding through
-# softmax . support and h^-1.  bench.py prints the same measurement as `net_error` for the dtype it ran.
+# (tests/netgold.py::golden_net_error; relative to max(1, |ref|)) and the bounds asserted: <= 1.5x the measured worst field
+# (r03, head logits fp32 through the scalar transform: fp32 7.2e-5 / 3.7e-6, fp16 5.5e-3 / 2.0e-3, bf16 3.9e-2 / 1.4e-2).
+# fp32 meets north_star's 1e-3.  fp16 is the reference's own search format (autocast, core/mcts.py:38-40): its bound is DERIVED
+# FROM THE REFERENCE -- the fp16 engine must be no further from the reference's fp32 outputs than the reference itself is when
+# run under fp16 autocast (tests/golden/nets_*_autocast.npz: worst 4.4e-3 Small / 6.5e-3 Full) -- and 1e-3 is out of reach of
+# any engine whose hidden-state pool is 16-bit: rounding the golden input state to fp16 alone moves the reward scalar by 2.9e-3
+# (tools/net_error_ablation.py).  bench.py prints the same measurement as `net_error` for the dtype it ran.
 NET_ERROR_BOUND = {
     # dtype: (bound on every output's worst element, bound on every output's mean)
     torch.float32: (1e-3, 1e-4),
-    torch.float16: (1.2e-2, 4e-3),
-    torch.bfloat16: (8e-2, 1.5e-2),
+    torch.float16: (8e-3, 3e-3),
+    torch.bfloat16: (5.5e-2, 2e-2),
 }
+# search level (tests/netgold.py::search_divergence, 512 roots x 49 simulations against the fp32 engine's search):
+# (minimum share of roots with the same most-visited action, maximum mean total-variation distance of the visit distributions)
+# measured r03: fp16 0.975-0.986 / 0.0016-0.0053, bf16 0.857-0.927 / 0.0097-0.029
+SEARCH_DIVERGENCE_BOUND = {torch.float16: (0.95, 0.01), torch.bfloat16: (0.80, 0.045)}
 
 
 @pytest.mark.gpu
@@ -133,15 +140,48 @@ NET_ERROR_BOUND = {
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
 def test_benched_inference_path_error_against_reference_goldens(game, dtype):
     """The path bench.py times in each --dtype (fused MFMA kernels for bf16 / fp16, GEMM chain for fp32) against the
-    reference nets' fp32 outputs: the measured error is printed and bounded per format."""
+    reference nets' fp32 outputs: the measured error is printed and bounded per format; the fp16 engine -- the reference's
+    search format -- additionally against the reference's own fp16-autocast outputs."""
     from tests.netgold import golden_net_error
     err = golden_net_error(game, dtype)
     assert err["fused"] == (dtype != torch.float32)
     mx, mean = NET_ERROR_BOUND[dtype]
-    print("net error %s %s: %s" % (game, dtype, {k: v for k, v in err.items() if isinstance(v, dict)}))
-    for k, v in err.items():
-        if isinstance(v, dict):
-            assert v["max"] <= mx and v["mean"] <= mean, (game, dtype, k, v)
+    fields = {k: v for k, v in err.items() if isinstance(v, dict) and "max" in v}
+    print("net error %s %s: %s; vs reference under fp16 autocast %.3g; reference autocast vs its fp32 %.3g" % (
+        game, dtype, fields, err["vs_reference_autocast"]["worst"], err["reference_autocast_vs_fp32"]["worst"]))
+    assert len(fields) == 7
+    for k, v in fields.items():
+        assert v["max"] <= mx and v["mean"] <= mean, (game, dtype, k, v)
+    if dtype == torch.float16:
+        ref = err["reference_autocast_vs_fp32"]
+        # no further from fp32 than the reference's own search-time outputs are (worst element over all outputs) ...
+        assert err["worst"] <= ref["worst"], (err["worst"], ref["worst"])
+        # ... and on the wide sample (256 rows: the 32-row means of the amplified scalars are noise) the engine's rms error, as
+        # a ratio to the reference-under-autocast's own rms error of the same output, is below 1 on average over the outputs and
+        # nowhere above 1.3 (measured r03: Small 0.71 - 1.05, Full 0.76 - 1.24; the outliers are the value scalars, where the
+        # FIXED rounding errors of a head's weights act on positive-mean ReLU inputs as a near-constant shift -- which way it
+        # falls is a property of the weight set, tools/net_error_ablation.py)
+        w = err["wide"]
+        ratios = {k: v["rms"] / w["reference_autocast_vs_fp32"][k]["rms"] for k, v in w["got_vs_fp32"].items()}
+        print("wide sample, rms(engine - fp32) / rms(reference autocast - fp32):", ratios)
+        assert max(ratios.values()) <= 1.3 and sum(ratios.values()) / len(ratios) <= 1.0, ratios
+        # the two 16-bit computations of the same nets differ from each other by no more than each differs from fp32
+        assert err["vs_reference_autocast"]["worst"] <= 1.5 * ref["worst"]
+    if dtype == torch.float32:
+        assert abs(err["vs_reference_autocast"]["worst"] - err["reference_autocast_vs_fp32"]["worst"]) < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("game", ["Hanabi-Small", "Hanabi-Full"])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_search_level_divergence_of_the_16_bit_engines(game, dtype):
+    """What the net error does to the quantity the contract cares about: visit counts and chosen actions of the benched engine's
+    search (persistent kernel, fused MFMA inference) against the fp32 engine's search of the same roots."""
+    from tests.netgold import search_divergence
+    d = search_divergence(game, dtype, roots=512)
+    print("search divergence %s %s: %s" % (game, dtype, d))
+    agree, tv = SEARCH_DIVERGENCE_BOUND[dtype]
+    assert d["argmax_agreement"] >= agree and d["visit_tv_mean"] <= tv, d
 
 
 @pytest.mark.gpu
@@ -155,7 +195,7 @@ def test_fused_mfma_recurrent_kernel(game, N, dtype):
     net, fx, sup = build(game)
     eng = InferenceEngine(net, sup, dtype=dtype, device="cuda")
     fused = FusedRecurrent(net, eng)
-    ulp = 2.0 ** -8 if dtype == dtype else 2.0 ** -11
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
     g = torch.Generator(device="cuda").manual_seed(N)
     B = fx["init_hidden"].shape[0]
     hid = torch.from_numpy(fx["init_hidden"]).cuda().to(dtype)

@@ -13,7 +13,7 @@ The fixtures are DATA: inputs and the reference's outputs.  No reference source 
   nets_<game>.npz   reference MuZeroNet / MuZeroNetFull (config/hanabi_control/model.py, loaded by file path)
                     state_dict + inputs + initial/recurrent inference outputs, CPU fp32, eval mode.
 
-Usage: python tools/gen_golden.py [--only tree|env|nets]
+Usage: python tools/gen_golden.py [--only tree|env|nets|nets_autocast]
 """
 import argparse
 import os
@@ -261,6 +261,62 @@ def gen_nets():
         print("nets", game, "params", sum(p.numel() for p in net.parameters()))
 
 
+def gen_nets_autocast():
+    """The same reference nets on the same inputs (read back from nets_<game>.npz), run UNMODIFIED under
+    torch.autocast(dtype=float16) -- the precision the reference searches with (core/mcts.py:38-40 wraps initial_inference /
+    recurrent_inference in autocast(); train.sh:10 --amp_type torch_amp) -- on the CPU, where this torch build supports fp16
+    autocast (bf16 autocast computes, but the reference's own `.numpy()` on its outputs refuses bfloat16).  What the fixture pins:
+    how far the reference's OWN search-time outputs are from its fp32 outputs, the yardstick for the 16-bit engines."""
+    import importlib.util
+    import torch
+    sys.path.insert(0, "/root/reference")
+    spec = importlib.util.spec_from_file_location("ref_hanabi_model", "/root/reference/config/hanabi_control/model.py")
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    from tests.netgold import fill_state_dict
+    for game, cls in [("Hanabi-Small", m.MuZeroNet), ("Hanabi-Full", m.MuZeroNetFull)]:
+        fx = dict(np.load(os.path.join(GOLD, "nets_%s.npz" % game)))
+        D, A, sup, stack = int(fx["D"]), int(fx["A"]), int(fx["support"]), int(fx["stack"])
+        inv = lambda x, s=sup: inverse_scalar_transform(x.float(), -s, s)
+        net = cls(D * stack, A, 2 * sup + 1, 2 * sup + 1, inv, inv)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in fill_state_dict(net.state_dict()).items()})
+        net.eval()
+        with torch.no_grad(), torch.autocast("cpu", dtype=torch.float16):
+            o0 = net.initial_inference(torch.from_numpy(fx["obs"]))
+            o1 = net.recurrent_inference(torch.from_numpy(fx["init_hidden"]), torch.from_numpy(fx["action"]))
+        assert o1.hidden_state.dtype == np.float16, "autocast did not reach the nets"
+        out = dict(init_value=o0.value, init_logits=o0.policy_logits, init_hidden=o0.hidden_state, rec_value=o1.value,
+                   rec_reward=o1.reward, rec_logits=o1.policy_logits, rec_hidden=o1.hidden_state)
+        out = {k: np.asarray(v, np.float32) for k, v in out.items()}
+        # a wider sample for statistics that 32 rows cannot carry (the value / reward scalars amplify their logits' error: means
+        # over 32 of them are noise): 256 fresh observation windows (bit-packed) and 256 input hidden states that are EXACT in
+        # fp16 (the initial inference's fp32 hidden states rounded once: both precisions then see identical inputs, as the search
+        # does -- its pool holds 16-bit states), through the fp32 nets and the same nets under fp16 autocast; scalars and policy
+        # logits only
+        Bw = 256
+        g = torch.Generator().manual_seed(1234)
+        obs_w = (torch.rand(Bw, D * stack, generator=g) < 0.3)
+        act_w = torch.randint(0, A, (Bw, 1), generator=g)
+        with torch.no_grad():
+            f0 = net.initial_inference(obs_w.float())
+            hid_w = torch.from_numpy(f0.hidden_state).half()
+            f1 = net.recurrent_inference(hid_w.float(), act_w)
+            with torch.autocast("cpu", dtype=torch.float16):
+                a0 = net.initial_inference(obs_w.float())
+                a1 = net.recurrent_inference(hid_w.float(), act_w)
+        out.update(wide_obs_bits=np.packbits(obs_w.numpy(), axis=1), wide_action=act_w.numpy().astype(np.int32),
+                   wide_hidden_in=hid_w.numpy())
+        for tag, (o0, o1) in (("fp32", (f0, f1)), ("autocast", (a0, a1))):
+            out.update({"wide_%s_init_value" % tag: np.asarray(o0.value, np.float32), "wide_%s_init_logits" % tag: np.asarray(o0.policy_logits, np.float32),
+                        "wide_%s_rec_value" % tag: np.asarray(o1.value, np.float32), "wide_%s_rec_reward" % tag: np.asarray(o1.reward, np.float32),
+                        "wide_%s_rec_logits" % tag: np.asarray(o1.policy_logits, np.float32)})
+        np.savez_compressed(os.path.join(GOLD, "nets_%s_autocast.npz" % game), **out)
+        out = {k: v for k, v in out.items() if not k.startswith("wide_")}
+        worst = max(float(np.max(np.abs(np.asarray(v, np.float64).reshape(-1) - fx[k].astype(np.float64).reshape(-1)) /
+                                 np.maximum(1.0, np.abs(fx[k].astype(np.float64).reshape(-1))))) for k, v in out.items())
+        print("nets autocast(fp16)", game, "worst |autocast - fp32| / max(1, |fp32|) = %.3g" % worst)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -286,6 +342,8 @@ def main():
         gen_env("Hanabi-Full-5p", [0, 1, 7, 123], ["first", "hash", "smart", "perfect"], episodes=3)
     if args.only in ("", "nets"):
         gen_nets()
+    if args.only in ("", "nets", "nets_autocast"):
+        gen_nets_autocast()
 
 
 if __name__ == "__main__":
