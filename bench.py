@@ -9,15 +9,16 @@ sampling -> HIP env step + encode -> finished-game flush -> reset.  Inputs are r
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Rank 0 prints ONE JSON line.  Besides the driver's contract fields it carries
-  net_error     measured error of the nets in the dtype of this run against the reference nets' fp32 outputs (tests/golden)
+  net_error     measured error of the nets in the dtype of this run against the reference nets' fp32 outputs (tests/golden), against
+                the reference run under fp16 autocast (its own search precision), and what it does to the search's visit counts
   roofline      the dominant hand-written kernel (k_search): arithmetic per launch / MEAN launch duration measured here with
                 HIP events on the launch stream, against the dense MFMA peak; beside it the L1<-L2 weight-stream rate
                 against the L2 peak (the binding resource), the min launch duration, and `traffic` = HBM bytes per launch
                 from the committed PMC passes (profiles/pmc_traffic.json, with the commit they were taken at)
   cpu_baseline  the plain-C oracle (tree + env, no nets: the part the reference runs on CPU) on the GPU box's host cores:
                 one core on a bounded sample, tree-only / env-only splits, and one process per core.  A baseline, not the target.
-  also          (N = 1) other configurations measured in the same invocation: BASELINE configs[2] (8192 envs), the same
-                workload with fp16 nets (the reference's autocast format), and a sharp-policy net (deep search paths)
+  also          (N = 1) other configurations measured in the same invocation: BASELINE configs[2] (8192 envs; in the run's format and
+                in the bf16 that config names), the same workload with bf16 nets, and a sharp-policy net (deep search paths)
 """
 import argparse
 import json
@@ -335,7 +336,7 @@ class Run:
                 a.stream = None
             self.group = ActorGroup(self.actors)
         self.games = self.rec_bytes = 0
-        self.flush_s = self.wait_s = 0.0
+        self.flush_s = self.wait_s = self.exchange_s = self.landing_s = 0.0
         self.env_ids = set()
         self._pending = False
 
@@ -352,8 +353,11 @@ class Run:
         import torch
         from hanabizero_amd.dist import gather_packed
         from hanabizero_amd.selfplay import packed_layout, unpack_packed
+        from hanabizero_amd.dist import last_gather
         with torch.cuda.stream(a.drain_stream):
             got = gather_packed(packed, a.A, a.W, dst=0)
+        self.exchange_s += last_gather["exchange_s"]  # (the all_gather of counts + the point-to-point receives: what this rank waited for)
+        self.landing_s += last_gather["landing_s"]    # (the copies into pinned host memory)
         if self.rank == 0 and got:
             for buf, n, moves in got:
                 self.games += n
@@ -413,7 +417,7 @@ class Run:
             dist.gather(w, [torch.empty_like(w) for _ in range(self.world)] if self.rank == 0 else None, dst=0)
         torch.cuda.synchronize()
         barrier()
-        self.games, self.rec_bytes, self.flush_s, self.wait_s = 0, 0, 0.0, 0.0
+        self.games, self.rec_bytes, self.flush_s, self.wait_s, self.exchange_s, self.landing_s = 0, 0, 0.0, 0.0, 0.0, 0.0
         self.env_ids = set()
         t0 = time.perf_counter()
         for k in range(steps):
@@ -437,13 +441,22 @@ class Run:
         torch.cuda.empty_cache()
 
 
-def net_error(game, dtype):
+def net_error(game, dtype, search=True):
     from tests.netgold import golden_net_error
     g = "Hanabi-Full" if game.startswith("Hanabi-Full") else game  # (the 5p net is the Full net at other widths)
     e = golden_net_error(g, dtype)
-    return {"against": "tests/golden/nets_%s.npz (reference MuZeroNet%s fp32 outputs)" % (g, "" if g == "Hanabi-Small" else "Full"),
-            "path": "fused MFMA kernels" if e["fused"] else "GEMM chain", "measure": "max / mean of |got - ref| / max(1, |ref|)",
-            "worst": e["worst"], **{k: v for k, v in e.items() if isinstance(v, dict)}}
+    w = e["wide"]
+    out = {"against": "tests/golden/nets_%s.npz (reference MuZeroNet%s fp32 outputs)" % (g, "" if g == "Hanabi-Small" else "Full"),
+           "path": "fused MFMA kernels" if e["fused"] else "GEMM chain", "measure": "max / mean of |got - ref| / max(1, |ref|)",
+           "worst": e["worst"], **{k: v for k, v in e.items() if isinstance(v, dict) and "max" in v},
+           # the reference's own search precision as the yardstick (tests/golden/nets_*_autocast.npz)
+           "reference_under_fp16_autocast_vs_its_fp32_worst": e["reference_autocast_vs_fp32"]["worst"],
+           "vs_reference_under_fp16_autocast_worst": e["vs_reference_autocast"]["worst"],
+           "rms_ratio_to_reference_autocast_256_rows": {k: v["rms"] / w["reference_autocast_vs_fp32"][k]["rms"] for k, v in w["got_vs_fp32"].items()}}
+    if search and e["fused"]:
+        from tests.netgold import search_divergence
+        out["search_vs_fp32_engine"] = search_divergence(g, dtype, roots=512)
+    return out
 
 
 def _poll_giveups():
@@ -464,14 +477,43 @@ def git_head():
         return None
 
 
+def spawn_ranks(n):
+    """Launcher of `python bench.py --gpus N` (no torch.distributed.run around it): N children of this same command line, rank r
+    on GPU r, rendezvous on 127.0.0.1 at a free port; their stdout / stderr pass straight through (only rank 0 prints the JSON
+    line).  Returns the worst exit code; if a rank dies the others are terminated rather than left at a barrier."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    worst, live = 0, list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            rc = p.poll()
+            if rc is None:
+                continue
+            live.remove(p)
+            if rc != 0:
+                worst = worst or rc
+                for q in live:  # (exactly the children started above)
+                    q.terminate()
+    return worst
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="full4096", choices=sorted(WORKLOADS))
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"],
-                    help="format of the nets (weights, activations, hidden-state pool; fp32 accumulate): bf16 = BASELINE.json's, fp16 = the reference's autocast")
+    ap.add_argument("--dtype", default="fp16", choices=["bf16", "fp16", "fp32"],
+                    help="format of the nets (weights, activations, hidden-state pool; fp32 accumulate): fp16 = the reference's own search "
+                         "precision (autocast, core/mcts.py:38-40; the default), bf16 = what BASELINE.json configs[2] names (measured under `also`)")
     ap.add_argument("--net", default="random", help='"random" (SURVEY 8d) or "sharp[:scale]" (concentrated policy: deep paths)')
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for --gpus > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path on one GPU)")
@@ -502,13 +544,20 @@ def main():
         print(json.dumps({"moves_per_s": v, "seconds": dt}), flush=True)
         return
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as typed: this process becomes the launcher -- it starts one rank per GPU (as the reference
+        # starts its own workers, core/train.py:463-474) BEFORE anything here has imported torch or touched a GPU, relays what
+        # they print (rank 0's JSON line) and leaves with the worst exit code.  Under torch.distributed.run WORLD_SIZE is set
+        # and this branch is not taken.
+        sys.exit(spawn_ranks(args.gpus))
+
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
+    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d, or with no WORLD_SIZE in the environment (bench.py then starts its own ranks)" % (args.gpus, world, args.gpus)
     if args.share_device:
         assert args.backend == "gloo", "--share-device is a gloo rehearsal mode"
         local_rank = 0
@@ -553,7 +602,10 @@ def main():
                    # host time of the flush points: the drain work proper (pack + gather + landing copy; under --sync-drain also the
                    # device-wide synchronize in front of it, which is what stalls the actors) and, asynchronous mode only, the
                    # host's wait for the snapshot of one interval ago -- the GPU runs the queued lock-steps meanwhile
-                   "drain_gather_ms_total": 1e3 * (run.flush_s - run.wait_s), "drain_snapshot_wait_ms_total": 1e3 * run.wait_s},
+                   "drain_gather_ms_total": 1e3 * (run.flush_s - run.wait_s), "drain_snapshot_wait_ms_total": 1e3 * run.wait_s,
+                   # of drain_gather_ms_total, on rank 0: waiting in the exchange (counts all_gather + receives from the other ranks:
+                   # 0 at N = 1) and copying the received buffers into pinned host memory
+                   "gather_exchange_ms_total": 1e3 * run.exchange_s, "gather_landing_ms_total": 1e3 * run.landing_s},
     }
     if args.check_env_ids and rank == 0:
         out["config"]["env_id_min_max_distinct"] = [min(run.env_ids), max(run.env_ids), len(run.env_ids)] if run.env_ids else None
@@ -637,8 +689,10 @@ def main():
         del run
         plan = []
         if args.workload == "full4096" and args.net == "random":
-            plan = [("full8192", "full8192", args.dtype, "random"), ("fp16" if args.dtype != "fp16" else "bf16", args.workload, "fp16" if args.dtype != "fp16" else "bf16", "random"),
-                    ("deep_paths", args.workload, args.dtype, "sharp")]
+            other_dt = "bf16" if args.dtype != "bf16" else "fp16"
+            plan = [("full8192", "full8192", args.dtype, "random"), ("full8192_bf16", "full8192", "bf16", "random"),  # configs[2] names bf16
+                    (other_dt, args.workload, other_dt, "random"), ("deep_paths", args.workload, args.dtype, "sharp")]
+            plan = [p for k, p in enumerate(plan) if p[1:] not in [q[1:] for q in plan[:k]]]
         for name, wl, dt, net in plan:
             r = Run(args, wl, dt, device, 0, 1, net=net)
             r.setup()
@@ -652,7 +706,8 @@ def main():
                 if net != "random":
                     entry["mean_path_edges"], entry["deepest_path_edges"] = mean_path_edges(r.actors[0])
                 if dt != args.dtype:
-                    entry["net_error_worst"] = net_error(r.game, r.dtype)["worst"]
+                    ne = net_error(r.game, r.dtype)
+                    entry["net_error_worst"], entry["search_vs_fp32_engine"] = ne["worst"], ne.get("search_vs_fp32_engine")
             also[name] = entry
             r.release()
             del r

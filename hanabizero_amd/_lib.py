@@ -100,6 +100,8 @@ def _load():
         "hz_search_run": [V, I, C.POINTER(MlpHeader), V, V, V, V, V, I64, I64, V, V, V, V, V, V, I, V],
         "hz_search_poll_giveups": [C.POINTER(C.c_uint)],
         "hz_mlp_poll_giveups": [C.POINTER(C.c_uint)],
+        "hz_mlp_poll_giveups_async": [V, V],
+        "hz_search_poll_giveups_async": [V, V],
         # include/hz_netglue.h
         "hz_add_relu": [V, I64, V, I64, I, I, I, V],
         "hz_test_expf": [V, V, I64, V],

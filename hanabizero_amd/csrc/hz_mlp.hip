@@ -52,6 +52,14 @@ extern "C" int hz_mlp_poll_giveups(unsigned int* count) {
   return 0;
 }
 
+extern "C" int hz_search_poll_giveups_async(unsigned int* host_pinned, void* stream);
+extern "C" int hz_mlp_poll_giveups_async(unsigned int* host_pinned2, void* stream) {
+  HZ_REQUIRE(host_pinned2 != nullptr, "hz_mlp_poll_giveups_async: NULL argument");
+  HZ_HIP(hipMemcpyFromSymbolAsync(host_pinned2, HIP_SYMBOL(hz_poll_giveups_dev), sizeof(unsigned int), 0, hipMemcpyDeviceToHost,
+                                  (hipStream_t)stream));
+  return hz_search_poll_giveups_async(host_pinned2 + 1, stream);
+}
+
 extern "C" int hz_mlp_recurrent(const hz_mlp_header_t* H, const hz_mlp_job_t* jobs, const void* wstream,
                                 const float* biases, const float* action_table, const void* state_src,
                                 int64_t row_stride, const int32_t* plane_index, int64_t plane_stride,

@@ -363,6 +363,14 @@ extern "C" int hz_search_poll_giveups(unsigned int* count) {
   return 0;
 }
 
+// the same count, copied on `stream` into pinned host memory: no device-wide synchronisation (hz_mlp_poll_giveups_async)
+extern "C" int hz_search_poll_giveups_async(unsigned int* host_pinned, void* stream) {
+  HZ_REQUIRE(host_pinned != nullptr, "hz_search_poll_giveups_async: NULL argument");
+  HZ_HIP(hipMemcpyFromSymbolAsync(host_pinned, HIP_SYMBOL(hz_poll_giveups_dev), sizeof(unsigned int), 0, hipMemcpyDeviceToHost,
+                                  (hipStream_t)stream));
+  return 0;
+}
+
 extern "C" int hz_search_run(hz_tree_t* t, int num_simulations, const hz_mlp_header_t* H, const hz_mlp_job_t* jobs,
                              const void* wstream, const float* biases, const float* action_table, void* pool,
                              int64_t plane_stride, int64_t row_stride, int32_t* ix, int32_t* iy, int32_t* la,

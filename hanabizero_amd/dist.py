@@ -110,63 +110,106 @@ def reserve_landing(nbytes, ranks=1):
         _pinned_bytes(("r", r), int(nbytes))
 
 
+_staging = {}
+
+
+def _staging_bytes(key, nbytes, device):
+    """A reusable byte buffer on `device` (send side: one; receive side: one per sending rank), grown geometrically: a drain
+    allocates nothing once the run has seen its largest interval."""
+    buf = _staging.get(key)
+    if buf is None or buf.numel() < nbytes or buf.device != device:
+        size = max(int(nbytes), 1 << 16, 2 * (buf.numel() if buf is not None and buf.device == device else 0))
+        buf = _staging[key] = torch.empty(size, dtype=torch.uint8, device=device)
+    return buf[:nbytes]
+
+
+last_gather = {"exchange_s": 0.0, "landing_s": 0.0}  # host seconds the last gather_packed spent in its two halves (bench.py adds them up)
+
+
 def gather_packed(packed, A, W, dst=0, group=None):
     """The device-resident form of gather_records: `packed` = SelfPlayActor.drain_packed() (uint8 device tensor, n games, their total moves)
-    or None.  Two collectives: all_gather of (n, moves), one gather of the byte buffers (padded to the longest; device to
-    device over xGMI under "nccl": the sending ranks never copy their records to the host).  Returns on `dst` a list of
-    (host uint8 numpy buffer in pinned memory, n, moves) per rank with games -- `unpack_packed` views them without a
-    copy; the buffers are reused by the next call -- elsewhere None.  Works without a process group (world 1).
-    Everything is enqueued on the CALLER's current stream and only that stream is waited for, so called under
-    ``with torch.cuda.stream(actor.drain_stream)`` the gather overlaps the lock-steps queued on the main stream."""
+    or None.  One all_gather of (n, moves), then every rank with games sends its byte buffer -- its exact size, no padding --
+    straight to `dst` (point-to-point, batched: device to device over xGMI's direct peer links under "nccl"; the sending
+    ranks never copy their records to the host; `dst`'s own games take no collective at all).  Send and receive staging
+    buffers are kept between calls.  Returns on `dst` a list of (host uint8 numpy buffer in pinned memory, n, moves) per rank
+    with games -- `unpack_packed` views them without a copy; the buffers are reused by the next call -- elsewhere None.
+    Works without a process group (world 1).  Everything is enqueued on the CALLER's current stream and only that stream is
+    waited for, so called under ``with torch.cuda.stream(actor.drain_stream)`` the gather overlaps the lock-steps queued on
+    the main stream."""
+    import time
     from .selfplay import packed_layout
     n, moves = (0, 0) if packed is None else (int(packed[1]), int(packed[2]))
+    t0 = time.perf_counter()
     if _alone(group):
+        last_gather["exchange_s"] = 0.0
         if not n:
+            last_gather["landing_s"] = 0.0
             return []
         host = _pinned_bytes(("r", 0), packed[0].numel())
         host.copy_(packed[0], non_blocking=True)
         if packed[0].is_cuda:  # (this stream only: lock-steps queued on other streams keep running)
             torch.cuda.current_stream(packed[0].device).synchronize()
+        last_gather["landing_s"] = time.perf_counter() - t0
         return [(host.numpy(), n, moves)]
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     backend = dist.get_backend(group)
     device = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
     mine = torch.tensor([n, moves], dtype=torch.int64, device=device)
-    every = [torch.zeros_like(mine) for _ in range(world)]
-    dist.all_gather(every, mine, group=group)
-    every = torch.stack(every).cpu().numpy()
+    every = _staging_bytes(("counts", world), 16 * world, device).view(torch.int64).view(world, 2)
+    dist.all_gather_into_tensor(every, mine, group=group) if backend == "nccl" else dist.all_gather(list(every.unbind(0)), mine, group=group)
+    every = every.cpu().numpy().copy()
     sizes = [packed_layout(int(a), int(b), A, W)[1] if a else 0 for a, b in every]
-    mxb = max(sizes)
-    if mxb == 0:
-        return [] if rank == dst else None
-    send = torch.zeros(mxb, dtype=torch.uint8, device=device)
-    if n:
-        send[:packed[0].numel()] = packed[0].to(device)
-    bufs = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
-    dist.gather(send, bufs, dst=dst, group=group)
+    ops, recv = [], {}
+    if rank == dst:
+        for r in range(world):
+            if sizes[r] and r != rank:
+                recv[r] = _staging_bytes(("recv", r), sizes[r], device)
+                ops.append(dist.P2POp(dist.irecv, recv[r], r, group=group))
+        if sizes[rank]:
+            recv[rank] = packed[0][:sizes[rank]]
+    elif n:
+        send = packed[0][:sizes[rank]]
+        if send.device != device:  # (a gloo rehearsal of device-resident records: through the host)
+            send = _staging_bytes(("send",), sizes[rank], device).copy_(send)
+        ops.append(dist.P2POp(dist.isend, send.contiguous(), dst, group=group))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    t1 = time.perf_counter()
+    last_gather["exchange_s"] = t1 - t0
     if rank != dst:
+        last_gather["landing_s"] = 0.0
         return None
     out = []
     for r in range(world):
         if sizes[r]:
             host = _pinned_bytes(("r", r), sizes[r])
-            host.copy_(bufs[r][:sizes[r]], non_blocking=True)
+            host.copy_(recv[r], non_blocking=True)
             out.append((host, int(every[r, 0]), int(every[r, 1])))
-    if device.type == "cuda":  # (this stream only: lock-steps queued on other streams keep running)
-        torch.cuda.current_stream(device).synchronize()
+    if torch.cuda.is_available() and any(b.is_cuda for b in recv.values()):  # (this stream only: lock-steps queued on other streams keep running)
+        torch.cuda.current_stream().synchronize()
+    last_gather["landing_s"] = time.perf_counter() - t1
     return [(h.numpy(), a, b) for h, a, b in out]
 
 
 def broadcast_weights(state_dict, src=0, group=None, device=None):
-    """Broadcast a model state_dict from `src` in place (tensors are moved to `device` for nccl)."""
+    """Broadcast a model state_dict from `src`: ONE flat buffer and one broadcast per dtype present (fp32 parameters and
+    running statistics; the int64 num_batches_tracked counters) -- two collectives for the ~60 tensors / 6 MB of a Hanabi net
+    instead of one per tensor.  Returns {name: tensor on `device`} (views of the flat buffers, in the state_dict's shapes)."""
     if _alone(group):
         return state_dict
     backend = dist.get_backend(group)
     device = torch.device(device) if device is not None else (
         torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu"))
+    keys = sorted(state_dict.keys())
     out = {}
-    for k in sorted(state_dict.keys()):
-        t = state_dict[k].detach().to(device).contiguous()
-        dist.broadcast(t, src=src, group=group)
-        out[k] = t
+    for dt in sorted({state_dict[k].dtype for k in keys}, key=str):
+        ks = [k for k in keys if state_dict[k].dtype == dt]
+        flat = torch.cat([state_dict[k].detach().reshape(-1).to(device) for k in ks]) if ks else None
+        dist.broadcast(flat, src=src, group=group)
+        off = 0
+        for k in ks:
+            m = state_dict[k].numel()
+            out[k] = flat[off:off + m].view(state_dict[k].shape)
+            off += m
     return out

@@ -35,7 +35,8 @@ def _overlap(a, b):
 
 def _closure(n_pass, waves, flags, jobs):
     """hb[(q, u)] = set of (p, w) that job (q, u) happens-before (q < p), from: program order; a barrier at the start of pass p;
-    a blockwise pass p (all jobs of pass p - 1 precede every job of pass p: see the module text for why the whole job);
+    a blockwise pass p (all jobs of pass p - 1 precede every ACTIVE job of pass p -- the last block a job waits for is the last
+    producer's; an idle entry of such a pass waits for nothing);
     tokens."""
     succ = {(p, w): set() for p in range(n_pass) for w in range(waves)}
     for p in range(n_pass):
@@ -46,10 +47,17 @@ def _closure(n_pass, waves, flags, jobs):
                 for u in range(4 * g, 4 * g + 4):
                     if jobs[q][u].active:
                         succ[(q, u)].add((p, w))
-        if p > 0 and (flags[p] & (BARRIER | BLOCKWISE)):
+        if p > 0 and (flags[p] & BARRIER):
             for u in range(waves):
                 for w in range(waves):
                     succ[(p - 1, u)].add((p, w))
+        elif p > 0 and (flags[p] & BLOCKWISE):
+            # only the ACTIVE entries of a blockwise pass poll their producers' counters; an idle entry waits for nothing (the
+            # kernel has no barrier there and `continue`s before any poll) and gets program order only
+            for u in range(waves):
+                for w in range(waves):
+                    if jobs[p][w].active:
+                        succ[(p - 1, u)].add((p, w))
     hb = {}
     for p in reversed(range(n_pass)):  # successors only ever lie in later passes: one backward sweep closes the relation
         for w in range(waves):

@@ -14,6 +14,9 @@ from . import cytree
 from .mcts import MCTS
 
 
+_giveups_seen = 0  # hz_mlp_poll_giveups at the last check (per process; 0 when the library is loaded)
+
+
 def policy_re_context(config, games, positions, indices=None):
     """What ``BatchWorker_CPU._prepare_policy_re_context`` (reanalyze_worker.py:101-144) hands to the searching worker for the
     sampled (game, position) pairs whose policy targets are to be refreshed: for each of the num_unroll_steps + 1 unroll
@@ -73,6 +76,14 @@ def prepare_policy_re(config, engine, policy_re_context, noises=None, generator=
         policy = dist / dist.sum(1, keepdim=True)
         mask = torch.as_tensor(np.asarray(policy_mask), device=device).reshape(B, 1)
         policy = torch.where(mask != 0, policy, torch.zeros_like(policy)).cpu().numpy()
+        if getattr(engine, "fused", None) is not None:  # (the read-back above has synchronised: this costs a 4-byte copy)
+            global _giveups_seen
+            from ._lib import poll_giveups
+            now = poll_giveups()
+            if now != _giveups_seen:
+                grew, _giveups_seen = now - _giveups_seen, now
+                raise RuntimeError("the fused inference gave up %d wait(s) on its arrival counters (include/hz_mlp.h): these policy "
+                                   "targets were searched with inputs that may not have been there" % grew)
     U = config.num_unroll_steps + 1
     assert B == len(state_index_lst) * U, "policy_re_context holds (num_unroll_steps + 1) entries per sampled position"
     return policy.reshape(len(state_index_lst), U, A)

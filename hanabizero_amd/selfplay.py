@@ -251,15 +251,27 @@ class SelfPlayActor:
 
     def drain_begin(self):
         """First half of a drain that never stalls the lock-steps: snapshot (finished games, their total moves) as of
-        the work enqueued so far.  Non-blocking -- the counters travel to pinned host memory on `drain_stream`, which
-        waits for the lock-steps enqueued up to now and for nothing enqueued later."""
+        the work enqueued so far.  Non-blocking.  The snapshot itself is taken ON THE WORK STREAM -- a 16-byte device copy
+        between two lock-steps, where the pair is consistent and every counted game's rows are in the outbox (inside a
+        lock-step the two counters are written by separate stores and the rows only by its later reset launch) -- and
+        `drain_stream` waits for that copy's event, for nothing enqueued later, before it takes the snapshot to pinned host
+        memory together with the inference kernels' give-up counters (include/hz_mlp.h::hz_mlp_poll_giveups_async)."""
         if self.drain_stream is None:
             self.drain_stream = torch.cuda.Stream(device=self.device)
             self._count_host = torch.zeros(2, dtype=torch.int64).pin_memory()
+            self._count_snap = torch.zeros(2, dtype=torch.int64, device=self.device)
+            self._giveups_host = torch.zeros(2, dtype=torch.int32).pin_memory()
+            self._giveups_seen = 0
         assert self._snap is None, "drain_begin: the previous snapshot has not been consumed (drain_end)"
-        self.drain_stream.wait_stream(self._work_stream())
+        ws = self._work_stream()
+        with torch.cuda.stream(ws):
+            self._count_snap.copy_(self.out_count)
+            taken = torch.cuda.Event()
+            taken.record(ws)
+        self.drain_stream.wait_event(taken)
         with torch.cuda.stream(self.drain_stream):
-            self._count_host.copy_(self.out_count, non_blocking=True)
+            self._count_host.copy_(self._count_snap, non_blocking=True)
+            check(lib.hz_mlp_poll_giveups_async(self._giveups_host.data_ptr(), _stream()), "hz_mlp_poll_giveups_async")
             self._snap = torch.cuda.Event()
             self._snap.record(self.drain_stream)
 
@@ -274,6 +286,12 @@ class SelfPlayActor:
         self._snap.synchronize()
         self._snap = None
         count, moves_total = (int(x) for x in self._count_host.tolist())
+        giveups = int(self._giveups_host[0]) + int(self._giveups_host[1])
+        if giveups != self._giveups_seen:  # a wait on an arrival counter timed out: search results since the last drain are not to be trusted
+            seen, self._giveups_seen = self._giveups_seen, giveups
+            raise RuntimeError("the fused inference gave up %d wait(s) on its arrival counters since the last drain "
+                               "(a job table that breaks include/hz_mlp.h's contract, or a stalled wave): the games of this "
+                               "interval were searched with inputs that may not have been there" % (giveups - seen))
         n, moves = count - self._drained, moves_total - self._moves_drained
         if n <= 0:
             return None

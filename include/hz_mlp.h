@@ -135,6 +135,12 @@ int hz_mlp_recurrent(const hz_mlp_header_t* host_header, const hz_mlp_job_t* job
  * wave that gave up went on with inputs that may not have been there.  (bench.py prints it; the GPU tests assert it.) */
 int hz_mlp_poll_giveups(unsigned int* count);
 
+/* The same two counters (stand-alone kernel's, search kernels') copied on `stream` into host_pinned2[0], [1] (pinned host
+ * memory): no device-wide synchronisation -- for callers that must not stall work queued on other streams.  The values are
+ * there once `stream` has reached this point; their sum is hz_mlp_poll_giveups's count.  hanabizero_amd/selfplay.py reads them
+ * with every drain of finished games and raises if they grew. */
+int hz_mlp_poll_giveups_async(unsigned int* host_pinned2, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -47,6 +47,7 @@ int hz_search_run(hz_tree_t* t, int num_simulations, const hz_mlp_header_t* H, c
 
 /* hz_search_run's share of hz_mlp_poll_giveups (include/hz_mlp.h), which is the one to call. */
 int hz_search_poll_giveups(unsigned int* count);
+int hz_search_poll_giveups_async(unsigned int* host_pinned, void* stream);  /* hz_mlp_poll_giveups_async's share */
 
 #ifdef __cplusplus
 }

@@ -69,9 +69,14 @@ def _worker(rank, world, port, counts, q):
                         ok &= bool(np.array_equal(np.asarray(a[k]), np.asarray(b[k])))
         else:
             ok &= got is None
-    sd = {"b": torch.full((3,), float(rank)), "a": torch.arange(4.0) * (rank + 1)}
+    # a state_dict as a net has it: several fp32 tensors of different shapes + int64 counters -> one flat broadcast per dtype
+    sd = {"b": torch.full((3,), float(rank)), "a": torch.arange(4.0) * (rank + 1), "w": torch.arange(6.0).reshape(2, 3) + rank,
+          "bn.num_batches_tracked": torch.tensor(7 + rank), "steps": torch.tensor([1, 2]) * (rank + 1)}
     out = broadcast_weights(sd, src=0)
     ok &= bool((out["b"] == 0).all()) and bool((out["a"] == torch.arange(4.0)).all())
+    ok &= out["w"].shape == (2, 3) and bool((out["w"] == torch.arange(6.0).reshape(2, 3)).all())
+    ok &= out["bn.num_batches_tracked"].dtype == torch.int64 and out["bn.num_batches_tracked"].shape == () and int(out["bn.num_batches_tracked"]) == 7
+    ok &= bool((out["steps"] == torch.tensor([1, 2])).all()) and set(out) == set(sd)
     q.put((rank, ok))
     dist.destroy_process_group()
 
@@ -140,20 +145,24 @@ def test_collectives_over_rccl_one_rank():
 
 
 @pytest.mark.gpu
-def test_bench_two_ranks_on_one_gpu_over_gloo():
-    """bench.py's N > 1 path exactly as the driver launches it (python -m torch.distributed.run --nproc-per-node 2 bench.py
-    --gpus 2 ...), rehearsed on the test box's one GPU: both ranks use cuda:0, the collectives go over gloo.  Checks the one
-    JSON line rank 0 prints: two ranks' worth of moves, finished games gathered from BOTH ranks (global env ids from each
-    rank's disjoint range), the asynchronous drain in use."""
+@pytest.mark.parametrize("launcher", ["torchrun", "self"])
+def test_bench_two_ranks_on_one_gpu_over_gloo(launcher):
+    """bench.py's N > 1 path both ways it can be started -- under python -m torch.distributed.run --nproc-per-node 2 bench.py
+    --gpus 2 ... , and as plain `python bench.py --gpus 2 ...` (no WORLD_SIZE in the environment: bench.py starts its own two
+    ranks before it touches a GPU) -- rehearsed on the test box's one GPU: both ranks use cuda:0, the collectives go over gloo.
+    Checks the one JSON line rank 0 prints: two ranks' worth of moves, finished games gathered from BOTH ranks (global env ids
+    from each rank's disjoint range), the asynchronous drain in use."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--backend", "gloo", "--share-device", "--steps", "24",
-           "--warmup", "2", "--workload", "small4096", "--flush-every", "8", "--no-cpu-baseline", "--no-roofline", "--no-also",
-           "--check-env-ids"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    head = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+            "--master-port", str(_free_port())] if launcher == "torchrun" else [sys.executable]
+    cmd = head + ["bench.py", "--gpus", "2", "--backend", "gloo", "--share-device", "--steps", "24",
+                  "--warmup", "2", "--workload", "small4096", "--flush-every", "8", "--no-cpu-baseline", "--no-roofline", "--no-also",
+                  "--check-env-ids"]
     p = subprocess.run(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]

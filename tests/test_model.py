@@ -292,7 +292,7 @@ def test_job_table_synchronisation_is_proven_and_the_proof_notices_a_missing_wai
     passes (blockwise boundaries + per-job waits); the checker accepts the table as built, and rejects it as soon as one
     token is taken away or a blockwise pass is declared to need nothing."""
     from hanabizero_amd import mlp_sync
-    from hanabizero_amd.model import FusedRecurrent, InferenceEngine, MLP_BARRIER, MLP_BLOCKWISE, MLP_STORE_HIDDEN, MLP_WAITS
+    from hanabizero_amd.model import FusedRecurrent, InferenceEngine, MLP_BARRIER, MLP_BLOCKWISE, MLP_F32_OUT, MLP_STORE_HIDDEN, MLP_WAITS
     net, fx, sup = build(game)
     eng = InferenceEngine(net, sup, dtype=torch.bfloat16, device="cpu", fused=False)
     f = FusedRecurrent(net, eng, 16, 2, host_only=True)
@@ -309,7 +309,7 @@ def test_job_table_synchronisation_is_proven_and_the_proof_notices_a_missing_wai
             e = tab[p * 16 + w]
             j = mlp_sync.Job(reads=hid, active=False) if e.ks == 0 else mlp_sync.Job(
                 reads=[(e.src_off, e.src_off + 32 * e.ks)] + hid + ([] if e.res_off < 0 else [(e.res_off, e.res_off + cw)]),
-                writes=[(e.dst_off, e.dst_off + cw)])
+                writes=[(e.dst_off, e.dst_off + (2 * cw if e.flags & MLP_F32_OUT else cw))])  # (fp32 outputs: 2 image columns each)
             if flags[p] & MLP_WAITS:
                 nt = (e.flags >> 8) & 7
                 j.tokens = [(((e.producer >> (8 * k)) >> 4) & 15, ((e.producer >> (8 * k)) >> 2) & 3, ((e.producer >> (8 * k)) & 3) + 1)
@@ -327,6 +327,34 @@ def test_job_table_synchronisation_is_proven_and_the_proof_notices_a_missing_wai
     q = next(i for i, x in enumerate(pf) if x & MLP_BLOCKWISE)
     with pytest.raises(AssertionError, match="may run before"):
         mlp_sync.verify(pf[:q] + [0] + pf[q + 1:], jobs)
+
+
+def test_a_wave_that_idles_through_a_blockwise_pass_is_not_ordered_by_it():
+    """In the kernel an idle entry of a HZ_MLP_BLOCKWISE pass polls nothing (hz_mlp_dev.h: no barrier there, `continue` before
+    any poll), so the proof must not credit it with the pass's producers: a wave that sits a blockwise pass out and then reads
+    the producers' columns needs tokens of its own (or a barrier), and a table without them must be rejected.  (Hanabi-Small's
+    table has such entries -- waves 12-15 idle in its third blockwise pass; they carry tokens in the pass after.)"""
+    from hanabizero_amd import mlp_sync
+    J, B, BW, W = mlp_sync.Job, mlp_sync.BARRIER, mlp_sync.BLOCKWISE, mlp_sync.WAITS
+
+    def table():
+        p0 = [J(reads=[(0, 512)], writes=[(512 + 32 * w, 544 + 32 * w)]) for w in range(16)]                     # full-width layer
+        p1 = [J(reads=[(512, 1024)], writes=[(1024 + 32 * w, 1056 + 32 * w)]) if w < 12 else J(active=False) for w in range(16)]
+        p2 = [J(reads=[(512, 1024)], writes=[(1536 + 32 * w, 1568 + 32 * w)]) if w >= 12 else J(active=False) for w in range(16)]
+        return [p0, p1, p2]
+    jobs = table()
+    flags, signal = mlp_sync.plan([0, BW, B], jobs)
+    assert (flags[2] & B) or all({(q, g) for (q, g, _c) in jobs[2][w].tokens} == {(0, 0), (0, 1), (0, 2), (0, 3)} for w in range(12, 16)), \
+        (flags, [jobs[2][w].tokens for w in range(12, 16)])
+    assert (flags[2] & B) or ((flags[2] & W) and 0 in signal)
+    # the same table with neither a barrier nor tokens on pass 2: waves 12-15 could read pass 0's columns before they exist
+    bare = table()
+    with pytest.raises(AssertionError, match="may run before"):
+        mlp_sync.verify([0, BW, 0], bare)
+    # an ACTIVE entry of the blockwise pass is ordered behind the producers, as before
+    ok = table()
+    ok[2] = [J(reads=[(1024, 1056)], writes=[(1536, 1568)]) if w == 0 else J(active=False) for w in range(16)]
+    assert mlp_sync.verify([0, BW, 0], ok)  # (wave 0 reads its own pass-1 output: program order behind an active blockwise job)
 
 
 @pytest.mark.gpu
