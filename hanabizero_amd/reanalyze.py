@@ -14,7 +14,7 @@ from . import cytree
 from .mcts import MCTS
 
 
-_giveups_seen = 0  # hz_mlp_poll_giveups at the last check (per process; 0 when the library is loaded)
+_giveups_seen = None  # hz_mlp_poll_giveups at the last check (per process; read before the first search)
 
 
 def policy_re_context(config, games, positions, indices=None):
@@ -59,6 +59,10 @@ def prepare_policy_re(config, engine, policy_re_context, noises=None, generator=
     obs = obs.to(device).reshape(obs.shape[0], -1)
     B, A = obs.shape[0], config.action_space_size
     legal = torch.as_tensor(np.asarray(legal_action_lst), device=device).reshape(B, A)
+    global _giveups_seen
+    if _giveups_seen is None and getattr(engine, "fused", None) is not None:
+        from ._lib import poll_giveups
+        _giveups_seen = poll_giveups()
     with torch.no_grad():
         _, logits, hidden = engine.initial(obs)
         if noises is None:
@@ -77,7 +81,6 @@ def prepare_policy_re(config, engine, policy_re_context, noises=None, generator=
         mask = torch.as_tensor(np.asarray(policy_mask), device=device).reshape(B, 1)
         policy = torch.where(mask != 0, policy, torch.zeros_like(policy)).cpu().numpy()
         if getattr(engine, "fused", None) is not None:  # (the read-back above has synchronised: this costs a 4-byte copy)
-            global _giveups_seen
             from ._lib import poll_giveups
             now = poll_giveups()
             if now != _giveups_seen:

@@ -46,7 +46,7 @@ def _stream():
 
 class SelfPlayActor:
     def __init__(self, config, engine, num_envs, rank=0, seed=0, device=None, use_graph=True, outbox_games=None,
-                 deterministic=False, env_id_base=None, stream=None):
+                 deterministic=False, env_id_base=None, stream=None, fused_tail=True):
         self.cfg, self.engine, self.N = config, engine, int(num_envs)
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         d, N = self.device, self.N
@@ -55,6 +55,8 @@ class SelfPlayActor:
         self.env_id_base = rank * N if env_id_base is None else int(env_id_base)
         self.stream = stream  # optional side stream: several actors of one GPU overlap their (latency-bound) kernels
         self.deterministic = deterministic
+        # everything after the search in two launches (include/hz_movetail.h) instead of one per phase; same bits (tests)
+        self.fused_tail = bool(fused_tail)
         seeds = seed + self.env_id_base + np.arange(N)
         self.env = HanabiVecEnv(config.env_name, seeds, device=d, mdp=config.mdp)
         self.A, self.D = self.env.num_moves, self.env.obs_dim
@@ -100,6 +102,7 @@ class SelfPlayActor:
         self.num_finished = z(1, dtype=torch.int32)
         self.counts = z(N, A, dtype=torch.int32)
         self.values = z(N, dtype=torch.float32)
+        self._tail_scratch = z(2, dtype=torch.int64)
         assert done_dtype_ok(self.env)
         tr, o = self.traj, self.out
         self.bufs = ActorBufs(num_envs=N, num_actions=A, packed_words=W, max_moves=T, outbox_games=self.cap,
@@ -160,8 +163,22 @@ class SelfPlayActor:
         value0, logits0, hidden0 = self.root_inference(state_out=self.pool[0])
         self.roots.prepare(cfg.root_exploration_fraction, self.noise, self.zeros_n, logits0, self.legal)
         self.mcts.run_multi(self.roots, self.engine, hidden0, pool=self.pool)
-        self.roots.root_stats_tensors(self.counts, self.values)
         b, st = C.byref(self.bufs), _stream()
+        if draw and self.fused_tail and self.Dp * self.stack_buf.element_size() % 16 == 0:
+            # read-out, action, env step, history append | hand-over of finished games, reset, observation, window, next draws
+            from .hanabi_env import _OBS_DTYPES
+            env, es = self.env, self.stack_buf.element_size()
+            check(lib.hz_actor_move_tail(self.roots._h, env._h, b, env.mdp, self.counts.data_ptr(), self.values.data_ptr(),
+                                         self.legal.data_ptr(), self.uniform.data_ptr(), float(cfg.visit_softmax_temperature_fn(0, 0)),
+                                         int(self.deterministic), self.action.data_ptr(), self.entropy.data_ptr(),
+                                         env.reward.data_ptr(), env.done.data_ptr(), env.score.data_ptr(), env.status.data_ptr(),
+                                         self.tmp_packed.data_ptr(), self.stack_buf.data_ptr(), self.stack_buf.stride(0) * es,
+                                         self.stack, self.Dp * es, _OBS_DTYPES[self.stack_buf.dtype], self.noise_seed,
+                                         self.move_count.data_ptr(), float(cfg.root_dirichlet_alpha), self.noise.data_ptr(),
+                                         self._tail_scratch.data_ptr(), st), "hz_actor_move_tail")
+            self._drawn = True
+            return
+        self.roots.root_stats_tensors(self.counts, self.values)
         check(lib.hz_actor_record_search(b, self.counts.data_ptr(), self.values.data_ptr(), self.legal.data_ptr(),
                                          self.uniform.data_ptr(), float(cfg.visit_softmax_temperature_fn(0, 0)),
                                          int(self.deterministic), self.action.data_ptr(), self.entropy.data_ptr(), st),
@@ -261,7 +278,8 @@ class SelfPlayActor:
             self._count_host = torch.zeros(2, dtype=torch.int64).pin_memory()
             self._count_snap = torch.zeros(2, dtype=torch.int64, device=self.device)
             self._giveups_host = torch.zeros(2, dtype=torch.int32).pin_memory()
-            self._giveups_seen = 0
+            from ._lib import poll_giveups
+            self._giveups_seen = poll_giveups()  # (what the process had before this actor's first drain -- e.g. a test's broken table -- is not this actor's)
         assert self._snap is None, "drain_begin: the previous snapshot has not been consumed (drain_end)"
         ws = self._work_stream()
         with torch.cuda.stream(ws):

@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 from tests.restate import ref_select_action  # noqa: E402  (checked against the reference: tests/test_reference_callers.py)
 
 
-def make(game, N, sims, stack, dtype, use_graph, seed=3, peaked=False):
+def make(game, N, sims, stack, dtype, use_graph, seed=3, peaked=False, fused_tail=True):
     from hanabizero_amd.config import make_config
     from hanabizero_amd.model import InferenceEngine
     from hanabizero_amd.selfplay import SelfPlayActor
@@ -27,7 +27,7 @@ def make(game, N, sims, stack, dtype, use_graph, seed=3, peaked=False):
                 head[-1].bias.zero_()
     net.eval()
     eng = InferenceEngine(net, cfg.value_support.max, dtype=dtype, device="cuda")
-    return cfg, eng, SelfPlayActor(cfg, eng, N, seed=seed, use_graph=use_graph)
+    return cfg, eng, SelfPlayActor(cfg, eng, N, seed=seed, use_graph=use_graph, fused_tail=fused_tail)
 
 
 @pytest.mark.parametrize("game,N,sims,stack,steps", [("Hanabi-Small", 16, 10, 2, 40), ("Hanabi-Full", 8, 12, 4, 25)])
@@ -318,35 +318,46 @@ def test_packed_drain_equals_drain():
             assert again[k].dtype == ragged[k].dtype and np.array_equal(again[k], ragged[k]), k
 
 
-def test_fused_launches_equal_their_separate_calls():
-    """The lock-step with its fused launches (hz_actor_begin_move_draw; hz_env_reset_rows carrying the flush) against the same
-    moves made with the separate entry points (hz_actor_draw + hz_actor_begin_move; hz_actor_flush + hz_env_reset): the
-    same finished games, bit for bit, and the same live state."""
+@pytest.mark.parametrize("game,N,stack,dtype,moves", [("Hanabi-Small", 96, 2, torch.bfloat16, 28), ("Hanabi-Full", 70, 4, torch.float16, 28),
+                                                       ("Hanabi-Full-5p", 37, 4, torch.float32, 70)])
+def test_fused_launches_equal_their_separate_calls(game, N, stack, dtype, moves):
+    """The lock-step's tail three ways: (tail) the two launches of include/hz_movetail.h, one wave per env from the root read-out
+    to the next move's window; (fused) one launch per phase with the fusions of r01 (hz_actor_begin_move_draw; hz_env_reset_rows
+    carrying the flush); (separate) every entry point on its own (hz_actor_draw + hz_actor_begin_move; hz_actor_flush +
+    hz_env_reset).  The same finished games, bit for bit, and the same live state -- histories under construction, windows,
+    legal masks, env states and generators, the next move's noise and uniforms, the outbox counters."""
     from hanabizero_amd._lib import check, lib
     import ctypes as C
     recs, states = [], []
-    for fused in (True, False):
-        cfg, eng, actor = make("Hanabi-Small", 96, 10, 2, torch.bfloat16, use_graph=False, seed=21)
-        if not fused:
+    for form in ("tail", "fused", "separate"):
+        cfg, eng, actor = make(game, N, 10, stack, dtype, use_graph=False, seed=21, fused_tail=form == "tail")
+        if form == "separate":
             def reset_then(mask, rows=None, _env=actor.env, _actor=actor):  # flush and reset as two launches
                 check(lib.hz_actor_flush(C.byref(_actor.bufs), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "flush")
                 type(_env).reset(_env, mask)
             actor.env.reset = reset_then
-        for _ in range(28):
-            if fused:
+        for _ in range(moves):
+            if form != "separate":
                 actor._step_body(draw=True)
             else:
                 actor._draw()
                 actor._step_body(draw=False)
+        if form == "separate":
+            actor._draw()  # (the other two forms have drawn for the next move already)
         torch.cuda.synchronize()
+        live = dict(stack=actor.stack_buf, legal=actor.legal, traj_len=actor.traj_len, ent_sum=actor.ent_sum, probe=actor.env.probe(),
+                    noise=actor.noise, uniform=actor.uniform, move_count=actor.move_count, out_count=actor.out_count,
+                    counts=actor.counts, values=actor.values, action=actor.action, slot=actor.slot,
+                    num_finished=actor.num_finished, illegal=actor.illegal_steps, **{"traj_" + k: v for k, v in actor.traj.items()})
+        states.append({k: v.clone() for k, v in live.items()})
         recs.append(actor.drain())
-        states.append((actor.stack_buf.clone(), actor.legal.clone(), actor.traj_len.clone(), actor.env.state_tensor().clone()
-                       if hasattr(actor.env, "state_tensor") else None))
-    assert recs[0]["meta"].shape[0] > 20
-    for k in recs[0]:
-        assert np.array_equal(recs[0][k], recs[1][k]), k
-    for a, b in zip(states[0], states[1]):
-        assert (a is None and b is None) or torch.equal(a, b)
+    assert recs[0]["meta"].shape[0] > (20 if game == "Hanabi-Small" else 3)
+    for other in (1, 2):
+        for k in recs[0]:
+            assert np.array_equal(recs[0][k], recs[other][k]), (other, k)
+        for k in states[0]:
+            assert torch.equal(states[0][k], states[other][k]), (other, k)
+    assert int(states[0]["illegal"]) == 0
 
 
 def test_new_entry_points_report_bad_arguments():
