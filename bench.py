@@ -306,6 +306,50 @@ def kernel_timing(actor, sample_sims=(4, 16, 28, 40), clones=8, replays=5):
     return times, search, launches * clones * replays, (depth / launches if launches else None), (entries / launches if launches else None)
 
 
+def tail_timing(actor, reps=6):
+    """Duration of everything a lock-step does after the search -- the two launches of include/hz_movetail.h -- on a LIVE position:
+    one more search is run, what the tail reads and overwrites is saved (env states and generator positions, legal masks,
+    uniforms, trajectory lengths, windows), and a hipGraph of `reps` x [restore, tail] is timed with HIP events; a graph of the
+    restores alone is timed the same way and subtracted.  Every replica sees the same searched trees and the same games, so it
+    picks the same (legal) actions and ends the same games as the product's lock-step would.  Returns seconds per tail and
+    the share of envs whose game ended in it.  (Leaves the actor's games in disarray: call it last.)"""
+    import torch
+    if not actor.fused_tail:
+        return None
+    actor._search_part()
+    torch.cuda.synchronize()
+    env = actor.env
+    snap = env.snapshot()
+    saved = [(t, t.clone()) for t in (actor.legal, actor.uniform, actor.traj_len, actor.ent_sum, actor.move_count, actor.stack_buf,
+                                      actor.out_count)]
+
+    def graph(with_tail):
+        side = torch.cuda.Stream(device=actor.device)
+        side.wait_stream(torch.cuda.current_stream())
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+            for _ in range(reps):
+                for live, copy in saved:
+                    live.copy_(copy)
+                env.restore(snap)
+                if with_tail:
+                    actor._tail_part(True)
+        return g
+    out = []
+    for with_tail in (True, False):
+        g = graph(with_tail)
+        best = 1e9
+        for _ in range(4):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); g.replay(); b.record()
+            torch.cuda.synchronize()
+            best = min(best, a.elapsed_time(b) * 1e-3 / reps)
+        out.append(best)
+        if with_tail:
+            ended = float(env.done.float().mean())
+    return max(out[0] - out[1], 1e-9), ended
+
+
 # ---------------------------------------------------------------------------------------------------- one self-play run
 class Run:
     """One actor set-up + timed loop of `steps` lock-steps (the driver's contract for the primary run; the `also` runs reuse it)."""
@@ -639,6 +683,27 @@ def main():
             other["k_mlp_recurrent"] = {"bound": "mfma", "avg_launch_us": t * 1e6, "flop_per_launch": flops,
                                         "TFLOPps": flops / t / 1e12, "frac": flops / t / 1e12 / MFMA_PEAK_TFLOPS,
                                         "weight_bytes_per_wg": engine.fused.weight_bytes_per_wg}
+        # the env / actor kernels of a lock-step: everything after the search = the two launches of include/hz_movetail.h.
+        # Algorithmic HBM bytes per env and move: the game's state line in and out (2 x 128 B), <= 8 generator
+        # words, the root's child records (16 A) and sums, legal masks in / out, counts / values / action out, the history's rows
+        # (visits 2 A, observation 4 W twice -- after the move and, identical unless the game ended, as the next head --, legal A
+        # twice, reward / action / value, meta 16), the next move's noise (4 A) and uniform, the model's input window moving up
+        # one slot ((2 stack - 1) slots of Dp elements), and for the share of envs whose game ended the seven trajectory rows
+        # out of the history into the outbox (read + write) plus the new game's generator words
+        tt = tail_timing(actor) if engine.fused is not None else None
+        if tt is not None:
+            t_tail, ended = tt
+            Wp, T, st_n, es = actor.W, actor.T, actor.stack, actor.stack_buf.element_size()
+            rows = T + T + 4 * T + 2 * T * A + (T + 1) * A + 4 * (T + 1) * Wp + 16
+            per_env = (2 * 128 + 32 + 16 * A + 8 + A + 8 + 4 * A + 4 + 4 + 2 * A + 2 * 4 * Wp + 2 * A + 6 + 16 + 4 * A + 8 + 16 + 16 +
+                       (2 * st_n - 1) * actor.Dp * es + ended * (2 * rows + 4 * 2 * 25))
+            btail = Nk * per_env
+            other["move_tail"] = {"bound": "hbm", "kernels": "k_move_tail_a + k_move_tail_b (one wave per env: read-out, action, env step, "
+                                  "history | finished games out, reset, observation, window; include/hz_movetail.h)",
+                                  "avg_launch_us": t_tail * 1e6, "bytes_per_launch": btail, "GBps": btail / t_tail / 1e9,
+                                  "frac": btail / t_tail / 1e9 / HBM_PEAK_GBS, "games_ended_share": ended,
+                                  "note": "both launches together, timed on a live position (restore + tail replayed in a hipGraph, the "
+                                          "restores' own time subtracted); latency-bound: ~15 dependent steps per env, not bandwidth"}
         traffic_all, traffic_src = {}, None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):

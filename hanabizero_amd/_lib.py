@@ -83,6 +83,8 @@ def _load():
         "hz_env_step": [V, V, V, V, V, V, V, V],
         "hz_env_observe": [V, I, V, I, I64, V, V, V],
         "hz_env_probe": [V, V, V],
+        "hz_env_snapshot": [V, V, V, V],
+        "hz_env_restore": [V, V, V, V],
         # include/hz_selfplay.h
         "hz_select_action": [I, I, V, V, V, F, I, V, V, V],
         "hz_rows_scatter": [V, V, I64, V, I, V],

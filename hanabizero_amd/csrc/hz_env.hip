@@ -300,3 +300,19 @@ extern "C" int hz_env_probe(hz_env_t* e, int32_t* out, void* stream) {
 }
 
 extern "C" int64_t hz_env_hbm_bytes(const hz_env_t* e) { return e ? e->bytes : 0; }
+
+extern "C" int hz_env_snapshot(hz_env_t* e, void* out_state, uint32_t* out_positions, void* stream) {
+  HZ_REQUIRE(e && out_state && out_positions, "hz_env_snapshot: NULL argument");
+  const size_t N = (size_t)e->cfg.N;
+  HZ_HIP(hipMemcpyAsync(out_state, e->state, N * 32 * sizeof(uint32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  HZ_HIP(hipMemcpyAsync(out_positions, e->mt + 624 * N, N * sizeof(uint32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return 0;
+}
+
+extern "C" int hz_env_restore(hz_env_t* e, const void* state, const uint32_t* positions, void* stream) {
+  HZ_REQUIRE(e && state && positions, "hz_env_restore: NULL argument");
+  const size_t N = (size_t)e->cfg.N;
+  HZ_HIP(hipMemcpyAsync(e->state, state, N * 32 * sizeof(uint32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  HZ_HIP(hipMemcpyAsync(e->mt + 624 * N, positions, N * sizeof(uint32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return 0;
+}

@@ -112,6 +112,16 @@ class HanabiVecEnv:
         check(lib.hz_env_observe(self._h, self.mdp, None, 0, 0, packed.data_ptr(), legal.data_ptr(), _stream()),
               "hz_env_observe")
 
+    def snapshot(self):
+        """(states [N, 32] i32, generator positions [N] i32) as of the work enqueued so far (include/hz_env.h::hz_env_snapshot)."""
+        st = torch.empty((self.N, 32), dtype=torch.int32, device=self.device)
+        pos = torch.empty(self.N, dtype=torch.int32, device=self.device)
+        check(lib.hz_env_snapshot(self._h, st.data_ptr(), pos.data_ptr(), _stream()), "hz_env_snapshot")
+        return st, pos
+
+    def restore(self, snap):
+        check(lib.hz_env_restore(self._h, snap[0].data_ptr(), snap[1].data_ptr(), _stream()), "hz_env_restore")
+
     def probe(self):
         out = torch.empty((self.N, 16), dtype=torch.int32, device=self.device)
         check(lib.hz_env_probe(self._h, out.data_ptr(), _stream()), "hz_env_probe")

@@ -157,12 +157,23 @@ class SelfPlayActor:
         """draw=True: the lock-step draws its own root noise / sampling uniforms -- the first one up front, every later
         one at the end of the step before (in the launch that moves the observation windows); draw=False: the caller has
         called _draw() for this move (tests)."""
-        cfg, N = self.cfg, self.N
         if draw and not self._drawn:
             self._draw()
+        self._search_part()
+        self._tail_part(draw)
+
+    def _search_part(self):
+        """Root inference, root preparation and the search of every env's current position (the part of a lock-step that reads
+        the env and writes only the trees and the pool)."""
+        cfg = self.cfg
         value0, logits0, hidden0 = self.root_inference(state_out=self.pool[0])
         self.roots.prepare(cfg.root_exploration_fraction, self.noise, self.zeros_n, logits0, self.legal)
         self.mcts.run_multi(self.roots, self.engine, hidden0, pool=self.pool)
+
+    def _tail_part(self, draw=True):
+        """Everything after the search: read-out, action, env step, history, finished games, reset, next observation and window
+        (and, draw=True, the next move's draws)."""
+        cfg, N = self.cfg, self.N
         b, st = C.byref(self.bufs), _stream()
         if draw and self.fused_tail and self.Dp * self.stack_buf.element_size() % 16 == 0:
             # read-out, action, env step, history append | hand-over of finished games, reset, observation, window, next draws

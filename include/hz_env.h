@@ -70,6 +70,13 @@ int hz_env_observe(hz_env_t* e, int mdp, void* obs_out, int obs_dtype, int64_t o
 int hz_env_probe(hz_env_t* e, int32_t* out /* [N][HZ_ENV_PROBE_FIELDS] */, void* stream);
 int64_t hz_env_hbm_bytes(const hz_env_t* e);
 
+/* The games' bit-packed states ([N][32] u32) and generator positions ([N] u32) copied out / back in on `stream` (device
+ * buffers): lets a measurement replay one move several times (bench.py's tail timing).  The generators' WORDS are not part of
+ * it -- after a restore the draws are made from words the replayed moves have already regenerated once: valid games, but not
+ * the games the saved position would have led to.  Not for product code. */
+int hz_env_snapshot(hz_env_t* e, void* out_state, uint32_t* out_positions, void* stream);
+int hz_env_restore(hz_env_t* e, const void* state, const uint32_t* positions, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

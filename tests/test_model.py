@@ -131,8 +131,8 @@ NET_ERROR_BOUND = {
 }
 # search level (tests/netgold.py::search_divergence, 512 roots x 49 simulations against the fp32 engine's search):
 # (minimum share of roots with the same most-visited action, maximum mean total-variation distance of the visit distributions)
-# measured r03: fp16 0.975-0.986 / 0.0016-0.0053, bf16 0.857-0.927 / 0.0097-0.029
-SEARCH_DIVERGENCE_BOUND = {torch.float16: (0.95, 0.01), torch.bfloat16: (0.80, 0.045)}
+# measured r03 over several root sets: fp16 0.961-0.986 / 0.0016-0.0080, bf16 0.857-0.927 / 0.0097-0.029
+SEARCH_DIVERGENCE_BOUND = {torch.float16: (0.93, 0.015), torch.bfloat16: (0.78, 0.05)}
 
 
 @pytest.mark.gpu

@@ -258,6 +258,47 @@ def test_persistent_search_kernel_equals_launch_per_phase(game, N, sims, peaked,
         assert int(a[4].max()) > 34, int(a[4].max())  # runs in two chunks (in fp16 the 49-deep chain of random nets turns NaN first)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_config3_at_full_size_8192_envs_50_simulations(dtype):
+    """BASELINE.json configs[2] at its own size through the product path: 8192 Hanabi-Full envs, 50 simulations per move, the
+    self-play actor under its hipGraph with the search kernel shape the library chooses there (32 trees per workgroup, two
+    side by side per wave: k_search_half).  Size-independent properties: every tree's visit counts add up to 49, no illegal
+    env step, no wait on an arrival counter given up; and on the same prepared roots the forced 16-trees-per-workgroup shape
+    -- the one the other tests pin to the oracle through the launch-per-phase search -- gives the same bits."""
+    from hanabizero_amd import cytree
+    from hanabizero_amd.mcts import MCTS
+    from hanabizero_amd._lib import poll_giveups
+    N, sims = 8192, 50
+    giveups_before = poll_giveups()
+    cfg, eng, actor = make("Hanabi-Full", N, sims, 4, dtype, use_graph=True, seed=8)
+    for move in range(3):
+        actor.step()
+        torch.cuda.synchronize()
+        dist = actor.roots.distributions_tensor()
+        assert dist.shape == (N, cfg.action_space_size) and bool((dist.sum(1) == sims - 1).all()), move
+        masked = actor.counts
+        assert bool(((masked == dist) | ((masked == 0) & (dist >= 0))).all()) and bool((masked.sum(1) > 0).all())
+    # (the first step() also ran the two eager lock-steps that precede the graph capture)
+    assert int(actor.illegal_steps) == 0 and int(actor.traj_len.max()) == actor.total_moves // N == 5 and int(actor.traj_len.min()) >= 0
+    # the same roots, searched by the shape of the library's choice and by the forced 16-row shape
+    A = cfg.action_space_size
+    _, logits0, hidden0 = actor.root_inference()
+    noise = actor.noise.clone()
+    res = []
+    for rows in (0, 16):
+        roots = cytree.Roots(N, A, sims, tie_seed=9, tree_id_base=3)
+        roots.prepare(cfg.root_exploration_fraction, noise, torch.zeros(N, device="cuda"), logits0, actor.legal)
+        pool = torch.zeros(sims, N, eng.H, dtype=eng.dtype, device="cuda")
+        MCTS(cfg, persistent=True, rows_per_workgroup=rows).run_multi(roots, eng, hidden0, pool=pool)
+        torch.cuda.synchronize()
+        res.append((roots.distributions_tensor(), roots.values_tensor(), roots.path_len_tensor(), pool))
+        del roots
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+    assert torch.equal(res[0][3].view(torch.int16), res[1][3].view(torch.int16))
+    assert int(res[0][0].sum()) == N * (sims - 1)
+    assert poll_giveups() == giveups_before, "a wave gave up waiting for an arrival counter (include/hz_mlp.h)"
+
+
 def test_persistent_search_limits_fall_back_to_launch_per_phase():
     """hz_search_run refuses 64 or more simulations (include/hz_search.h); MCTS.run_multi then runs the launch-per-phase
     search, whose results are what they would have been."""
