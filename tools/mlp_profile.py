@@ -16,12 +16,8 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
 def main():
-    out = os.path.join(ROOT, "gpurun_out", "libmlp_prof.so")
-    os.makedirs(os.path.dirname(out), exist_ok=True)
-    src = os.path.join(ROOT, "hanabizero_amd", "csrc")
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                           "-ffp-contract=off", "-w", "-DHZ_MLP_PROFILE"] + [f for f in sys.argv[5:] if f.startswith("-D")] + [ "-I" + src, "-I" + os.path.join(ROOT, "include"),
-                           "-o", out, os.path.join(src, "hz_mlp.hip"), os.path.join(src, "hz_tree.hip")])
+    from _build import build
+    out = build("libmlp_prof.so", {"hz_mlp.hip": ["-DHZ_MLP_PROFILE"] + [f for f in sys.argv[5:] if f.startswith("-D")]})
     import bench
     from hanabizero_amd._lib import MlpHeader
     from hanabizero_amd.config import make_config

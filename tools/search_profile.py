@@ -9,20 +9,9 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-out = os.path.join(ROOT, "gpurun_out", "libsearch_prof.so")
-os.makedirs(os.path.dirname(out), exist_ok=True)
-src = os.path.join(ROOT, "hanabizero_amd", "csrc")
-files = [os.path.join(src, f) for f in ("hz_tree.hip", "hz_env.hip", "hz_selfplay.hip", "hz_netglue.hip", "hz_mlp.hip",
-                                        "hz_search.hip")]
-base = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
-        "-fhip-fp32-correctly-rounded-divide-sqrt", "-w", "-I" + src, "-I" + os.path.join(ROOT, "include")]
-objs = []
-for f in files:  # the tree stamps (TP macros of hz_tree_dev.h) only inside the search kernel's translation unit
-    o = os.path.join(ROOT, "gpurun_out", os.path.basename(f) + ".prof.o")
-    extra = ["-DHZ_SEARCH_PROFILE", "-DHZ_TREE_PROFILE"] + sys.argv[2:] if f.endswith("hz_search.hip") else []
-    subprocess.check_call(base + extra + ["-c", "-o", o, f])
-    objs.append(o)
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from _build import build  # noqa: E402
+out = build("libsearch_prof.so", {"hz_search.hip": ["-DHZ_SEARCH_PROFILE", "-DHZ_TREE_PROFILE"] + sys.argv[2:]})
 os.environ["HANABIZERO_HIP_LIB"] = out
 
 import numpy as np  # noqa: E402

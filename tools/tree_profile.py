@@ -10,13 +10,9 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-out = os.path.join(ROOT, "gpurun_out", "libtree_prof.so")
-os.makedirs(os.path.dirname(out), exist_ok=True)
-src = os.path.join(ROOT, "hanabizero_amd", "csrc")
-files = [os.path.join(src, f) for f in ("hz_tree.hip", "hz_env.hip", "hz_selfplay.hip", "hz_netglue.hip", "hz_mlp.hip")]
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                       "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt", "-w",
-                       "-DHZ_TREE_PROFILE", "-I" + src, "-I" + os.path.join(ROOT, "include"), "-o", out] + files)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from _build import build  # noqa: E402
+out = build("libtree_prof.so", {"hz_tree.hip": ["-DHZ_TREE_PROFILE"]})
 os.environ["HANABIZERO_HIP_LIB"] = out
 
 import numpy as np  # noqa: E402
