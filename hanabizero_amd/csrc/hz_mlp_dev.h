@@ -233,6 +233,9 @@ struct RowFrag {
 // FINAL = false: stop after the last layer (logits stay in the image; the caller's waves read them there).
 // BW = false: HZ_MLP_BLOCKWISE jobs wait at a workgroup barrier instead (the stronger condition; for the kernel that has no
 // registers to spare for the counters' address).
+// (Tried, r03: the ring primed across the caller's tree phase -- the next inference's first fragments requested at the end of the
+// previous one, the prologue below skipped: -0.4 % moves/s at 4096 envs, -0.5 % at 8192 in an A/B on one box.  The prologue's
+// round trip is already hidden behind the staging of the rows, and the extra requests are in the way of the tree phase's.)
 template <class EL, int RT, int NW, int NT, int STAGE = STAGE_GATHER, bool FINAL = true, bool BW = true>
 __device__ __forceinline__ void mlp_body(
     const hz_mlp_header_t& H, const hz_mlp_job_t* __restrict__ jobs, const uint16_t* __restrict__ wstream,

@@ -153,7 +153,7 @@ extern "C" int hz_search_profile_read(unsigned long long* host) {
 // trees than 16 x #CUs, where the workgroups would otherwise queue and stream the weights once per 16 rows.
 // (amdgpu_num_vgpr: the compiler's registers end below the weight ring of the hand-scheduled k-loop, hz_mlp_dev.h)
 template <class EL, int RT>
-__global__ __launch_bounds__(1024, 1) __attribute__((amdgpu_num_vgpr(HZ_ASMK_VGPRS))) void k_search(TreeView tv, hz_mlp_header_t H, SearchArgs a) {
+__device__ __forceinline__ void search_kernel_body(const TreeView& tv, const hz_mlp_header_t& H, const SearchArgs& a) {
   extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
   constexpr int MT = 16 * RT;
   const int lane = threadIdx.x & 63;
@@ -227,6 +227,17 @@ __global__ __launch_bounds__(1024, 1) __attribute__((amdgpu_num_vgpr(HZ_ASMK_VGP
     o[0] = p_tree + (SP_NOW() - t0); o[1] = p_wait1; o[2] = p_mlp; o[3] = p_wait2;
   }
 #endif
+}
+
+template <class EL>
+__global__ __launch_bounds__(1024, 1) __attribute__((amdgpu_num_vgpr(HZ_ASMK_VGPRS))) void k_search(TreeView tv, hz_mlp_header_t H, SearchArgs a) {
+  search_kernel_body<EL, 1>(tv, H, a);
+}
+// the two trees of a wave one after the other: its register pressure peaks above the others', and amdgpu_num_vgpr is a budget the
+// allocator was seen to overdraw by four registers -- into the ring (tools/scan_ring_registers.py) -- so this one gets a lower one
+template <class EL>
+__global__ __launch_bounds__(1024, 1) __attribute__((amdgpu_num_vgpr(HZ_ASMK_VGPRS - 8))) void k_search_turn(TreeView tv, hz_mlp_header_t H, SearchArgs a) {
+  search_kernel_body<EL, 2>(tv, H, a);
 }
 
 // Two trees per tree-owning wave, side by side in its two 32-lane halves (hz_tree_half_dev.h; A <= 32, hidden <= 512): the tree
@@ -444,8 +455,8 @@ extern "C" int hz_search_run(hz_tree_t* t, int num_simulations, const hz_mlp_hea
   do {                                                                                               \
     if (halves && rows_wg == 32) HZ_SEARCH_LAUNCH(V0 + 2, (k_search_half<EL, 16>), (t->N + 31) / 32); \
     else if (halves) HZ_SEARCH_LAUNCH(V0 + 3, (k_search_half<EL, 8>), (t->N + 15) / 16);             \
-    else if (rows_wg == 32) HZ_SEARCH_LAUNCH(V0 + 1, (k_search<EL, 2>), (t->N + 31) / 32);           \
-    else HZ_SEARCH_LAUNCH(V0, (k_search<EL, 1>), (t->N + 15) / 16);                                  \
+    else if (rows_wg == 32) HZ_SEARCH_LAUNCH(V0 + 1, (k_search_turn<EL>), (t->N + 31) / 32);         \
+    else HZ_SEARCH_LAUNCH(V0, (k_search<EL>), (t->N + 15) / 16);                                     \
   } while (0)
   int cur = -1;
   HZ_HIP(hipGetDevice(&cur));
