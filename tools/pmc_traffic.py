@@ -11,7 +11,7 @@ import json
 import os
 import sys
 
-KERNELS = {"k_search": ("k_search<", "k_search_half<"), "k_traverse": "k_traverse(", "k_backprop": "k_backprop<", "k_backprop_traverse": "k_backprop_traverse<", "k_mlp_recurrent": "k_mlp_recurrent",
+KERNELS = {"k_search": ("k_search<", "k_search_half<", "k_search_turn<"), "k_move_tail_a": "k_move_tail_a", "k_move_tail_b": "k_move_tail_b", "k_traverse": "k_traverse(", "k_backprop": "k_backprop<", "k_backprop_traverse": "k_backprop_traverse<", "k_mlp_recurrent": "k_mlp_recurrent",
            "k_env_observe": "k_env_observe", "k_env_rules": "k_env_rules", "k_env_reset_rows": "k_env_reset_rows", "k_prepare": "k_prepare",
            "k_select_action": "k_select_action", "k_rows_scatter": "k_rows_scatter", "k_actor_draw": "k_actor_draw",
            "k_actor_record_search": "k_actor_record_search", "k_actor_record_step_slots": "k_actor_record_step_slots",

@@ -15,7 +15,7 @@ from contextlib import redirect_stdout
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
-R01 = {  # round 1's values of the same counters (profiles/r01_k_search_pmc.md, r01_k_search_half_pmc.md)
+R01 = {  # round 1's values of the same counters (profiles/r01_k_search_pmc.md, r01_k_search_half_pmc.md; bf16 nets then, fp16 now)
     "cyc": ("4.5-4.7 M", "5.1-5.3 M"), "req": ("3.247e8", "3.242e8"), "rate": ("21.9 TB/s, 63 %", "53 %"), "lat": ("258", "224"),
     "tcc": ("89-92 %", "92 %"), "ta": ("69 %", "-"), "pend": ("23 %", "-"), "hit": ("95.6 %", "93.9 %"), "nmfma": ("3.83e7", "7.67e7"),
     "mfma": ("13 %", "23 %"), "wait": ("36 %", "35 %"), "lds": ("48 %", "47 %"), "hbm": ("1.58 GB", "-")}
@@ -45,9 +45,11 @@ Command (on the MI355X box, `tools/profile_round.sh %s`): `cd /tmp && export TMP
 (tree built from commit %s: %s).
 
 State: Hanabi-Full 2p, %d envs, 49 simulations per move in ONE launch of the persistent search kernel (%d trees per workgroup); the whole
-lock-step (15 kernels) is one hipGraph.  Search-kernel rows: 14 from the timed / warm-up / capture steps, the rest from bench.py's roofline pass
-(6 graphs of 4 back-to-back launches on snapshots of live trees); `k_backprop_traverse`, `k_traverse`, `k_backprop`, `k_mlp_recurrent<.., 4, 4>` and the
-`__amd_rocclr_copyBuffer` rows come ONLY from that pass (snapshots, the launch-per-phase search that measures the mean path length).
+lock-step (9 kernels: three hipBLASLt GEMMs + `k_add_relu` + `k_mlp_recurrent16` = the root inference, `k_prepare`, the search kernel,
+`k_move_tail_a`, `k_move_tail_b`) is one hipGraph.  Search-kernel rows: 14 from the timed / warm-up / capture steps, the rest from bench.py's
+roofline pass (6 graphs of 4 back-to-back launches on snapshots of live trees); `k_backprop_traverse`, `k_traverse`, `k_backprop`,
+`k_mlp_recurrent<.., 4, 4>`, the `__amd_rocclr_copyBuffer` rows and 24 of the `k_move_tail_*` rows come ONLY from that pass (snapshots, the
+launch-per-phase search that measures the mean path length, the tail timing's replays).
 bench.py's own HIP-event figure for the same kernel in this run: avg %.1f us, best graph %.1f us
 (rocprofv3's per-dispatch average below includes the cold first launches of each snapshot).
 
@@ -87,8 +89,8 @@ def pmc(tag, commit, note):
     rate = lambda c, g: c["gb"] / (c["cyc"] / (g * 1e9)) / 1e3
     md = """# %s hardware counters of the persistent search kernels (Hanabi-Full, 49 simulations per launch)
 
-Command (on the MI355X box, repo root): `bash tools/pmc_search.sh` (4096 envs: `k_search<ElBf16, 1>`, 256 workgroups x 16 trees) and
-`bash tools/pmc_search.sh --workload full8192` (`k_search_half<ElBf16, 16>`, 256 workgroups x 32 trees): one `rocprofv3 --pmc <group>
+Command (on the MI355X box, repo root): `bash tools/pmc_search.sh` (4096 envs: `k_search<ElF16>`, 256 workgroups x 16 trees) and
+`bash tools/pmc_search.sh --workload full8192` (`k_search_half<ElF16, 16>`, 256 workgroups x 32 trees): one `rocprofv3 --pmc <group>
 --kernel-include-regex k_search --output-format csv` pass per counter group (no trace options) over `python bench.py --steps 3 --warmup 1
 --no-cpu-baseline --no-roofline --no-also`; means over the 7 launches of each pass; tree at commit %s (%s).
 `_sum` = over the 256 TCPs / 128 L2 channels, `_avr` = per instance.  Round 1's values of the same counters (profiles/r01_k_search_pmc.md,
@@ -135,7 +137,7 @@ kernel scales with it.  The MFMA pipes are busy 14 %% / 24 %% of the time: with 
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
     note = sys.argv[2] if len(sys.argv) > 2 else "hand-scheduled k-loop, scalar-cache start values, blockwise layer boundaries"
     commit = head()
     for w in ("full4096", "full8192"):
