@@ -97,7 +97,7 @@ def _load():
         "hz_actor_begin_move": [C.POINTER(ActorBufs), V, V, V, V, I64, V, I64, I, I64, V],
         "hz_actor_begin_move_draw": [C.POINTER(ActorBufs), V, V, V, V, I64, V, I64, I, I64, U64, V, C.c_double, V, V, V],
         # include/hz_movetail.h
-        "hz_actor_move_tail": [V, V, C.POINTER(ActorBufs), I, V, V, V, V, F, I, V, V, V, V, V, V, V, V, I64, I, I64, I, U64, V,
+        "hz_actor_move_tail": [V, V, C.POINTER(ActorBufs), I, V, V, V, V, F, V, I, V, V, V, V, V, V, V, V, I64, I, I64, I, U64, V,
                                C.c_double, V, V, V],
         # include/hz_mlp.h
         "hz_mlp_recurrent": [C.POINTER(MlpHeader), V, V, V, V, V, I64, V, I64, V, V, V, V, V, I, I, V],

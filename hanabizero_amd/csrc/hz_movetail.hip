@@ -34,6 +34,7 @@ struct TailA {
   const uint8_t* legal;   // [N][A] legal moves of the position searched
   const double* uniform;  // [N] sampling uniforms of this move
   float temperature;
+  const float* temperature_dev;  // [1] or NULL: read at run time, so that a captured lock-step follows a temperature schedule
   int deterministic;
   int32_t* action;        // [N] OUT
   double* entropy;        // [N] OUT or NULL
@@ -74,6 +75,7 @@ __global__ __launch_bounds__(256) void k_move_tail_a(TreeView tv, EnvCfg g, uint
   // this move's uniforms, read by everybody before anybody's draw overwrites them
   const bool live = env < b.num_envs;
   const double u_now = (a.deterministic || !live) ? 0.0 : a.uniform[env];
+  const float temperature = a.temperature_dev ? a.temperature_dev[0] : a.temperature;
   __syncthreads();
   // the next move's draws, floor(64 / A) envs to a wave: wave w draws for the workgroup's envs [w * per, (w + 1) * per)
   const int per = 64 / A;
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(256) void k_move_tail_a(TreeView tv, EnvCfg g, uint
   // ... select_action + store_search_stats (hz_actor_record_search)
   double ent;
   int mc;
-  int action = select_action_wave(env, lane, A, a.counts, visit, lg_now, u_now, a.temperature, a.deterministic, &ent, &mc);
+  int action = select_action_wave(env, lane, A, a.counts, visit, lg_now, u_now, temperature, a.deterministic, &ent, &mc);
   action = __builtin_amdgcn_readfirstlane(action);
   TS(0, 2);
   if (lane < A) b.visits[((size_t)env * T + t) * A + lane] = (int16_t)mc;
@@ -444,7 +446,7 @@ __global__ __launch_bounds__(256) void k_move_tail_b(EnvCfg g, uint32_t* __restr
 }
 
 extern "C" int hz_actor_move_tail(hz_tree_t* tree, hz_env_t* env, const hz_actor_bufs_t* bufs, int mdp, int32_t* counts,
-                                  float* root_values, uint8_t* legal, double* uniform, float temperature, int deterministic,
+                                  float* root_values, uint8_t* legal, double* uniform, float temperature, const float* temperature_dev, int deterministic,
                                   int32_t* action, double* entropy, int32_t* reward, uint8_t* done, int32_t* score,
                                   int32_t* status, int32_t* packed, void* stack_buf, int64_t stack_row_bytes, int stack,
                                   int64_t slot_bytes, int obs_dtype, uint64_t seed, int64_t* move_count, double alpha,
@@ -476,7 +478,7 @@ extern "C" int hz_actor_move_tail(hz_tree_t* tree, hz_env_t* env, const hz_actor
              D, stack, (long long)slot_bytes, (long long)stack_row_bytes);
   HZ_REQUIRE(((uintptr_t)done % 4) == 0, "hz_actor_move_tail: the done flags must be 4-B aligned");
   TailA a;
-  a.counts = counts; a.values = root_values; a.legal = legal; a.uniform = uniform; a.temperature = temperature;
+  a.counts = counts; a.values = root_values; a.legal = legal; a.uniform = uniform; a.temperature = temperature; a.temperature_dev = temperature_dev;
   a.deterministic = deterministic; a.action = action; a.entropy = entropy; a.reward = reward; a.done = done; a.score = score;
   a.status = status; a.count_snap = scratch; a.mdp = mdp;
   a.seed = seed; a.move_count = (long long*)move_count; a.alpha = alpha; a.noise = noise; a.uniform_next = uniform;

@@ -103,6 +103,9 @@ class SelfPlayActor:
         self.counts = z(N, A, dtype=torch.int32)
         self.values = z(N, dtype=torch.float32)
         self._tail_scratch = z(2, dtype=torch.int64)
+        # visit_softmax_temperature_fn's value in device memory: the fused tail reads it when it runs, so a captured lock-step
+        # follows the schedule (set_trained_steps)
+        self.temperature = torch.full((1,), float(config.visit_softmax_temperature_fn(0, 0)), dtype=torch.float32, device=d)
         assert done_dtype_ok(self.env)
         tr, o = self.traj, self.out
         self.bufs = ActorBufs(num_envs=N, num_actions=A, packed_words=W, max_moves=T, outbox_games=self.cap,
@@ -180,7 +183,7 @@ class SelfPlayActor:
             from .hanabi_env import _OBS_DTYPES
             env, es = self.env, self.stack_buf.element_size()
             check(lib.hz_actor_move_tail(self.roots._h, env._h, b, env.mdp, self.counts.data_ptr(), self.values.data_ptr(),
-                                         self.legal.data_ptr(), self.uniform.data_ptr(), float(cfg.visit_softmax_temperature_fn(0, 0)),
+                                         self.legal.data_ptr(), self.uniform.data_ptr(), 1.0, self.temperature.data_ptr(),
                                          int(self.deterministic), self.action.data_ptr(), self.entropy.data_ptr(),
                                          env.reward.data_ptr(), env.done.data_ptr(), env.score.data_ptr(), env.status.data_ptr(),
                                          self.tmp_packed.data_ptr(), self.stack_buf.data_ptr(), self.stack_buf.stride(0) * es,
@@ -191,7 +194,7 @@ class SelfPlayActor:
             return
         self.roots.root_stats_tensors(self.counts, self.values)
         check(lib.hz_actor_record_search(b, self.counts.data_ptr(), self.values.data_ptr(), self.legal.data_ptr(),
-                                         self.uniform.data_ptr(), float(cfg.visit_softmax_temperature_fn(0, 0)),
+                                         self.uniform.data_ptr(), float(getattr(self, "_temperature_host", cfg.visit_softmax_temperature_fn(0, 0))),
                                          int(self.deterministic), self.action.data_ptr(), self.entropy.data_ptr(), st),
               "hz_actor_record_search")
         reward, done, score, status = self.env.step(self.action)
@@ -218,6 +221,13 @@ class SelfPlayActor:
                                           self.newest.data_ptr(), self.newest.stride(0) * es, self.stack_buf.data_ptr(),
                                           self.stack_buf.stride(0) * es, self.stack, self.Dp * es, st), "hz_actor_begin_move")
             self._drawn = False
+
+    def set_trained_steps(self, trained_steps):
+        """selfplay_worker.py:172-174: the visit-count temperature of the coming moves, from the learner's step counter
+        (config.visit_softmax_temperature_fn; 1.0 throughout while change_temperature is off, as in both Hanabi configs).  In place:
+        a captured lock-step picks it up at its next replay (fused tail; the launch-per-phase tail takes it at enqueue time)."""
+        self.temperature.fill_(float(self.cfg.visit_softmax_temperature_fn(0, int(trained_steps))))
+        self._temperature_host = float(self.cfg.visit_softmax_temperature_fn(0, int(trained_steps)))
 
     def _capture(self):
         self.roots.set_params(self.cfg.pb_c_base, self.cfg.pb_c_init, self.cfg.discount, self.cfg.value_delta_max)
@@ -357,6 +367,13 @@ class ActorGroup:
         self.actors = list(actors)
         self.device = self.actors[0].device
         self._graph = None
+
+    def set_trained_steps(self, trained_steps):
+        """selfplay_worker.py:172-174: the visit-count temperature of the coming moves, from the learner's step counter
+        (config.visit_softmax_temperature_fn; 1.0 throughout while change_temperature is off, as in both Hanabi configs).  In place:
+        a captured lock-step picks it up at its next replay (fused tail; the launch-per-phase tail takes it at enqueue time)."""
+        self.temperature.fill_(float(self.cfg.visit_softmax_temperature_fn(0, int(trained_steps))))
+        self._temperature_host = float(self.cfg.visit_softmax_temperature_fn(0, int(trained_steps)))
 
     def _capture(self):
         for a in self.actors:

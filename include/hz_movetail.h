@@ -27,6 +27,10 @@ extern "C" {
  *   counts [N][A] i32, root_values [N] f32   OUT  as hz_tree_get_root_stats + hz_actor_record_search leave them
  *   legal [N][A] u8                          IN: legal moves of the searched positions; OUT: of the next positions
  *   uniform [N] f64                          IN: this move's sampling uniforms; OUT: the next move's (hz_actor_draw)
+ *   temperature, temperature_dev             visit_softmax_temperature_fn's value: the float, or -- when temperature_dev is not NULL --
+ *                                            the DEVICE float it points at, read when the kernel runs (a lock-step captured in a
+ *                                            hipGraph then follows a temperature schedule: core/config.py visit_softmax_temperature_fn,
+ *                                            selfplay_worker.py:172-174)
  *   action [N] i32, entropy [N] f64 or NULL  OUT  hz_actor_record_search
  *   reward, done, score, status [N]          OUT  hz_env_step (done: u8, 4-byte aligned; the others i32)
  *   packed [N][W] i32                        OUT  the next positions' observations, bit-packed (hz_env_observe)
@@ -37,7 +41,7 @@ extern "C" {
  *   scratch [2] i64                          DEVICE scratch
  * bufs->slot / finished / num_finished are filled as hz_actor_record_step fills them. */
 int hz_actor_move_tail(hz_tree_t* tree, hz_env_t* env, const hz_actor_bufs_t* bufs, int mdp, int32_t* counts,
-                       float* root_values, uint8_t* legal, double* uniform, float temperature, int deterministic,
+                       float* root_values, uint8_t* legal, double* uniform, float temperature, const float* temperature_dev, int deterministic,
                        int32_t* action, double* entropy, int32_t* reward, uint8_t* done, int32_t* score, int32_t* status,
                        int32_t* packed, void* stack_buf, int64_t stack_row_bytes, int stack, int64_t slot_bytes,
                        int obs_dtype, uint64_t seed, int64_t* move_count, double alpha, float* noise, int64_t* scratch,

@@ -103,6 +103,51 @@ def test_gather_and_broadcast_world2_gloo():
     assert res == [(0, True), (1, True)]
 
 
+def _worker_packed(rank, world, port, q):
+    """gather_packed's point-to-point exchange with more than one sender: ranks with games send their exact bytes to rank 0,
+    ranks without send nothing, rank 0's own games take no transfer; three rounds, buffers reused."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hanabizero_amd.dist import gather_packed
+    from hanabizero_amd.selfplay import pack_records, unpack_packed, unpack_record
+    A, W = 20, 25
+    ok = True
+    for rnd, ns in enumerate([(2, 0, 5, 1), (0, 3, 0, 4), (1, 1, 1, 1), (0, 0, 0, 0)]):
+        n = ns[rank]
+        mine = _fake_rec(n, 900 + 10 * rnd + rank, T=4 + 2 * rank, A=A, W=W) if n else None
+        packed = None
+        if mine is not None:
+            buf, n_, moves_ = pack_records(mine, A, W)
+            packed = (torch.from_numpy(buf), n_, moves_)
+        got = gather_packed(packed, A, W, dst=0)
+        if rank == 0:
+            want = [(r, _fake_rec(c, 900 + 10 * rnd + r, T=4 + 2 * r, A=A, W=W)) for r, c in enumerate(ns[:world]) if c]
+            ok &= len(got) == len(want)
+            for (buf, n_, moves_), (r, w) in zip(got, want):
+                view = unpack_packed(buf, n_, moves_, A, W)
+                ok &= n_ == ns[r] and moves_ == int(w["meta"][:, 0].sum())
+                for i in range(n_):
+                    a, b = unpack_record(view, i), unpack_record(w, i)
+                    ok &= all(np.array_equal(np.asarray(a[k]), np.asarray(b[k])) for k in a)
+        else:
+            ok &= got is None
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_gather_packed_world4_gloo():
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_packed, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert res == [(r, True) for r in range(4)]
+
+
 @pytest.mark.gpu
 def test_collectives_over_rccl_one_rank():
     """The same three exchange steps through the "nccl" (= RCCL) backend with device tensors: one rank on the one GPU of

@@ -401,6 +401,31 @@ def test_fused_launches_equal_their_separate_calls(game, N, stack, dtype, moves)
     assert int(states[0]["illegal"]) == 0
 
 
+def test_temperature_schedule_reaches_a_graph_captured_actor():
+    """config.visit_softmax_temperature_fn (selfplay_worker.py:172-174) changes with the learner's step counter when
+    change_temperature is on.  The fused tail reads the temperature from device memory when it runs, so an actor whose lock-step
+    was captured at temperature 1 samples at 0.5 after set_trained_steps -- exactly like an eager actor that enqueues the
+    launch-per-phase tail with the new value."""
+    recs = []
+    for use_graph, fused_tail in ((True, True), (False, False)):
+        cfg, eng, actor = make("Hanabi-Small", 80, 10, 2, torch.float16, use_graph=use_graph, seed=13, fused_tail=fused_tail)
+        cfg.visit_softmax_temperature_fn = lambda num_moves, trained_steps: 1.0 if trained_steps < 100 else 0.5
+        actor.set_trained_steps(0)
+        n_first = 9 if use_graph else 11  # (the graph-captured actor's first step() also runs the two eager warm-up lock-steps)
+        for _ in range(n_first):
+            actor.step()
+        actor.set_trained_steps(200)
+        for _ in range(14):
+            actor.step()
+        torch.cuda.synchronize()
+        assert actor.total_moves == 25 * 80 and float(actor.temperature) == 0.5
+        recs.append((actor.drain(), actor.action.clone(), actor.entropy.clone()))
+    assert recs[0][0]["meta"].shape[0] > 10
+    for k in recs[0][0]:
+        assert np.array_equal(recs[0][0][k], recs[1][0][k]), k
+    assert torch.equal(recs[0][1], recs[1][1]) and torch.equal(recs[0][2], recs[1][2])
+
+
 def test_new_entry_points_report_bad_arguments():
     """hz_actor_pack / hz_actor_packed_bytes / hz_env_reset_rows / hz_actor_begin_move_draw / hz_search_run:
     malformed calls come back as error codes with a message (the reference aborts or corrupts memory), nothing is launched."""
