@@ -81,7 +81,7 @@ def adjust_lr(config, optimizer, step_count):
 
 
 # ---- batches (core/reanalyze_worker.py, the parts that do not search) ---------------------------------------------
-def make_batch(games, positions, config, value_fn, weights=None, rng=None, policy_re=None):
+def make_batch(games, positions, config, value_fn, weights=None, rng=None, policy_re=None, obs_dtype=np.float32):
     """A learner batch in the reference's layout from finished ``GameHistory`` objects and sampled positions:
     inputs as BatchWorker_CPU.make_batch assembles them (reanalyze_worker.py:148-168: stacked observations padded with
     the last frame, actions padded with random ones past the end, mask), value / reward targets as
@@ -91,15 +91,19 @@ def make_batch(games, positions, config, value_fn, weights=None, rng=None, polic
     -> [M] values`` is the target model (e.g. ``lambda o: engine.initial(torch.from_numpy(o).cuda())[0].cpu().numpy()``).
     policy_re: [R, U + 1, A] policy targets re-searched with the target model for the FIRST R positions of the batch
     (hanabizero_amd.reanalyze.prepare_policy_re over reanalyze.policy_re_context(config, games[:R], positions[:R])); they
-    replace those rows' stored search statistics, as _prepare_target_gpu concatenates [reanalyzed | stored] (:412-419)."""
+    replace those rows' stored search statistics, as _prepare_target_gpu concatenates [reanalyzed | stored] (:412-419).
+    obs_dtype: element type of the observation arrays this function fills (the batch's `obs_batch` and the bootstrap windows
+    handed to value_fn).  float32 is the reference's; np.uint8 keeps the frames as they are stored (0 / 1 bytes: a quarter of
+    the host traffic and of the PCIe bytes -- 12 MB instead of 47 MB per Hanabi-Full-5p batch); update_weights /
+    GraphedUpdate and the engines convert on the device."""
     rng = rng or np.random
     U, td, stack, A, g = config.num_unroll_steps, config.td_steps, config.stacked_observations, config.action_space_size, config.discount
     B = len(games)
     D = config.obs_shape // stack
     # (outputs are written in place: the per-sample lists + np.stack of the straightforward version cost more than
     # everything else in this function)
-    obs_batch = np.empty((B, stack + U, D), np.float32)
-    value_obs = np.zeros((B * (U + 1), config.obs_shape), np.float32)  # zero_obs past the end of a game
+    obs_batch = np.empty((B, stack + U, D), obs_dtype)
+    value_obs = np.zeros((B * (U + 1), config.obs_shape), obs_dtype)  # zero_obs past the end of a game
     value_mask = np.zeros(B * (U + 1), np.float64)
     action_lst, mask_lst = [], []
     k = 0
@@ -142,7 +146,9 @@ def make_batch(games, positions, config, value_fn, weights=None, rng=None, polic
 
 # ---- one learner step ------------------------------------------------------------------------------------------
 def _t(a, device, dtype=torch.float32):
-    t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.asarray(a))
+    t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))  # (a strided host view crosses PCIe row by row)
+    if t.dtype == torch.uint8 and t.device != torch.device(device):
+        return t.to(device).to(dtype)  # (0 / 1 frames travel as bytes and are widened on the device)
     return t.to(device=device, dtype=dtype)
 
 
@@ -196,9 +202,8 @@ def update_weights(model, batch, optimizer, config, amp=torch.bfloat16):
     target_reward = np.asarray(target_reward)[:, :config.num_unroll_steps] if not isinstance(target_reward, torch.Tensor) \
         else target_reward[:, :config.num_unroll_steps]
     dev = next(model.parameters()).device
-    obs_batch_ori = _t(obs_batch_ori, dev)
     # non-image branch of train.py:71-74: image_channel = 1, the first `stack` observations are the model input
-    obs_batch = obs_batch_ori[:, 0:config.stacked_observations, :]
+    obs_batch = _t(obs_batch_ori[:, 0:config.stacked_observations, :], dev)
     action_batch = _t(action_batch, dev, torch.long)
     target_reward, target_value = _t(target_reward, dev), _t(target_value, dev)
     target_policy, weights = _t(target_policy, dev), _t(weights, dev)
@@ -295,7 +300,7 @@ class GraphedUpdate:
         if self._graph is None:
             self._capture()
         dev = self.obs.device
-        self.obs.copy_(_t(obs_batch_ori, dev)[:, 0:cfg.stacked_observations, :], non_blocking=True)
+        self.obs.copy_(_t(obs_batch_ori[:, 0:cfg.stacked_observations, :], dev), non_blocking=True)  # (only the first window is the model's input)
         self.action.copy_(_t(action_batch, dev, torch.long), non_blocking=True)
         self.target_reward.copy_(_t(target_reward, dev)[:, :cfg.num_unroll_steps], non_blocking=True)
         self.target_value.copy_(_t(target_value, dev), non_blocking=True)

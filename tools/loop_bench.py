@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--reanalyze-share", type=float, default=0.5, help="share of every batch whose policy targets are re-searched")
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
     ap.add_argument("--flush-every", type=int, default=10)
+    ap.add_argument("--obs-float32", action="store_true", help="make_batch in the reference's float32 layout (default: frames stay bytes until they are on the device)")
     ap.add_argument("--checkpoint-interval", type=int, default=0, help="learner steps between weight hand-overs to the actor (0: the config's, 2000 for Hanabi-Full; one hand-over is timed after the loop either way)")
     args = ap.parse_args()
     device = torch.device("cuda", 0)
@@ -85,7 +86,7 @@ def main():
             ctx = policy_re_context(cfg, games[:R], pos[:R], idx[:R])
             pol_re = prepare_policy_re(cfg, target, ctx, tie_seed=it)
         t2 = time.perf_counter()
-        batch = make_batch(games, pos, cfg, value_fn, weights=w, rng=np.random.RandomState(it), policy_re=pol_re)
+        batch = make_batch(games, pos, cfg, value_fn, weights=w, rng=np.random.RandomState(it), policy_re=pol_re, obs_dtype=np.float32 if args.obs_float32 else np.uint8)
         t3 = time.perf_counter()
         adjust_lr(cfg, opt, it)
         loss_data, prio = graphed(batch)
