@@ -39,6 +39,8 @@ def test(config, engine, counter=0, test_episodes=1000, device=None, tie_seed=0,
     zeros = torch.zeros(E, dtype=torch.float32, device=device)
     stream = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
     limit = max_moves if max_moves is not None else 10 * config.max_moves
+    from ._lib import poll_giveups
+    giveups_before = poll_giveups() if getattr(engine, "fused", None) is not None else 0
     with torch.no_grad():
         for _ in range(limit):
             if bool(done.all()):
@@ -59,4 +61,8 @@ def test(config, engine, counter=0, test_episodes=1000, device=None, tie_seed=0,
             env.observe(out=newest, legal=legal)  # finished games keep their last observation; they are not stepped again
             shifted = torch.cat((stack_buf[:, 1:], newest[:, None, :]), dim=1)
             stack_buf.copy_(torch.where(active[:, None, None], shifted, stack_buf))
-    return final.cpu().numpy().tolist(), steps.cpu().numpy().tolist()
+    scores, lengths = final.cpu().numpy().tolist(), steps.cpu().numpy().tolist()
+    if getattr(engine, "fused", None) is not None and poll_giveups() != giveups_before:  # (include/hz_mlp.h: must not happen)
+        raise RuntimeError("the fused inference gave up waits on its arrival counters during this evaluation: its searches "
+                           "ran with inputs that may not have been there")
+    return scores, lengths
