@@ -38,6 +38,8 @@ WORKLOADS = {
     "full16384": ("Hanabi-Full", 16384, 50, 4),   # scaling probes beyond the named configs (288 GB HBM has room)
     "full32768": ("Hanabi-Full", 32768, 50, 4),
     "full5p2048": ("Hanabi-Full-5p", 2048, 50, 4),  # BASELINE.json configs[4]'s game (A = 48, D = 1385), self-play part
+    "full5p4096": ("Hanabi-Full-5p", 4096, 50, 4),  # ... with a workgroup of 16 trees on every compute unit
+    "full5p8192": ("Hanabi-Full-5p", 8192, 50, 4),  # ... and with 32 trees per workgroup, one after the other (A > 32: k_search_turn)
 }
 HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_PEAK_TFLOPS = 2500.0       # same guide: ~2.5 PFLOP/s dense bf16 (fp16 runs at the same rate)
