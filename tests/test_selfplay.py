@@ -360,7 +360,9 @@ def test_packed_drain_equals_drain():
 
 
 @pytest.mark.parametrize("game,N,stack,dtype,moves", [("Hanabi-Small", 96, 2, torch.bfloat16, 28), ("Hanabi-Full", 70, 4, torch.float16, 28),
-                                                       ("Hanabi-Full-5p", 37, 4, torch.float32, 70)])
+                                                       ("Hanabi-Full-5p", 37, 4, torch.float32, 70),
+                                                       # (enough envs that the slot prefix of a late workgroup takes several trips)
+                                                       ("Hanabi-Small", 2501, 1, torch.float16, 9)])
 def test_fused_launches_equal_their_separate_calls(game, N, stack, dtype, moves):
     """The lock-step's tail three ways: (tail) the two launches of include/hz_movetail.h, one wave per env from the root read-out
     to the next move's window; (fused) one launch per phase with the fusions of r01 (hz_actor_begin_move_draw; hz_env_reset_rows
