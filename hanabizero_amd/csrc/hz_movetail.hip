@@ -44,7 +44,7 @@ struct TailA {
   int32_t* status;
   int64_t* count_snap;    // [1] OUT: out_count[0] as this lock-step found it (k_move_tail_b's base)
   int mdp;
-  uint64_t seed;          // the NEXT move's draws (hz_actor_draw), made by the partner waves meanwhile
+  uint64_t seed;          // the NEXT move's draws (hz_actor_draw), made in this launch while the wave's own loads are in flight
   long long* move_count;
   double alpha;
   float* noise;           // [N][A] OUT
