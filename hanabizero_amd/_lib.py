@@ -101,6 +101,7 @@ def _load():
                                C.c_double, V, V, V],
         # include/hz_mlp.h
         "hz_mlp_recurrent": [C.POINTER(MlpHeader), V, V, V, V, V, I64, V, I64, V, V, V, V, V, I, I, V],
+        "hz_mlp_recurrent_res": [C.POINTER(MlpHeader), V, V, V, V, V, I64, V, I64, V, V, V, V, V, I, I, V, I64, V],
         # include/hz_search.h
         "hz_search_run": [V, I, C.POINTER(MlpHeader), V, V, V, V, V, I64, I64, V, V, V, V, V, V, I, V],
         "hz_search_poll_giveups": [C.POINTER(C.c_uint)],

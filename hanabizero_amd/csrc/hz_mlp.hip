@@ -21,10 +21,12 @@ __global__ __launch_bounds__(64 * NW, 1) void k_mlp_recurrent(
     const float* __restrict__ bias, const float* __restrict__ act_tab, const uint16_t* __restrict__ state_src,
     long long state_row_stride, const int32_t* __restrict__ plane_index, long long plane_stride,
     const int32_t* __restrict__ actions, uint16_t* __restrict__ hidden_out, float* __restrict__ out_reward,
-    float* __restrict__ out_value, float* __restrict__ out_policy, int n_rows) {
+    float* __restrict__ out_value, float* __restrict__ out_policy, int n_rows, const uint16_t* __restrict__ state_res,
+    long long state_res_stride) {
   extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
   mlp_body<EL, RT, NW, NT>(H, jobs, wstream, bias, act_tab, state_src, state_row_stride, plane_index, plane_stride, actions,
-                       hidden_out, out_reward, out_value, out_policy, n_rows, lds, (int)blockIdx.x * 16 * RT, nullptr);
+                       hidden_out, out_reward, out_value, out_policy, n_rows, lds, (int)blockIdx.x * 16 * RT, nullptr, nullptr,
+                       state_res, state_res_stride);
 }
 
 // The 16 waves x 2 tiles shape runs the hand-scheduled k-loop of hz_mlp_dev.h, whose weight ring lives in registers the
@@ -35,10 +37,12 @@ __global__ __launch_bounds__(1024, 1) __attribute__((amdgpu_num_vgpr(HZ_ASMK_VGP
     const float* __restrict__ bias, const float* __restrict__ act_tab, const uint16_t* __restrict__ state_src,
     long long state_row_stride, const int32_t* __restrict__ plane_index, long long plane_stride,
     const int32_t* __restrict__ actions, uint16_t* __restrict__ hidden_out, float* __restrict__ out_reward,
-    float* __restrict__ out_value, float* __restrict__ out_policy, int n_rows) {
+    float* __restrict__ out_value, float* __restrict__ out_policy, int n_rows, const uint16_t* __restrict__ state_res,
+    long long state_res_stride) {
   extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
   mlp_body<EL, RT, 16, 2>(H, jobs, wstream, bias, act_tab, state_src, state_row_stride, plane_index, plane_stride, actions,
-                          hidden_out, out_reward, out_value, out_policy, n_rows, lds, (int)blockIdx.x * 16 * RT, nullptr);
+                          hidden_out, out_reward, out_value, out_policy, n_rows, lds, (int)blockIdx.x * 16 * RT, nullptr, nullptr,
+                          state_res, state_res_stride);
 }
 
 extern "C" int hz_search_poll_giveups(unsigned int* count);
@@ -65,10 +69,22 @@ extern "C" int hz_mlp_recurrent(const hz_mlp_header_t* H, const hz_mlp_job_t* jo
                                 int64_t row_stride, const int32_t* plane_index, int64_t plane_stride,
                                 const int32_t* actions, void* hidden_out, float* out_reward, float* out_value,
                                 float* out_policy, int num_rows, int rows_per_wg, void* stream) {
+  return hz_mlp_recurrent_res(H, jobs, wstream, biases, action_table, state_src, row_stride, plane_index, plane_stride, actions,
+                              hidden_out, out_reward, out_value, out_policy, num_rows, rows_per_wg, nullptr, 0, stream);
+}
+
+extern "C" int hz_mlp_recurrent_res(const hz_mlp_header_t* H, const hz_mlp_job_t* jobs, const void* wstream,
+                                    const float* biases, const float* action_table, const void* state_src,
+                                    int64_t row_stride, const int32_t* plane_index, int64_t plane_stride,
+                                    const int32_t* actions, void* hidden_out, float* out_reward, float* out_value,
+                                    float* out_policy, int num_rows, int rows_per_wg, const void* state_res,
+                                    int64_t res_stride, void* stream) {
   HZ_REQUIRE(H && jobs && wstream && biases && action_table && state_src && actions && hidden_out && out_reward &&
                  out_value && out_policy,
              "hz_mlp_recurrent: NULL argument");
   HZ_REQUIRE(num_rows > 0, "hz_mlp_recurrent: num_rows must be > 0");
+  HZ_REQUIRE(state_res == nullptr || (plane_index == nullptr && res_stride % 8 == 0 && res_stride >= H->in_width && ((uintptr_t)state_res % 16) == 0),
+             "hz_mlp_recurrent_res: the residual rows go with ungathered input rows, 16-B aligned, stride a multiple of 8 elements");
   HZ_REQUIRE(rows_per_wg == 16 || rows_per_wg == 32, "hz_mlp_recurrent: rows_per_wg must be 16 or 32");
   HZ_REQUIRE(H->n_jobs > 0 && H->n_jobs <= 32, "hz_mlp_recurrent: bad job count %d", H->n_jobs);
   HZ_REQUIRE(H->dtype == HZ_BF16 || H->dtype == HZ_F16, "hz_mlp_recurrent: header dtype must be HZ_BF16 or HZ_F16 (got %d)", H->dtype);
@@ -113,7 +129,7 @@ extern "C" int hz_mlp_recurrent(const hz_mlp_header_t* H, const hz_mlp_job_t* jo
     hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(64 * NW), lds_bytes, (hipStream_t)stream,                            \
                        *H, jobs, (const uint16_t*)wstream, biases, action_table, (const uint16_t*)state_src,         \
                        (long long)row_stride, plane_index, (long long)plane_stride, actions, (uint16_t*)hidden_out,  \
-                       out_reward, out_value, out_policy, num_rows);                                                 \
+                       out_reward, out_value, out_policy, num_rows, (const uint16_t*)state_res, (long long)res_stride); \
   } while (0)
 #define HZ_LAUNCH(RT, NW, NT)                           \
   do {                                                  \

@@ -3,6 +3,7 @@
 // activations: ElBf16 (v_mfma_f32_16x16x32_bf16) or ElF16 (v_mfma_f32_16x16x32_f16 -- the reference's own autocast
 // format, /root/reference/core/mcts.py:38-40); accumulation, bias, residual and ReLU are fp32 in both.
 #pragma once
+#include "hz_addrelu_dev.h"
 #include "hz_common.h"
 #include "hz_mlp.h"
 #include "hz_tree.h"
@@ -243,7 +244,8 @@ __device__ __forceinline__ void mlp_body(
     long long state_row_stride, const int32_t* __restrict__ plane_index, long long plane_stride,
     const int32_t* __restrict__ actions, uint16_t* __restrict__ hidden_out, float* __restrict__ out_reward,
     float* __restrict__ out_value, float* __restrict__ out_policy, int n_rows, uint16_t* lds, int row0,
-    const RowFrag* row_frag, const int* jv_cached = nullptr) {
+    const RowFrag* row_frag, const int* jv_cached = nullptr, const uint16_t* __restrict__ state_res = nullptr,
+    long long state_res_stride = 0) {
   typedef typename EL::v8 v8;
   constexpr int NTHR = 64 * NW;
   constexpr bool PRESTAGED = STAGE != STAGE_GATHER;
@@ -329,6 +331,16 @@ __device__ __forceinline__ void mlp_body(
       if (i < n_stage && row < n_rows) {
         const long long plane = base == 0 ? plane0[u] : (plane_index ? (long long)plane_index[row] * plane_stride : 0);
         v[u] = *reinterpret_cast<const uint4*>(state_src + plane + (long long)row * state_row_stride + c * 8);
+        if (state_res != nullptr) {  // the input rows are relu(state_src + state_res): hz_add_relu's arithmetic, applied on the way in
+          const uint4 b = *reinterpret_cast<const uint4*>(state_res + (long long)row * state_res_stride + c * 8);
+          if (EL::code == HZ_BF16) {
+            v[u].x = hz_add_relu_word<HZ_BF16>(v[u].x, b.x); v[u].y = hz_add_relu_word<HZ_BF16>(v[u].y, b.y);
+            v[u].z = hz_add_relu_word<HZ_BF16>(v[u].z, b.z); v[u].w = hz_add_relu_word<HZ_BF16>(v[u].w, b.w);
+          } else {
+            v[u].x = hz_add_relu_word<HZ_F16>(v[u].x, b.x); v[u].y = hz_add_relu_word<HZ_F16>(v[u].y, b.y);
+            v[u].z = hz_add_relu_word<HZ_F16>(v[u].z, b.z); v[u].w = hz_add_relu_word<HZ_F16>(v[u].w, b.w);
+          }
+        }
       }
     }
 #pragma unroll

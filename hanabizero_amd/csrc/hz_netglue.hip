@@ -1,15 +1,6 @@
 // hz_netglue.hip -- residual-add + ReLU between the dynamics/prediction GEMMs (gfx950); HBM-bound elementwise.
-#include "hz_common.h"
+#include "hz_addrelu_dev.h"
 #include "hz_netglue.h"
-#include "hz_tree.h"
-
-__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
-__device__ __forceinline__ uint16_t f32_to_bf16(float f) {  // round to nearest even; inputs here are finite sums
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);  // NaN stays NaN
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
-}
 
 template <int DTYPE>
 __global__ __launch_bounds__(256) void k_add_relu_vec(uint4* __restrict__ y, long long ys16, const uint4* __restrict__ r,
@@ -23,26 +14,7 @@ __global__ __launch_bounds__(256) void k_add_relu_vec(uint4* __restrict__ y, lon
     uint32_t* pa = reinterpret_cast<uint32_t*>(&a);
     const uint32_t* pb = reinterpret_cast<const uint32_t*>(&b);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (DTYPE == HZ_F32) {
-        const float v = __uint_as_float(pa[k]) + __uint_as_float(pb[k]);
-        pa[k] = __float_as_uint(v > 0.0f ? v : (v != v ? v : 0.0f));
-      } else if (DTYPE == HZ_BF16) {
-        const float lo = bf16_to_f32((uint16_t)(pa[k] & 0xffffu)) + bf16_to_f32((uint16_t)(pb[k] & 0xffffu));
-        const float hi = bf16_to_f32((uint16_t)(pa[k] >> 16)) + bf16_to_f32((uint16_t)(pb[k] >> 16));
-        const uint16_t l = f32_to_bf16(lo > 0.0f ? lo : (lo != lo ? lo : 0.0f));
-        const uint16_t h = f32_to_bf16(hi > 0.0f ? hi : (hi != hi ? hi : 0.0f));
-        pa[k] = (uint32_t)l | ((uint32_t)h << 16);
-      } else {
-        const uint16_t al = (uint16_t)(pa[k] & 0xffffu), ah = (uint16_t)(pa[k] >> 16);
-        const uint16_t bl = (uint16_t)(pb[k] & 0xffffu), bh = (uint16_t)(pb[k] >> 16);
-        _Float16 lo = *reinterpret_cast<const _Float16*>(&al) + *reinterpret_cast<const _Float16*>(&bl);
-        _Float16 hi = *reinterpret_cast<const _Float16*>(&ah) + *reinterpret_cast<const _Float16*>(&bh);
-        if (!(lo > (_Float16)0) && lo == lo) lo = (_Float16)0;
-        if (!(hi > (_Float16)0) && hi == hi) hi = (_Float16)0;
-        pa[k] = (uint32_t)(*reinterpret_cast<uint16_t*>(&lo)) | ((uint32_t)(*reinterpret_cast<uint16_t*>(&hi)) << 16);
-      }
-    }
+    for (int k = 0; k < 4; ++k) pa[k] = hz_add_relu_word<DTYPE>(pa[k], pb[k]);
     y[row * ys16 + c] = a;
   }
 }

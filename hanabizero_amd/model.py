@@ -411,12 +411,12 @@ class InferenceEngine:
             # the two large representation layers as GEMMs, everything after them in one launch of the MFMA kernel
             r, x = self.rep, obs.to(self.dtype)
             x = first(x, relu=True)
-            x = self._add_relu(r[2](r[1](x, relu=True)), x)
+            y = r[2](r[1](x, relu=True))   # (the block's skip -- relu(y + x) -- is added by the tail kernel while it stages its rows)
             N = x.shape[0]
             state = state_out if state_out is not None else torch.empty((N, self.H), dtype=self.dtype, device=x.device)
             value = torch.empty(N, dtype=torch.float32, device=x.device)
             logits = torch.empty((N, self.A), dtype=torch.float32, device=x.device)
-            self.fused_tail(x, state, value, logits)
+            self.fused_tail(y, state, value, logits, residual=x)
             return value, logits, state
         state = self._representation(obs.to(self.dtype), first)
         if state_out is not None:
@@ -738,16 +738,17 @@ class _FusedChain:
         return 16 if N <= 16 * 256 or self.lds_bytes(32) > 160 * 1024 else 32
 
     def _launch(self, state_src, row_stride, ix, plane_stride, actions, hidden_out, out_reward, out_value, out_policy, N,
-                rows_per_wg=None):
+                rows_per_wg=None, residual=None):
         import ctypes as C
         from ._lib import check, lib
         mt = rows_per_wg or self.rows_per_wg(N)
-        check(lib.hz_mlp_recurrent(C.byref(self.header), self.jobs.data_ptr(), self.weights.data_ptr(),
-                                   self.biases.data_ptr(), self.act_table.data_ptr(), state_src.data_ptr(), row_stride,
-                                   None if ix is None else ix.data_ptr(), plane_stride, actions.data_ptr(),
-                                   hidden_out.data_ptr(), out_reward.data_ptr(), out_value.data_ptr(),
-                                   out_policy.data_ptr(), N, mt, C.c_void_p(torch.cuda.current_stream().cuda_stream)),
-              "hz_mlp_recurrent")
+        check(lib.hz_mlp_recurrent_res(C.byref(self.header), self.jobs.data_ptr(), self.weights.data_ptr(),
+                                       self.biases.data_ptr(), self.act_table.data_ptr(), state_src.data_ptr(), row_stride,
+                                       None if ix is None else ix.data_ptr(), plane_stride, actions.data_ptr(),
+                                       hidden_out.data_ptr(), out_reward.data_ptr(), out_value.data_ptr(),
+                                       out_policy.data_ptr(), N, mt, None if residual is None else residual.data_ptr(),
+                                       0 if residual is None else residual.stride(0),
+                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)), "hz_mlp_recurrent_res")
 
 
 class FusedRecurrent(_FusedChain):
@@ -887,13 +888,16 @@ class FusedInitialTail(_FusedChain):
         self._finish(width, in_width=IN, hidden=H, state_off=0, hidden_off=S, off_r=V3, off_v=V3, off_p=Z)
         self._zeros = None
 
-    def __call__(self, x, hidden_out, out_value, out_policy, rows_per_wg=None):
+    def __call__(self, x, hidden_out, out_value, out_policy, rows_per_wg=None, residual=None):
+        """residual: the chain's input rows are relu(x + residual) (the skip of the representation net's first residual block,
+        added while the rows are staged: include/hz_mlp.h::hz_mlp_recurrent_res)."""
         N = x.shape[0]
         assert x.dtype == self.engine.dtype and x.shape[1] == self.in_width and x.stride(1) == 1
+        assert residual is None or (residual.dtype == x.dtype and residual.shape == x.shape and residual.stride(1) == 1)
         if self._zeros is None or self._zeros[0].shape[0] < N:
             self._zeros = (torch.zeros(N, dtype=torch.int32, device=x.device), torch.empty(N, dtype=torch.float32, device=x.device))
         actions, dummy = self._zeros
-        self._launch(x, x.stride(0), None, 0, actions, hidden_out, dummy, out_value, out_policy, N, rows_per_wg)
+        self._launch(x, x.stride(0), None, 0, actions, hidden_out, dummy, out_value, out_policy, N, rows_per_wg, residual=residual)
         return out_value, out_policy
 
 

@@ -130,6 +130,16 @@ int hz_mlp_recurrent(const hz_mlp_header_t* host_header, const hz_mlp_job_t* job
                      float* out_reward, float* out_value, float* out_policy, int num_rows, int rows_per_wg,
                      void* stream);
 
+/* The same with input rows relu(state_src[i] + state_res[i]) (state_res: [N] rows of res_stride elements in the header's dtype;
+ * plane_index must be NULL): the residual-add + ReLU in front of the chain (hz_add_relu's arithmetic, include/hz_netglue.h)
+ * applied while the rows are staged, instead of a launch of its own -- the tail of the root inference takes the output of the
+ * representation net's first residual block this way (config/hanabi_control/model.py:43-57, 240-248). */
+int hz_mlp_recurrent_res(const hz_mlp_header_t* host_header, const hz_mlp_job_t* jobs, const void* wstream,
+                         const float* biases, const float* action_table, const void* state_src, int64_t row_stride,
+                         const int32_t* plane_index, int64_t plane_stride, const int32_t* actions, void* hidden_out,
+                         float* out_reward, float* out_value, float* out_policy, int num_rows, int rows_per_wg,
+                         const void* state_res, int64_t res_stride, void* stream);
+
 /* Waits on arrival counters (HZ_MLP_BLOCKWISE / HZ_MLP_WAITS) that gave up -- after 2^16 looks, about 70 ms -- since the
  * library was loaded, summed over hz_mlp_recurrent and hz_search_run launches on the current device (synchronises with it).  Must be 0: a
  * wave that gave up went on with inputs that may not have been there.  (bench.py prints it; the GPU tests assert it.) */
