@@ -29,6 +29,7 @@ struct SearchArgs {
   float* pol;
   int sims;                // simulations to run (S - 1, as the reference)
   int ptab;                // 1: the launch reserved hz_ptab_words(S) floats of LDS behind the other arrays for SearchLds::ptab
+  int nextact;             // 1: ... and behind that [16][64] words (k_search: the nodes' last selections, hz_tree_replay_dev.h)
 };
 
 // (The phases must be inlined into the kernel: through a real call the compiler loses the address space of every
@@ -44,6 +45,7 @@ struct SearchLds {
   uint16_t* image;  // [16][row_stride]
   float4* prec_s;   // [16][S+1]  the last descent's records, per tree
   int32_t* path_s;  // [16][S+1]  the last descent's path, per tree
+  int32_t* nextact_s;  // [16][64] or null: TreeLocal::nextact
   float* lds_q;     // [16][S]    q cache, per tree, for the whole search
   int32_t* act_s;   // [16]
   uint64_t* exp_s;  // [32] hz_exp2f_tab
@@ -82,7 +84,7 @@ __device__ __forceinline__ RowFrag search_first_descent(const TreeView& tv, cons
   return search_request_row(tv, H, a, entry, tree, lane);
 }
 
-template <class EL>
+template <class EL, bool REPLAY>
 __device__ __forceinline__ RowFrag search_backup_descent(const TreeView& tv, const hz_mlp_header_t& H, const SearchArgs& a,
                                                          const SearchLds& L, int row0, int tree, int lane, int srow, int sim,
                                                          bool more, TreeLocal& tl, float4& root_row) {
@@ -122,7 +124,7 @@ __device__ __forceinline__ RowFrag search_backup_descent(const TreeView& tv, con
     int entry;
     TP(5);
     tl.publish = sim + 2 == a.sims;  // the last descent
-    traverse_body<true>(tv, tree, lane, sim + 1, mn, mx, rv, to, true, root_row, &entry, &tl);
+    traverse_body<true, REPLAY>(tv, tree, lane, sim + 1, mn, mx, rv, to, true, root_row, &entry, &tl);
     TP(13);
     f = search_request_row(tv, H, a, entry, tree, lane);
   }
@@ -167,6 +169,8 @@ __device__ __forceinline__ void search_kernel_body(const TreeView& tv, const hz_
   L.lds_q = reinterpret_cast<float*>(L.path_s + MT * (tv.S + 1));
   L.act_s = reinterpret_cast<int32_t*>(L.lds_q + MT * tv.S);
   L.ptab = (a.ptab && tv.S < 64) ? reinterpret_cast<float*>(L.act_s + MT + 2) + 128 : nullptr;  // (behind the half kernels' tab_s)
+  L.nextact_s = (RT == 1 && a.nextact && L.ptab != nullptr) ? reinterpret_cast<int32_t*>(L.ptab + hz_ptab_words(tv.S)) : nullptr;
+  if (L.nextact_s != nullptr) L.nextact_s[threadIdx.x] = 0;
   if (threadIdx.x < 32) L.exp_s[threadIdx.x] = hz_exp2f_tab[threadIdx.x];
   if (L.ptab != nullptr) hz_ptab_fill(L.ptab, tv.pbc_tab, tv.S, (int)threadIdx.x, 1024);
   TreeLocal tl[RT];
@@ -183,8 +187,9 @@ __device__ __forceinline__ void search_kernel_body(const TreeView& tv, const hz_
     tl[s].pbc_reg = (tv.S < 64 && lane <= tv.S) ? tv.pbc_tab[lane] : 0.0f;
     tl[s].sqrt_reg = sqrtf((float)lane + 1.0f);
     tl[s].path = L.path_s + srow * (tv.S + 1);
+    tl[s].nextact = L.nextact_s != nullptr ? L.nextact_s + srow * 64 : nullptr;
     tl[s].prec = L.prec_s + srow * (tv.S + 1);
-    tl[s].root_vsum = 0.0f; tl[s].root_visit = 0; tl[s].path_len = 0; tl[s].publish = false;
+    tl[s].root_vsum = 0.0f; tl[s].root_visit = 0; tl[s].path_len = 0; tl[s].deep = false; tl[s].publish = false;
     rows[s].v[0] = rows[s].v[1] = make_uint4(0u, 0u, 0u, 0u);
     root_row[s] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
@@ -216,7 +221,7 @@ __device__ __forceinline__ void search_kernel_body(const TreeView& tv, const hz_
 #pragma unroll
     for (int s = 0; s < RT; ++s)
       if (mine[s])
-        rows[s] = search_backup_descent<EL>(tv, H, a, L, row0, row0 + 16 * s + wave, lane_t, 16 * s + wave, sim, sim + 1 < a.sims,
+        rows[s] = search_backup_descent<EL, RT == 1>(tv, H, a, L, row0, row0 + 16 * s + wave, lane_t, 16 * s + wave, sim, sim + 1 < a.sims,
                                         tl[s], root_row[s]);
     p_tree += t1 - t0; p_wait1 += t2 - t1; p_mlp += t3 - t2; p_wait2 += t4 - t3;
     t0 = t4;
@@ -434,6 +439,9 @@ extern "C" int hz_search_run(hz_tree_t* t, int num_simulations, const hz_mlp_hea
   const size_t ptab_bytes = (size_t)(t->S + 1) * (t->S + 2) / 2 * sizeof(float);
   const bool use_ptab = t->S < 64 && lds_bytes + ptab_bytes <= 160 * 1024;
   if (use_ptab) lds_bytes += ptab_bytes;
+  const size_t nextact_bytes = (size_t)16 * 64 * sizeof(int32_t);
+  const bool use_nextact = use_ptab && rows_wg == 16 && rows_per_workgroup != -16 && lds_bytes + nextact_bytes <= 160 * 1024;
+  if (use_nextact) lds_bytes += nextact_bytes;
   // two trees per tree-owning wave, side by side: the default with 32 trees per workgroup; with 16 only on request (-16) --
   // measured at 4096 envs: +1.4 % moves/s with random-init nets (mean path 2.2 edges), -12 % with a sharp policy (5.3 edges: a
   // half that has reached its leaf idles through the other's remaining levels)
@@ -443,6 +451,7 @@ extern "C" int hz_search_run(hz_tree_t* t, int num_simulations, const hz_mlp_hea
   a.pool = (uint16_t*)pool; a.plane_stride = plane_stride; a.row_stride = row_stride;
   a.ix = ix; a.iy = iy; a.la = la; a.rew = rewards; a.val = values; a.pol = policy; a.sims = num_simulations;
   a.ptab = use_ptab ? 1 : 0;
+  a.nextact = use_nextact ? 1 : 0;
 #define HZ_SEARCH_LAUNCH(VARIANT, KERNEL, GRID)                                                                       \
   do {                                                                                                                \
     if (lds_bytes > dev.configured[VARIANT]) {                                                                        \

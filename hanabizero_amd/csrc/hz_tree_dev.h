@@ -93,6 +93,12 @@ struct TraverseOut {
   int tree0;  // row of net_in that tree `tree0` owns is row 0 (0 for the whole-batch buffer)
 };
 
+#ifndef HZ_TREE_REPLAY
+#define HZ_TREE_REPLAY 1
+#endif
+#ifndef HZ_TREE_REPLAY_MIN  // levels of a descent from which on the tree's descents look for predicted lines
+#define HZ_TREE_REPLAY_MIN 6
+#endif
 // one descent of one tree by one wave; mn / mx / root_visit are passed in registers so that the fused
 // backup+descent kernel does not have to re-read what it has just computed
 // Diagnostic build only (-DHZ_TREE_PROFILE, tools/tree_profile.py): s_memtime stamps of the wave that owns tree 400.
@@ -104,9 +110,62 @@ extern "C" int hz_tree_profile_read(unsigned long long* host) {
 }
 #define TP(i) do { if (tree == 400 && lane == 0 && hz_tree_prof_on) hz_tree_prof[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #define TP_ON(v) do { if (tree == 400 && lane == 0) hz_tree_prof_on = (v); } while (0)
+// sums over every level of every descent of the wave that owns tree HZ_TREE_PROFILE_TREE, or (HZ_TREE_PROFILE_TREE < 0) of
+// trees 17, 81, 145, ... in slots tree / 64 (tools/level_profile.py): fields 0..7 = the segments of a level between the TPL
+// stamps, 8 = levels, 9 / 10 = cycles / levels of whole descents at least HZ_TREE_PROFILE_MINDEPTH levels long
+#ifndef HZ_TREE_PROFILE_TREE
+#define HZ_TREE_PROFILE_TREE 400
+#endif
+#ifndef HZ_TREE_PROFILE_MINDEPTH
+#define HZ_TREE_PROFILE_MINDEPTH 0
+#endif
+__device__ unsigned long long hz_tree_lvl[64 * 32];
+extern "C" int hz_tree_level_profile_read(unsigned long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(hz_tree_lvl), sizeof(hz_tree_lvl));
+}
+#define TPL_DECL unsigned long long tpl_prev = __builtin_amdgcn_s_memtime(), tpl_acc[9] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull}; \
+                 const unsigned long long tpl_t0 = tpl_prev
+#define TPL_WAIT asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+// (i: segment that ends here; at_depth: the level it belongs to)
+#define TPL(i, at_depth) do { const unsigned long long tpl_now = __builtin_amdgcn_s_memtime();                         \
+                    if ((at_depth) >= HZ_TREE_PROFILE_MINDEPTH) tpl_acc[(i)] += ((i) == 8) ? 1ull : tpl_now - tpl_prev;  \
+                    tpl_prev = __builtin_amdgcn_s_memtime(); } while (0)
+#define TPL_FLUSH do { if ((HZ_TREE_PROFILE_TREE < 0 ? (tree & 63) == 17 && tree < 4096 : tree == HZ_TREE_PROFILE_TREE) && lane == 0) { \
+                         unsigned long long* slot = hz_tree_lvl + 32 * (HZ_TREE_PROFILE_TREE < 0 ? tree >> 6 : 0);     \
+                         for (int q = 0; q < 9; ++q) slot[q] += tpl_acc[q];                                             \
+                         if (depth >= HZ_TREE_PROFILE_MINDEPTH && depth >= 2) {                                         \
+                           slot[9] += __builtin_amdgcn_s_memtime() - tpl_t0;                                            \
+                           slot[10] += (unsigned long long)depth; slot[15] += (unsigned long long)tpr_levels; } } } while (0)
+// replays (hz_tree_replay_dev.h): fields 11 = replays, 12 = levels they covered, 13 = their cycles, 14 = descents
+#define TPR_T0 const unsigned long long tpr_t0 = __builtin_amdgcn_s_memtime()
+#define TPR_LEVELS_DECL int tpr_levels = 0
+#define TPR_LEVELS(n) tpr_levels = (n)
+#define TPR(levels) do { if ((HZ_TREE_PROFILE_TREE < 0 ? (tree & 63) == 17 && tree < 4096 : tree == HZ_TREE_PROFILE_TREE) && lane == 0) { \
+                      unsigned long long* slot = hz_tree_lvl + 32 * (HZ_TREE_PROFILE_TREE < 0 ? tree >> 6 : 0);        \
+                      slot[11] += 1; slot[12] += (unsigned long long)(levels);                                          \
+                      slot[13] += __builtin_amdgcn_s_memtime() - tpr_t0; } } while (0)
+// inside a pass (hz_tree_replay_dev.h): fields 16.. = segments between the TPP stamps, 24 = passes
+#define TPP_DECL unsigned long long tpp_prev = __builtin_amdgcn_s_memtime()
+#define TPP(i) do { const unsigned long long tpp_now = __builtin_amdgcn_s_memtime();                                     \
+                    if ((HZ_TREE_PROFILE_TREE < 0 ? (tree & 63) == 17 && tree < 4096 : tree == HZ_TREE_PROFILE_TREE) && lane == 0) \
+                      hz_tree_lvl[32 * (HZ_TREE_PROFILE_TREE < 0 ? tree >> 6 : 0) + 16 + (i)] += ((i) == 8) ? 1ull : tpp_now - tpp_prev; \
+                    tpp_prev = __builtin_amdgcn_s_memtime(); } while (0)
+#define TPR_DESCENT do { if ((HZ_TREE_PROFILE_TREE < 0 ? (tree & 63) == 17 && tree < 4096 : tree == HZ_TREE_PROFILE_TREE) && lane == 0) \
+                      hz_tree_lvl[32 * (HZ_TREE_PROFILE_TREE < 0 ? tree >> 6 : 0) + 14] += 1; } while (0)
 #else
+#define TPR_T0 do { } while (0)
+#define TPP_DECL do { } while (0)
+#define TPP(i) do { } while (0)
+#define TPR_LEVELS_DECL do { } while (0)
+#define TPR_LEVELS(n) do { } while (0)
+#define TPR(levels) do { } while (0)
+#define TPR_DESCENT do { } while (0)
 #define TP(i) do { } while (0)
 #define TP_ON(v) do { } while (0)
+#define TPL_DECL do { } while (0)
+#define TPL_WAIT do { } while (0)
+#define TPL(i, at_depth) do { } while (0)
+#define TPL_FLUSH do { } while (0)
 #endif
 
 // Per-tree search state a persistent kernel keeps on chip from simulation to simulation (hz_search.hip): the last
@@ -114,6 +173,7 @@ extern "C" int hz_tree_profile_read(unsigned long long* host) {
 // bodies read all of it from the tree's arrays in HBM (one launch per phase) and this struct is ignored.
 struct TreeLocal {
   int32_t* path;    // [S+1]  (LDS)
+  int32_t* nextact;   // [64] (LDS) or null: per node its last selection, HZ_NEXTACT (hz_tree_replay_dev.h)
   float4* prec;     // [S+1]  (LDS)
   float root_vsum;  // the root's value_sum / visit_count (also stored to HBM for the read-outs)
   int root_visit;
@@ -127,6 +187,7 @@ struct TreeLocal {
                             // per launch with the very operations the descent would use, so a level reads one word instead of
                             // issuing two lane reads, a conversion, a correctly rounded division and a product
   const uint64_t* exp_tab;  // hz_exp2f_tab in LDS
+  bool deep;                // a descent of this tree has been HZ_TREE_REPLAY_MIN levels long: its descents look for predicted lines
   float leaf_reward, leaf_value;  // the leaf's outputs for the coming backup (uniform), and lane a's policy logit
   float leaf_logit;
 };
@@ -147,6 +208,8 @@ __device__ __forceinline__ void hz_ptab_fill(float* ptab, const float* pbc_tab, 
   }
 }
 
+#include "hz_tree_replay_dev.h"
+
 // Issue priority of the tree phases inside the persistent search kernels.  The four waves of a SIMD share its issue port and
 // the sequencer serves the oldest first: with equal priorities the youngest wave of each SIMD needs 21 k cycles for a tree
 // phase the oldest gets through in 12 k (tools/search_profile.py), and the inference waits for the slowest tree.  Youngest
@@ -166,7 +229,7 @@ __device__ __forceinline__ void hz_tree_phase_prio() {
   }
 }
 
-template <bool LOCAL = false>
+template <bool LOCAL = false, bool REPLAY = false>
 __device__ __forceinline__ void traverse_body(const TreeView& tv, int tree, int lane, int sim, float mn, float mx,
                                               int root_visit, const TraverseOut& to, bool have_root, float4 root_row,
                                               int* out_entry = nullptr, TreeLocal* tl = nullptr) {
@@ -192,9 +255,47 @@ __device__ __forceinline__ void traverse_body(const TreeView& tv, int tree, int 
   // the level's child records: the root's come in registers from the fused backup (have_root), a node's are requested at the
   // end of the level above
   float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (have_root) r = root_row;
-  else if (on) r = rec[lane];
-  while (true) {
+  bool at_leaf = false;
+  // LOCAL: in a tree that has grown deep, the predicted line below a node is walked sixteen levels at a time
+  // (hz_tree_replay_dev.h) wherever one is known; one level at a time from where none is
+  const bool replay = LOCAL && REPLAY && HZ_TREE_REPLAY && A <= 20 && tl->ptab != nullptr && tl->nextact != nullptr && tl->deep;
+  TPR_DESCENT;
+  TPR_LEVELS_DECL;
+  if (__builtin_expect(replay, 0)) {  // ("unlikely": the register allocator then spills here rather than in the ordinary walk's loop)
+    TPR_T0;
+    ReplayIn in;
+    in.A = A; in.S = S; in.tree = tree; in.sim = sim;
+    in.mn = mn; in.mx = mx; in.discount = discount; in.delta_floor = tv.delta;
+    in.seed = tv.seed; in.id_base = tv.id_base;
+    in.rec = rec; in.best_action = tv.best_action + (size_t)tree * S;
+    in.nextact = tl->nextact; in.path = path; in.prec = prec; in.lq = tl->lq; in.ptab = tl->ptab;
+    // the last backup's stores to the records must have landed (the ordinary walk waits for them behind its root level)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    while (true) {
+      const ReplayOut ro = traverse_replay<5>(in, e, depth, parent_q, pvc);
+      e = ro.e;
+      action = ro.action;
+      depth = ro.depth;
+      pvc = ro.pvc;
+      parent_q = ro.parent_q;
+      is_root = false;
+      at_leaf = ro.leaf;
+      if (at_leaf) break;
+      const int na = tl->nextact[e];  // another pass if the node has been passed before and its choice led to an expanded node
+      if (!((na & 0x10000) && ((na >> 8) & 0xff))) break;
+    }
+    TPR(depth);
+    TPR_LEVELS(depth);
+    if (!at_leaf && on) r = rec[(size_t)e * A + lane];
+  } else if (have_root) {
+    r = root_row;
+  } else if (on) {
+    r = rec[lane];
+  }
+  TPL_DECL;
+  while (!at_leaf) {
+    TPL_WAIT;
+    TPL(0, depth);
     const uint32_t w = __float_as_uint(r.w);
     const int visit = (int)(w >> 16);
     const int child = (int)(w & 0xffffu) - 1;
@@ -227,6 +328,7 @@ __device__ __forceinline__ void traverse_body(const TreeView& tv, int tree, int 
     const float mean_q = (root_mean ? total : parent_q + total) / (float)(root_mean ? nvis : nvis + 1);
     is_root = false;
     parent_q = mean_q;
+    TPL(1, depth);
     // cucb_score
     float pb_c;
     if (LOCAL && tl->ptab != nullptr) {
@@ -246,6 +348,7 @@ __device__ __forceinline__ void traverse_body(const TreeView& tv, int tree, int 
     const bool valid = on && (score == score) && (score > HZ_FLOAT_MIN);
     const float M = hz_wave_max(valid ? score : -INFINITY);
     const uint64_t eq = __ballot(valid && score == M);
+    TPL(2, depth);
     action = 0;
     if (eq != 0) {
       const int first = __ffsll((unsigned long long)eq) - 1;
@@ -261,6 +364,7 @@ __device__ __forceinline__ void traverse_body(const TreeView& tv, int tree, int 
       action = __ffsll((unsigned long long)cand) - 1;
     }
     action = hz_uniform(action);
+    TPL(3, depth);
     // LOCAL (persistent search kernel): the backup that ran just before this descent stored child records the next levels may
     // load.  Its stores are waited for HERE -- a level's worth of work after they were issued, so the wait is over before it
     // begins -- and before this level's own store goes out, which nothing below depends on.
@@ -270,16 +374,25 @@ __device__ __forceinline__ void traverse_body(const TreeView& tv, int tree, int 
       path[depth] = (e << 8) | action;
     }
     if (lane == action) prec[depth] = r;  // the record the coming backup updates: saves it a dependent load
+    TPL(4, depth);
     const int child_e = hz_readlane_i(child, action);
     const int child_visit = hz_readlane_i(visit, action);
+    if (LOCAL && REPLAY && HZ_TREE_REPLAY && lane == 0 && tl->nextact != nullptr) tl->nextact[e] = HZ_NEXTACT(child_e, action);
     ++depth;
     TP(5 + (depth < 7 ? depth : 7));
-    if (child_e < 0 || depth >= S) break;  // leaf reached (second clause: defensive bound, never true)
+    if (child_e < 0 || depth >= S) {  // leaf reached (second clause: defensive bound, never true)
+      TPL(5, depth - 1);
+      TPL(8, depth - 1);
+      break;
+    }
     e = child_e;
     pvc = child_visit;
     r = make_float4(0.f, 0.f, 0.f, 0.f);
     if (on) r = rec[(size_t)e * A + lane];
+    TPL(5, depth - 1);
+    TPL(8, depth - 1);
   }
+  TPL_FLUSH;
   if (lane == 0) {
     to.la[tree] = action;
     if (!LOCAL || tl->publish) {
@@ -289,6 +402,7 @@ __device__ __forceinline__ void traverse_body(const TreeView& tv, int tree, int 
     }
   }
   if (LOCAL) tl->path_len = depth + 1;
+  if (LOCAL && REPLAY) tl->deep = tl->deep || depth >= HZ_TREE_REPLAY_MIN;
   if (out_entry) *out_entry = e;
   if (to.pool != nullptr) {
     // hidden_states[i] = hidden_state_pool[ix][iy]  (core/mcts.py:31-32), 16 B per lane per trip
@@ -466,6 +580,7 @@ __device__ __forceinline__ void backprop_body(const TreeView& tv, int tree, int 
       r.z = leaf_reward;
       child = e_new;
       if (!LOCAL) tv.ref[(size_t)tree * S + e_new] = pr;
+      if (LOCAL && tl->nextact != nullptr) tl->nextact[pr >> 8] = HZ_NEXTACT(e_new, pr & 255);  // (the edge now leads to an entry)
     }
     // the backup chain, deepest node first: value_sum += G; G = reward + discount * G   (cnode.cpp:320-331)
     float myG = 0.0f;

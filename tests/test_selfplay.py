@@ -18,13 +18,20 @@ def make(game, N, sims, stack, dtype, use_graph, seed=3, peaked=False, fused_tai
     cfg = make_config(game, simulations=sims, stack=stack, p_mcts_num=N)
     net = cfg.get_uniform_network()
     net.load_state_dict({k: torch.from_numpy(v) for k, v in fill_state_dict(net.state_dict()).items()})
-    if peaked:  # a policy head that all but always proposes one action and constant values / rewards: every simulation
+    if peaked is True:  # a policy head that all but always proposes one action and constant values / rewards: every simulation
         with torch.no_grad():  # extends one chain (deep paths)
             net._prediction_actor[-1].weight.zero_()   # (the same logits at every node)
             net._prediction_actor[-1].bias[5] += 40.0  # (play card 0: legal in every position)
             for head in (net._prediction_value, net._dynamics_reward):
                 head[-1].weight.zero_()
                 head[-1].bias.zero_()
+    if peaked == "sharp":  # a concentrated policy that still depends on the state (bench.py's deep_paths net): long paths that
+        with torch.no_grad():  # repeat from one simulation to the next and now and then branch off -- replays that end early
+            for head in (net._prediction_value, net._dynamics_reward, net._prediction_actor):
+                head[-1].weight.normal_(0, 0.1, generator=torch.Generator().manual_seed(1))
+                head[-1].bias.normal_(0, 0.1, generator=torch.Generator().manual_seed(2))
+            net._prediction_actor[-1].weight.mul_(40.0)
+            net._prediction_actor[-1].bias.mul_(40.0)
     net.eval()
     eng = InferenceEngine(net, cfg.value_support.max, dtype=dtype, device="cuda")
     return cfg, eng, SelfPlayActor(cfg, eng, N, seed=seed, use_graph=use_graph, fused_tail=fused_tail)
@@ -218,7 +225,8 @@ def test_select_action_kernel_edge_cases():
     ("Hanabi-Full", 1000, 20, False, torch.bfloat16), ("Hanabi-Full-5p", 70, 30, False, torch.bfloat16),
     ("Hanabi-Full", 4170, 8, False, torch.bfloat16), ("Hanabi-Full", 45, 50, True, torch.bfloat16),
     ("Hanabi-Small", 100, 12, False, torch.float16), ("Hanabi-Full", 1000, 20, False, torch.float16),
-    ("Hanabi-Full-5p", 70, 30, False, torch.float16), ("Hanabi-Full", 45, 50, True, torch.float16)])
+    ("Hanabi-Full-5p", 70, 30, False, torch.float16), ("Hanabi-Full", 45, 50, True, torch.float16),
+    ("Hanabi-Full", 700, 50, "sharp", torch.bfloat16), ("Hanabi-Full", 700, 50, "sharp", torch.float16)])
 def test_persistent_search_kernel_equals_launch_per_phase(game, N, sims, peaked, dtype):
     """hz_search_run (all simulations in one persistent kernel, a workgroup per 16 trees) against the launch-per-phase
     search (hz_tree_traverse -> hz_mlp_recurrent -> hz_tree_backprop_traverse ...): bit-identical trees, hidden-state
@@ -240,7 +248,7 @@ def test_persistent_search_kernel_equals_launch_per_phase(game, N, sims, peaked,
     # the library's own choice (32 once the trees outnumber 16 per compute unit: the last case)
     for persistent in (False, 16, -16, 32, -32, "auto"):
         roots = cytree.Roots(N, A, sims, tie_seed=5, tree_id_base=17)
-        roots.prepare(0.0 if peaked else cfg.root_exploration_fraction, noise, torch.zeros(N, device="cuda"), logits0, actor.legal)
+        roots.prepare(0.0 if peaked is True else cfg.root_exploration_fraction, noise, torch.zeros(N, device="cuda"), logits0, actor.legal)
         pool = torch.zeros(sims, N, eng.H, dtype=eng.dtype, device="cuda")
         MCTS(cfg, persistent=bool(persistent), rows_per_workgroup=0 if persistent in (False, "auto") else int(persistent)
              ).run_multi(roots, eng, hidden0, pool=pool)
@@ -254,7 +262,9 @@ def test_persistent_search_kernel_equals_launch_per_phase(game, N, sims, peaked,
         assert torch.equal(a[5].view(torch.int16), b[5].view(torch.int16))  # (bit patterns: a 49-deep fp16 chain of random nets overflows to inf / NaN)
     assert int(a[0].sum()) == N * (sims - 1)
     assert poll_giveups() == giveups_before, "a wave gave up waiting for an arrival counter (include/hz_mlp.h)"
-    if peaked and dtype == torch.bfloat16:  # paths longer than the 32 lanes a tree has in the side-by-side kernel: its backup
+    if peaked == "sharp":  # (the 16-tree kernel walks long repeated paths sixteen levels at a time: hz_tree_replay_dev.h)
+        assert int(a[4].max()) > 12 and float(a[4].float().mean()) > 4, (int(a[4].max()), float(a[4].float().mean()))
+    if peaked is True and dtype == torch.bfloat16:  # paths longer than the 32 lanes a tree has in the side-by-side kernel: its backup
         assert int(a[4].max()) > 34, int(a[4].max())  # runs in two chunks (in fp16 the 49-deep chain of random nets turns NaN first)
 
 
