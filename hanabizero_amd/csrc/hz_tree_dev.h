@@ -187,7 +187,7 @@ struct TreeLocal {
                             // per launch with the very operations the descent would use, so a level reads one word instead of
                             // issuing two lane reads, a conversion, a correctly rounded division and a product
   const uint64_t* exp_tab;  // hz_exp2f_tab in LDS
-  bool deep;                // a descent of this tree has been HZ_TREE_REPLAY_MIN levels long: its descents look for predicted lines
+  bool deep;                // a descent of this tree has been HZ_TREE_REPLAY_MIN levels long: it keeps `nextact` (non-null then) and its descents look for predicted lines
   float leaf_reward, leaf_value;  // the leaf's outputs for the coming backup (uniform), and lane a's policy logit
   float leaf_logit;
 };
@@ -258,7 +258,7 @@ __device__ __forceinline__ void traverse_body(const TreeView& tv, int tree, int 
   bool at_leaf = false;
   // LOCAL: in a tree that has grown deep, the predicted line below a node is walked sixteen levels at a time
   // (hz_tree_replay_dev.h) wherever one is known; one level at a time from where none is
-  const bool replay = LOCAL && REPLAY && HZ_TREE_REPLAY && A <= 20 && tl->ptab != nullptr && tl->nextact != nullptr && tl->deep;
+  const bool replay = LOCAL && REPLAY && HZ_TREE_REPLAY && A <= 20 && tl->ptab != nullptr && tl->nextact != nullptr && hz_uniform(tl->deep ? 1 : 0) != 0;
   TPR_DESCENT;
   TPR_LEVELS_DECL;
   if (__builtin_expect(replay, 0)) {  // ("unlikely": the register allocator then spills here rather than in the ordinary walk's loop)
@@ -273,15 +273,17 @@ __device__ __forceinline__ void traverse_body(const TreeView& tv, int tree, int 
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     while (true) {
       const ReplayOut ro = traverse_replay<5>(in, e, depth, parent_q, pvc);
-      e = ro.e;
-      action = ro.action;
-      depth = ro.depth;
-      pvc = ro.pvc;
-      parent_q = ro.parent_q;
+      // (said to the compiler in so many words: all of this is wave-uniform -- what it cannot prove it computes per lane,
+      // and the ordinary walk below would inherit that)
+      e = hz_uniform(ro.e);
+      action = hz_uniform(ro.action);
+      depth = hz_uniform(ro.depth);
+      pvc = hz_uniform(ro.pvc);
+      parent_q = __int_as_float(hz_uniform(__float_as_int(ro.parent_q)));
       is_root = false;
-      at_leaf = ro.leaf;
+      at_leaf = hz_uniform(ro.leaf ? 1 : 0) != 0;
       if (at_leaf) break;
-      const int na = tl->nextact[e];  // another pass if the node has been passed before and its choice led to an expanded node
+      const int na = hz_uniform(tl->nextact[e]);  // another pass if the node has been passed before and its choice led to an expanded node
       if (!((na & 0x10000) && ((na >> 8) & 0xff))) break;
     }
     TPR(depth);
@@ -377,7 +379,7 @@ __device__ __forceinline__ void traverse_body(const TreeView& tv, int tree, int 
     TPL(4, depth);
     const int child_e = hz_readlane_i(child, action);
     const int child_visit = hz_readlane_i(visit, action);
-    if (LOCAL && REPLAY && HZ_TREE_REPLAY && lane == 0 && tl->nextact != nullptr) tl->nextact[e] = HZ_NEXTACT(child_e, action);
+    if (LOCAL && REPLAY && HZ_TREE_REPLAY && replay && lane == 0) tl->nextact[e] = HZ_NEXTACT(child_e, action);  // (a deep tree's table)
     ++depth;
     TP(5 + (depth < 7 ? depth : 7));
     if (child_e < 0 || depth >= S) {  // leaf reached (second clause: defensive bound, never true)
@@ -402,7 +404,16 @@ __device__ __forceinline__ void traverse_body(const TreeView& tv, int tree, int 
     }
   }
   if (LOCAL) tl->path_len = depth + 1;
-  if (LOCAL && REPLAY) tl->deep = tl->deep || depth >= HZ_TREE_REPLAY_MIN;
+  if (LOCAL && REPLAY && HZ_TREE_REPLAY && !replay && depth >= HZ_TREE_REPLAY_MIN && A <= 20 && tl->ptab != nullptr && tl->nextact != nullptr) {
+    // the tree has grown deep: from now on its descents keep the table of last choices (the ordinary walk above, the passes,
+    // the backup for the entry it expands) -- which starts as this path: level k's choice led to level k + 1's node, the last
+    // level's edge leads nowhere yet.  Nodes off this path have no entry until they are passed again (a pass stops there).
+    if (lane < depth) {
+      const int here = path[lane], below = lane + 1 < depth ? (path[lane + 1] >> 8) : -1;
+      tl->nextact[here >> 8] = HZ_NEXTACT(below, here & 255);
+    }
+    tl->deep = true;
+  }
   if (out_entry) *out_entry = e;
   if (to.pool != nullptr) {
     // hidden_states[i] = hidden_state_pool[ix][iy]  (core/mcts.py:31-32), 16 B per lane per trip
@@ -580,7 +591,7 @@ __device__ __forceinline__ void backprop_body(const TreeView& tv, int tree, int 
       r.z = leaf_reward;
       child = e_new;
       if (!LOCAL) tv.ref[(size_t)tree * S + e_new] = pr;
-      if (LOCAL && tl->nextact != nullptr) tl->nextact[pr >> 8] = HZ_NEXTACT(e_new, pr & 255);  // (the edge now leads to an entry)
+      if (LOCAL && tl->deep) tl->nextact[pr >> 8] = HZ_NEXTACT(e_new, pr & 255);  // (a deep tree's table: the edge now leads to an entry)
     }
     // the backup chain, deepest node first: value_sum += G; G = reward + discount * G   (cnode.cpp:320-331)
     float myG = 0.0f;
