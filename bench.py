@@ -758,7 +758,8 @@ def main():
         if args.workload == "full4096" and args.net == "random":
             other_dt = "bf16" if args.dtype != "bf16" else "fp16"
             plan = [("full8192", "full8192", args.dtype, "random"), ("full8192_bf16", "full8192", "bf16", "random"),  # configs[2] names bf16
-                    (other_dt, args.workload, other_dt, "random"), ("deep_paths", args.workload, args.dtype, "sharp")]
+                    (other_dt, args.workload, other_dt, "random"), ("deep_paths", args.workload, args.dtype, "sharp"),
+                    ("deep_paths_full8192", "full8192", args.dtype, "sharp")]
             plan = [p for k, p in enumerate(plan) if p[1:] not in [q[1:] for q in plan[:k]]]
         for name, wl, dt, net in plan:
             r = Run(args, wl, dt, device, 0, 1, net=net)

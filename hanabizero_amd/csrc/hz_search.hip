@@ -267,6 +267,10 @@ __global__ __launch_bounds__(1024, 1) __attribute__((amdgpu_num_vgpr(HZ_ASMK_VGP
   float* tab_s = reinterpret_cast<float*>(L.act_s + MT);  // the descent's tables: pb_c's log factor and sqrt(n + 1), n < 64
   L.ptab = (a.ptab && tv.S < 64) ? reinterpret_cast<float*>(L.act_s + MT + 2) + 128 : nullptr;
   if (L.ptab != nullptr) hz_ptab_fill(L.ptab, tv.pbc_tab, tv.S, (int)threadIdx.x, 1024);
+  // [MT][S] 16-bit words behind the table of exploration factors: the nodes' last selections (HalfTree::nextact), all "never passed"
+  uint16_t* nextact16_s = (TW == 16 && a.nextact && L.ptab != nullptr) ? reinterpret_cast<uint16_t*>(L.ptab + hz_ptab_words(tv.S)) : nullptr;
+  if (nextact16_s != nullptr)
+    for (int i = (int)threadIdx.x; i < MT * tv.S; i += 1024) nextact16_s[i] = 0;
   if (threadIdx.x < 32) L.exp_s[threadIdx.x] = hz_exp2f_tab[threadIdx.x];
   if (threadIdx.x < 64) {
     tab_s[threadIdx.x] = (tv.S < 64 && (int)threadIdx.x <= tv.S) ? tv.pbc_tab[threadIdx.x] : 0.0f;
@@ -289,9 +293,10 @@ __global__ __launch_bounds__(1024, 1) __attribute__((amdgpu_num_vgpr(HZ_ASMK_VGP
     t.path = L.path_s + srow * (tv.S + 1);                                                \
     t.prec = L.prec_s + srow * (tv.S + 1);                                                \
     t.lq = L.lds_q + srow * tv.S;                                                         \
+    t.nextact = nextact16_s != nullptr ? nextact16_s + srow * tv.S : nullptr;             \
   }
   HZ_HALF_SETUP(lane)
-  t.root_vsum = 0.0f; t.root_visit = 0; t.path_len = 1;
+  t.root_vsum = 0.0f; t.root_visit = 0; t.path_len = 1; t.deep = false;
   t.leaf_reward = t.leaf_value = t.leaf_logit = 0.0f;
   const bool any_mine = wave < TW && row0 + wave < tv.N;  // (rows are filled in order: the lower half's tree exists if any does)
   if (any_mine) {
@@ -345,8 +350,12 @@ __global__ __launch_bounds__(1024, 1) __attribute__((amdgpu_num_vgpr(HZ_ASMK_VGP
     if (more) {
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
       hz_tree_descent_prio();
-      const int entry = traverse_half(tv, q, t, sim + 1, mn, mx, root_row, tab_s, L.ptab, L.act_s + TW * q.h + wave, a.ix,
-                                      a.iy, sim + 2 == a.sims);
+      int entry;
+      if (TW == 16 && __ballot(t.deep) != 0)
+        entry = traverse_half<2>(tv, q, t, sim + 1, mn, mx, root_row, tab_s, L.ptab, L.act_s + TW * q.h + wave, a.ix, a.iy, sim + 2 == a.sims);
+      else
+        entry = traverse_half<TW == 16 ? 1 : 0>(tv, q, t, sim + 1, mn, mx, root_row, tab_s, L.ptab, L.act_s + TW * q.h + wave, a.ix, a.iy,
+                                                sim + 2 == a.sims);
       if (t.mine) {
         const uint4* src = reinterpret_cast<const uint4*>(a.pool + ((size_t)entry * tv.N + t.tree) * (size_t)H.hidden);
 #pragma unroll
@@ -427,7 +436,7 @@ extern "C" int hz_search_run(hz_tree_t* t, int num_simulations, const hz_mlp_hea
   if (rows_wg == 0) rows_wg = (t->N + 15) / 16 > dev.n_cu ? 32 : 16;
   auto lds_for = [&](int mt) {
     return (size_t)mt * H->row_stride * sizeof(uint16_t) + (size_t)mt * (t->S + 1) * (16 + 4) + (size_t)mt * t->S * sizeof(float) +
-           (size_t)(mt + 2) * sizeof(float) + 32 * 8 + 128 * sizeof(float) + 256;  // (+256: slack behind the last array)
+           (size_t)(mt + 2) * sizeof(float) + 32 * 8 + 128 * sizeof(float) + 128;  // (+128: slack behind the last array)
   };
   if (rows_wg == 32 && lds_for(32) > 160 * 1024 && rows_per_workgroup == 0) rows_wg = 16;
   size_t lds_bytes = lds_for(rows_wg);
@@ -439,8 +448,12 @@ extern "C" int hz_search_run(hz_tree_t* t, int num_simulations, const hz_mlp_hea
   const size_t ptab_bytes = (size_t)(t->S + 1) * (t->S + 2) / 2 * sizeof(float);
   const bool use_ptab = t->S < 64 && lds_bytes + ptab_bytes <= 160 * 1024;
   if (use_ptab) lds_bytes += ptab_bytes;
-  const size_t nextact_bytes = (size_t)16 * 64 * sizeof(int32_t);
-  const bool use_nextact = use_ptab && rows_wg == 16 && rows_per_workgroup != -16 && lds_bytes + nextact_bytes <= 160 * 1024;
+  // the nodes' last selections for the descent along predicted lines (hz_tree_replay_dev.h): [16][64] words in the 16-tree
+  // kernel, [32][S] half-words in the side-by-side 32-tree kernel (which has 3 KB left), where they fit
+  const bool halves_early = ((rows_wg == 32 && rows_per_workgroup != -32) || rows_per_workgroup == -16) && t->A <= 32 && H->hidden <= 512;
+  const size_t nextact_bytes = rows_wg == 16 ? (size_t)16 * 64 * sizeof(int32_t) : (((size_t)32 * t->S * sizeof(uint16_t) + 15) & ~(size_t)15);
+  const bool use_nextact = use_ptab && ((rows_wg == 16 && rows_per_workgroup != -16) || (rows_wg == 32 && halves_early)) &&
+                           lds_bytes + nextact_bytes <= 160 * 1024;
   if (use_nextact) lds_bytes += nextact_bytes;
   // two trees per tree-owning wave, side by side: the default with 32 trees per workgroup; with 16 only on request (-16) --
   // measured at 4096 envs: +1.4 % moves/s with random-init nets (mean path 2.2 edges), -12 % with a sharp policy (5.3 edges: a

@@ -261,7 +261,9 @@ __device__ __forceinline__ void traverse_body(const TreeView& tv, int tree, int 
   const bool replay = LOCAL && REPLAY && HZ_TREE_REPLAY && A <= 20 && tl->ptab != nullptr && tl->nextact != nullptr && hz_uniform(tl->deep ? 1 : 0) != 0;
   TPR_DESCENT;
   TPR_LEVELS_DECL;
-  if (__builtin_expect(replay, 0)) {  // ("unlikely": the register allocator then spills here rather than in the ordinary walk's loop)
+  // ("unlikely": the register allocator then spills here rather than in the ordinary walk's loop.  Two copies of the walk -- one
+  // for trees that have not grown deep, without any of this, as in the side-by-side kernel -- cost MORE here: 1.15 % instead of 0.6 %.)
+  if (__builtin_expect(replay, 0)) {
     TPR_T0;
     ReplayIn in;
     in.A = A; in.S = S; in.tree = tree; in.sim = sim;
