@@ -45,7 +45,7 @@ Command (on the MI355X box, `tools/profile_round.sh %s`): `cd /tmp && export TMP
 (tree built from commit %s: %s).
 
 State: Hanabi-Full 2p, %d envs, 49 simulations per move in ONE launch of the persistent search kernel (%d trees per workgroup); the whole
-lock-step (9 kernels: three hipBLASLt GEMMs + `k_add_relu` + `k_mlp_recurrent16` = the root inference, `k_prepare`, the search kernel,
+lock-step (8 kernels: three hipBLASLt GEMMs + `k_mlp_recurrent16` = the root inference, `k_prepare`, the search kernel,
 `k_move_tail_a`, `k_move_tail_b`) is one hipGraph.  Search-kernel rows: 14 from the timed / warm-up / capture steps, the rest from bench.py's
 roofline pass (6 graphs of 4 back-to-back launches on snapshots of live trees); `k_backprop_traverse`, `k_traverse`, `k_backprop`,
 `k_mlp_recurrent<.., 4, 4>`, the `__amd_rocclr_copyBuffer` rows and 24 of the `k_move_tail_*` rows come ONLY from that pass (snapshots, the
