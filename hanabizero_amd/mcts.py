@@ -52,7 +52,7 @@ class MCTS(object):
                 # (hz_search_run's own limits, mirrored: tree capacity < 64 simulations, <= 16 passes, hidden <= 512, 16 rows of
                 # the image + the 16 trees' search state within 160 KiB -- anything else takes the launch-per-phase search below)
                 if fused16 is not None and S < 64 and fused16.n_jobs <= 16 and H <= 512 and \
-                        fused16.lds_bytes(16) + 16 * ((S + 1) * 20 + S * 4) + (16 + 2) * 4 + 32 * 8 + 128 * 4 + 256 <= 160 * 1024:
+                        fused16.lds_bytes(16) + 16 * ((S + 1) * 20 + S * 4) + (16 + 2) * 4 + 32 * 8 + 128 * 4 + 128 <= 160 * 1024:
                     # the whole loop below as ONE persistent kernel: a workgroup keeps 16 trees for all simulations
                     roots.search_tensors(fused16, pool, S - 1, rew, val, pol, self.rows_per_workgroup)
                     return

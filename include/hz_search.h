@@ -35,6 +35,9 @@ extern "C" {
  *                  hidden <= 512, a wavefront searches its TWO trees side by side in its two 32-lane halves; -32 forces them
  *                  one after the other; -16 = 16 trees per workgroup side by side on 8 of the 16 wavefronts (measured: no
  *                  faster than one per wavefront, slower on deep paths).  The results do not depend on any of it.
+ *                  With num_actions <= 20, where the workgroup's LDS has room for a table of the nodes' last selections, a
+ *                  tree whose descents have grown 6 levels long walks its predicted lines 16 (side by side: 8) levels at a time
+ *                  (csrc/hz_tree_replay_dev.h) -- again the same bits, only sooner when the policy is sharp.
  * The MLP header's dtype (HZ_BF16 / HZ_F16) selects the element format of pool, weights and activations.
  * Limits (HZ_ERR otherwise -- the launch-per-phase calls of hz_tree.h / hz_mlp.h have none of them and compute the same
  * bits): fewer than 64 simulations per tree (t's S; the reference's configs have 50), hidden <= 512, support_size <= 256,
