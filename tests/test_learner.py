@@ -154,6 +154,84 @@ def test_make_batch_targets_follow_the_reference_recipe():
             assert np.allclose(tp[b, j], G_.child_visits[cur])
 
 
+def make_batch_spec(games, positions, config, value_fn, weights=None, rng=None, policy_re=None, obs_dtype=np.float32):
+    """hanabizero_amd.learner.make_batch written the straightforward way (reanalyze_worker.py:148-168, 249-304, 374-399 line by
+    line: a Python loop per unroll step and per reward term) -- the specification the vectorised function is compared with."""
+    rng = rng or np.random
+    U, td, stack, A, g = config.num_unroll_steps, config.td_steps, config.stacked_observations, config.action_space_size, config.discount
+    B = len(games)
+    D = config.obs_shape // stack
+    # (outputs are written in place: the per-sample lists + np.stack of the straightforward version cost more than
+    # everything else in this function)
+    obs_batch = np.empty((B, stack + U, D), obs_dtype)
+    value_obs = np.zeros((B * (U + 1), config.obs_shape), obs_dtype)  # zero_obs past the end of a game
+    value_mask = np.zeros(B * (U + 1), np.float64)
+    action_lst, mask_lst = [], []
+    k = 0
+    for b, (game, pos) in enumerate(zip(games, positions)):
+        acts = [int(a) for a in game.actions[pos:pos + U]]
+        mask = [1.0] * len(acts) + [0.0] * (U - len(acts))
+        acts += [int(rng.randint(0, A)) for _ in range(U - len(acts))]
+        obs_batch[b] = game.obs(pos, extra_len=U, padding=True)
+        action_lst.append(acts)
+        mask_lst.append(mask)
+        traj_len = len(game)
+        game_obs = np.asarray(game.obs(pos + td, U))  # :204-222 bootstrap observations
+        for cur in range(pos, pos + U + 1):
+            if cur + td < traj_len:
+                value_mask[k] = 1.0
+                beg = cur - pos
+                value_obs[k].reshape(stack, D)[:] = game_obs[beg:beg + stack]
+            k += 1
+    values = np.asarray(value_fn(value_obs), dtype=np.float64).reshape(-1) * (g ** td) * value_mask
+    target_value = np.zeros((B, U + 1), np.float32)
+    target_reward = np.zeros((B, U + 1), np.float32)
+    target_policy = np.zeros((B, U + 1, A), np.float32)
+    k = 0
+    for b, (game, pos) in enumerate(zip(games, positions)):
+        traj_len = len(game)
+        for j, cur in enumerate(range(pos, pos + U + 1)):
+            v = values[k]
+            for i, r in enumerate(game.rewards[cur:cur + td]):
+                v += float(r) * g ** i  # (the reference's rewards are Python floats: float64 products, whatever the history stores)
+            if cur < traj_len:
+                target_value[b, j], target_reward[b, j] = v, game.rewards[cur]
+                target_policy[b, j] = game.child_visits[cur]
+            k += 1
+    if policy_re is not None and len(policy_re):
+        target_policy[:len(policy_re)] = policy_re
+    w = np.ones(B, np.float32) if weights is None else np.asarray(weights, np.float32)
+    inputs = (obs_batch, np.asarray(action_lst, np.int64), np.asarray(mask_lst, np.float32), np.arange(B), w, np.zeros(B))
+    return inputs, (target_reward[:, :U + 1], target_value, target_policy)
+
+
+def test_make_batch_equals_its_line_by_line_specification():
+    from hanabizero_amd.config import make_config
+    from hanabizero_amd.game import GameHistory
+    from hanabizero_amd.learner import make_batch
+    cfg = make_config("Hanabi-Small", simulations=10, stack=2, p_mcts_num=8, batch_size=32)
+    A, stack = cfg.action_space_size, cfg.stacked_observations
+    D = cfg.obs_shape // stack
+    rng = np.random.RandomState(5)
+    games = []
+    for T in (3, 7, 12, 30, 31, 9):  # (shorter than td_steps, shorter than the unroll, long)
+        games.append(GameHistory.from_arrays(None, cfg, rng.randint(0, A, T), rng.rand(T).astype(np.float32),
+                                             rng.dirichlet(np.ones(A), T).astype(np.float32), rng.rand(T).astype(np.float32),
+                                             np.ones((T + 1, A), np.uint8), (rng.rand(T + 1, D) < 0.3).astype(np.uint8)))
+    gs = [games[i % len(games)] for i in range(40)]
+    pos = [int(rng.randint(0, len(g))) for g in gs]
+    pos[:6] = [len(g) - 1 for g in gs[:6]]  # the last position of every game
+    value_fn = lambda o: (o.astype(np.float64) * np.arange(1, o.shape[1] + 1)).sum(1) * 1e-3
+    pol_re = rng.dirichlet(np.ones(A), (7, cfg.num_unroll_steps + 1)).astype(np.float32)
+    for dt in (np.float32, np.uint8):
+        for pr in (None, pol_re):
+            a = make_batch(gs, pos, cfg, value_fn, weights=rng.rand(40), rng=np.random.RandomState(1), policy_re=pr, obs_dtype=dt)
+            b = make_batch_spec(gs, pos, cfg, value_fn, weights=a[0][4], rng=np.random.RandomState(1), policy_re=pr, obs_dtype=dt)
+            for x, y in zip(a[0] + a[1], b[0] + b[1]):
+                x, y = np.asarray(x), np.asarray(y)
+                assert x.shape == y.shape and x.dtype == y.dtype and (x == y).all()
+
+
 @pytest.mark.gpu
 def test_bf16_learner_step_on_gpu_and_weights_reach_the_engine():
     from hanabizero_amd.learner import make_optimizer, update_weights
