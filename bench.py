@@ -228,7 +228,8 @@ def kernel_timing(actor, sample_sims=(4, 16, 28, 40), clones=8, replays=5):
             torch.cuda.synchronize()
             per_graph.append(a.elapsed_time(b) * 1e-3 / 4)
             del g0, snaps
-        search = {"mean_s": sum(per_graph) / len(per_graph), "min_s": min(per_graph), "launches": 4 * len(per_graph)}
+        search = {"mean_s": sum(per_graph) / len(per_graph), "min_s": min(per_graph), "launches": 4 * len(per_graph),
+                  "per_graph_us": [round(1e6 * t, 1) for t in per_graph]}
     if sample_sims:
         for sim in range(S - 1):
             sampled = sim in sample_sims
@@ -728,7 +729,7 @@ def main():
             out["roofline"] = {"bound": "mfma", "kernel": "k_search", "achieved": fl / t / 1e12, "peak": MFMA_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": fl / t / 1e12 / MFMA_PEAK_TFLOPS,
                                "traffic": traffic_all.get("k_search"), "traffic_source": traffic_src,
-                               "avg_launch_us": t * 1e6, "min_launch_us": search["min_s"] * 1e6, "launches_timed": search["launches"],
+                               "avg_launch_us": t * 1e6, "min_launch_us": search["min_s"] * 1e6, "launches_timed": search["launches"], "per_graph_us": search["per_graph_us"],
                                "poll_giveups": _poll_giveups(),  # waits on arrival counters that timed out in this process (must be 0)
                                "flop_per_launch": fl, "simulations_per_launch": S - 1, "trees_per_workgroup": rows_wg, "workgroups": wgs,
                                "l2_stream": {"bytes_per_launch": l2_bytes, "achieved_TBps": l2_bytes / t / 1e12, "peak_TBps": L2_PEAK_TBS,
