@@ -175,14 +175,51 @@ def mean_path_edges(actor):
     return float(total) / (S - 1), deepest
 
 
+def search_in_step(actor, steps=32):
+    """Launch duration of the persistent search kernel INSIDE lock-steps: `steps` more moves of the live actor, enqueued
+    kernel by kernel (the captured graph's own sequence: root inference, prepare, search, move tail) with a HIP event on
+    either side of the search launch, on the launch stream.  The stream stays full (the host runs ahead of a 1.9 ms step), so a
+    pair brackets the kernel and nothing else; an empty pair recorded right behind it gives the events' own share (~5 us, reported,
+    not subtracted).  Until r03 this figure came from graphs of four back-to-back launches on snapshots: 8-11 % longer than the
+    same kernel takes between the GEMMs and the move tail of a real step (no kernel before it to rest the clocks, cold trees)."""
+    import torch
+    cfg = actor.cfg
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    pairs, empties = [], []
+    first, last = ev(), ev()
+    warm = 8  # (the first kernel-by-kernel steps of a process that has replayed graphs so far are slow on the HOST: not timed)
+    for k in range(warm + steps):
+        if k == warm:
+            pairs, empties = [], []
+            first.record()
+        if not actor._drawn:
+            actor._draw()
+        value0, logits0, hidden0 = actor.root_inference(state_out=actor.pool[0])
+        actor.roots.prepare(cfg.root_exploration_fraction, actor.noise, actor.zeros_n, logits0, actor.legal)
+        a, b, c, d = ev(), ev(), ev(), ev()
+        a.record()
+        actor.mcts.run_multi(actor.roots, actor.engine, hidden0, pool=actor.pool)
+        b.record()
+        c.record()
+        d.record()
+        actor._tail_part(True)
+        actor.total_moves += actor.N
+        pairs.append((a, b))
+        empties.append((c, d))
+    last.record()
+    torch.cuda.synchronize()
+    t = [a.elapsed_time(b) * 1e-3 for a, b in pairs]
+    e = [c.elapsed_time(d) * 1e-3 for c, d in empties]
+    return {"mean_s": sum(t) / len(t), "min_s": min(t), "launches": len(t), "empty_event_pair_us": 1e6 * sum(e) / len(e),
+            "eager_step_us": 1e3 * first.elapsed_time(last) / steps}
+
+
 def kernel_timing(actor, sample_sims=(4, 16, 28, 40), clones=8, replays=5):
     """Launch durations of the hand-written kernels on LIVE search states, with HIP events on the launch stream.
 
-    k_search (the kernel the product launches once per move): a hipGraph of 4 back-to-back launches, each on its own snapshot
-    (hz_tree_copy) of the freshly prepared trees of a live move -- a finished tree cannot be searched again and no launch sees
-    data the previous one left in cache -- between two events, 6 graphs: the MEAN over all 24 launches and the best graph's
-    mean are both reported.  (An eager launch cannot be timed this way: an empty event pair already reads ~26 us.)
-    The launch-per-phase kernels: the same with `clones` snapshots at each sampled simulation, best of `replays`.
+    k_search (the kernel the product launches once per move): inside further lock-steps of the live actor (search_in_step).
+    The launch-per-phase kernels: hipGraphs of `clones` back-to-back launches on snapshots (hz_tree_copy) at each sampled
+    simulation, between two events, best of `replays` (an eager launch of a 10 us kernel cannot be timed with an event pair).
     Returns ({kernel: seconds per launch}, {k_search statistics}, launches, mean path edges, mean expanded entries)."""
     import torch
     cfg, roots, eng = actor.cfg, actor.roots, actor.engine
@@ -213,23 +250,14 @@ def kernel_timing(actor, sample_sims=(4, 16, 28, 40), clones=8, replays=5):
 
     fused16 = eng.fused_shape(16, 2) if (fused is not None and getattr(actor.mcts, "persistent", False)) else None
     if fused16 is not None:
-        per_graph = []
-        busy = torch.empty(2, 1 << 27, dtype=torch.uint8, device=actor.device)  # (2 x 128 MiB: copies, not MFMA work -- a burst of
-        #                                                                             GEMMs leaves the chip throttled instead)
-        for _ in range(6):
-            snaps = [roots.clone() for _ in range(4)]
-            torch.cuda.synchronize()
-            g0 = timed_graph(lambda: [c.search_tensors(fused16, actor.pool, S - 1, rew, val, pol, actor.mcts.rows_per_workgroup)
-                                      for c in snaps])
-            for _k in range(16):  # (cloning and capturing leave the GPU idle for milliseconds: a launch that meets it on its way up from
-                busy[_k & 1].copy_(busy[1 - (_k & 1)])  # the idle clocks once took 30 ms instead of 2 -- keep it busy up to the first event)
-            a, b = ev(), ev()
-            a.record(); g0.replay(); b.record()
-            torch.cuda.synchronize()
-            per_graph.append(a.elapsed_time(b) * 1e-3 / 4)
-            del g0, snaps
-        search = {"mean_s": sum(per_graph) / len(per_graph), "min_s": min(per_graph), "launches": 4 * len(per_graph),
-                  "per_graph_us": [round(1e6 * t, 1) for t in per_graph]}
+        search = search_in_step(actor)
+        # (the in-step loop has moved the games on: prepare this function's own roots again for what follows)
+        actor._draw()
+        actor._drawn = True
+        value0, logits0, hidden0 = actor.root_inference()
+        roots.prepare(cfg.root_exploration_fraction, actor.noise, actor.zeros_n, logits0, actor.legal)
+        roots.set_params(cfg.pb_c_base, cfg.pb_c_init, cfg.discount, cfg.value_delta_max)
+        actor.pool[0].copy_(hidden0)
     if sample_sims:
         for sim in range(S - 1):
             sampled = sim in sample_sims
@@ -729,7 +757,7 @@ def main():
             out["roofline"] = {"bound": "mfma", "kernel": "k_search", "achieved": fl / t / 1e12, "peak": MFMA_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": fl / t / 1e12 / MFMA_PEAK_TFLOPS,
                                "traffic": traffic_all.get("k_search"), "traffic_source": traffic_src,
-                               "avg_launch_us": t * 1e6, "min_launch_us": search["min_s"] * 1e6, "launches_timed": search["launches"], "per_graph_us": search["per_graph_us"],
+                               "avg_launch_us": t * 1e6, "min_launch_us": search["min_s"] * 1e6, "launches_timed": search["launches"], "empty_event_pair_us": search["empty_event_pair_us"], "eager_step_us": search["eager_step_us"],
                                "poll_giveups": _poll_giveups(),  # waits on arrival counters that timed out in this process (must be 0)
                                "flop_per_launch": fl, "simulations_per_launch": S - 1, "trees_per_workgroup": rows_wg, "workgroups": wgs,
                                "l2_stream": {"bytes_per_launch": l2_bytes, "achieved_TBps": l2_bytes / t / 1e12, "peak_TBps": L2_PEAK_TBS,
@@ -739,7 +767,7 @@ def main():
                                                    "GBps": (b_trav + b_back + 2 * Nk * H * e) * (S - 1) / t / 1e9,
                                                    "frac_of_hbm_peak": (b_trav + b_back + 2 * Nk * H * e) * (S - 1) / t / 1e9 / HBM_PEAK_GBS},
                                "mean_path_edges": dbar, "mean_expanded_entries": sbar,
-                               "method": "HIP events around hipGraph replays of 4 back-to-back launches on independent snapshots of live search states; mean over 6 graphs (avg_launch_us) and the best graph (min_launch_us)",
+                               "method": "a HIP event on either side of the search launch in 32 further lock-steps of the live actor, enqueued kernel by kernel on the launch stream (search_in_step): mean (avg_launch_us) and shortest (min_launch_us); eager_step_us = those lock-steps end to end, to be read against ms_per_step",
                                "other": other}
         elif other:
             dom = max(other, key=lambda k: other[k]["avg_launch_us"])
