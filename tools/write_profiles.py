@@ -38,6 +38,15 @@ def stats(tag, w, commit, note):
     sys.argv = ["summarize_rocprof.py", files[0], js]
     with redirect_stdout(buf):
         summarize_rocprof.main()
+    # the dispatches bench.py's own figure is about: the last 32 launches of the search kernel in the trace (search_in_step's timed ones)
+    tr = glob.glob(os.path.join(os.path.dirname(files[0]), "*kernel_trace.csv"))
+    instep = ""
+    if tr:
+        rows = [r for r in csv.DictReader(open(tr[0])) if "k_search" in r["Kernel_Name"]]
+        rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+        dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows[-32:]]
+        instep = "rocprofv3's durations of those same 32 dispatches (the last 32 of the search kernel in the kernel trace): avg %.1f us, min %.1f us, max %.1f us.\n" % (
+            sum(dur) / len(dur), min(dur), max(dur))
     cmd = "python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-also --workload %s" % w
     out = """# %s rocprofv3 --kernel-trace --stats: %s
 
@@ -46,15 +55,16 @@ Command (on the MI355X box, `tools/profile_round.sh %s`): `cd /tmp && export TMP
 
 State: Hanabi-Full 2p, %d envs, 49 simulations per move in ONE launch of the persistent search kernel (%d trees per workgroup); the whole
 lock-step (8 kernels: three hipBLASLt GEMMs + `k_mlp_recurrent16` = the root inference, `k_prepare`, the search kernel,
-`k_move_tail_a`, `k_move_tail_b`) is one hipGraph.  Search-kernel rows: 14 from the timed / warm-up / capture steps, the rest from bench.py's
-roofline pass (6 graphs of 4 back-to-back launches on snapshots of live trees); `k_backprop_traverse`, `k_traverse`, `k_backprop`,
-`k_mlp_recurrent<.., 4, 4>`, the `__amd_rocclr_copyBuffer` rows and 24 of the `k_move_tail_*` rows come ONLY from that pass (snapshots, the
-launch-per-phase search that measures the mean path length, the tail timing's replays).
-bench.py's own HIP-event figure for the same kernel in this run: avg %.1f us, best graph %.1f us
-(rocprofv3's per-dispatch average below includes the cold first launches of each snapshot).
+`k_move_tail_a`, `k_move_tail_b`) is one hipGraph.  Search-kernel rows: 14 from the timed / warm-up / capture steps, 40 from bench.py's
+roofline pass (further lock-steps of the live actor enqueued kernel by kernel, a HIP event on either side of the search launch:
+`bench.py::search_in_step`), the rest from the launch-per-phase search that measures the mean path length; `k_backprop_traverse`,
+`k_traverse`, `k_backprop`, `k_mlp_recurrent<.., 4, 4>` and the `__amd_rocclr_copyBuffer` rows come ONLY from that last pass and from the
+tail timing's snapshots.
+bench.py's own HIP-event figure for the same kernel in this run: avg %.1f us, shortest %.1f us (an event pair adds ~5 us of its own).
+%s(The per-kernel averages of the table below are over ALL dispatches, the process's first launches and the warm-up steps included.)
 
 %s""" % (tag, cmd, tag, tag, w, cmd, commit, note, d["config"]["envs_per_gpu"], rf["trees_per_workgroup"], rf["avg_launch_us"],
-         rf["min_launch_us"], buf.getvalue())
+         rf["min_launch_us"], instep, buf.getvalue())
     open(os.path.join(ROOT, "profiles", "%s_bench_kernel_stats_%s.md" % (tag, w)), "w").write(out)
     row = [l for l in buf.getvalue().splitlines() if "k_search" in l][0]
     print(w, row[:160])
