@@ -487,6 +487,9 @@ class Run:
         for _ in range(warmup):
             self.step_all()
         self.flush(final=True)
+        for _ in range(3):  # (an actor whose first drains changed its search kernels -- SelfPlayActor(predicted_lines="auto") -- captures
+            self.step_all()  # its lock-step again at its next move: not inside the timed region)
+        self.flush(final=True)
         if self.world > 1:  # the record gather's point-to-point channels exist before the timed region even if no game has ended yet
             w = torch.zeros(16, dtype=torch.uint8, device=self.device if self.args.backend == "nccl" else "cpu")
             dist.gather(w, [torch.empty_like(w) for _ in range(self.world)] if self.rank == 0 else None, dst=0)
@@ -760,6 +763,7 @@ def main():
                                "avg_launch_us": t * 1e6, "min_launch_us": search["min_s"] * 1e6, "launches_timed": search["launches"], "empty_event_pair_us": search["empty_event_pair_us"], "eager_step_us": search["eager_step_us"],
                                "poll_giveups": _poll_giveups(),  # waits on arrival counters that timed out in this process (must be 0)
                                "flop_per_launch": fl, "simulations_per_launch": S - 1, "trees_per_workgroup": rows_wg, "workgroups": wgs,
+                               "predicted_line_kernels": bool(actor._lines_on),  # (SelfPlayActor's choice for this policy: hz_search_set_predicted_lines)
                                "l2_stream": {"bytes_per_launch": l2_bytes, "achieved_TBps": l2_bytes / t / 1e12, "peak_TBps": L2_PEAK_TBS,
                                              "frac": l2_bytes / t / 1e12 / L2_PEAK_TBS,
                                              "note": "L1<-L2 weight stream (every workgroup pulls all %d weight bytes per simulation) + pool rows: the resource that binds this kernel" % engine.fused.weight_bytes_per_wg},
@@ -795,7 +799,8 @@ def main():
             r.setup()
             el = r.timed(args.steps, args.warmup, lambda: None)
             entry = {"workload": wl, "dtype": dt, "net": net, "value": r.N * args.steps / el, "unit": "moves/s",
-                     "ms_per_step": 1e3 * el / args.steps, "steps": args.steps, "games_finished": r.games}
+                     "ms_per_step": 1e3 * el / args.steps, "steps": args.steps, "games_finished": r.games,
+                     "predicted_line_kernels": bool(r.actors[0]._lines_on)}
             if not args.no_roofline:
                 _, search, _, _, _ = kernel_timing(r.actors[0], sample_sims=())
                 if search:

@@ -104,6 +104,7 @@ def _load():
         "hz_mlp_recurrent_res": [C.POINTER(MlpHeader), V, V, V, V, V, I64, V, I64, V, V, V, V, V, I, I, V, I64, V],
         # include/hz_search.h
         "hz_search_run": [V, I, C.POINTER(MlpHeader), V, V, V, V, V, I64, I64, V, V, V, V, V, V, I, V],
+        "hz_search_set_predicted_lines": [V, I],
         "hz_search_poll_giveups": [C.POINTER(C.c_uint)],
         "hz_mlp_poll_giveups": [C.POINTER(C.c_uint)],
         "hz_mlp_poll_giveups_async": [V, V],

@@ -154,7 +154,7 @@ extern "C" int hz_search_profile_read(unsigned long long* host) {
 // per wave, taken one after the other in the tree phases, and 32 rows per weight fragment in the inference -- for more
 // trees than 16 x #CUs, where the workgroups would otherwise queue and stream the weights once per 16 rows.
 // (amdgpu_num_vgpr: the compiler's registers end below the weight ring of the hand-scheduled k-loop, hz_mlp_dev.h)
-template <class EL, int RT>
+template <class EL, int RT, bool RP>  // RP: the descent along predicted lines compiled in (hz_tree_replay_dev.h; RT == 1 only)
 __device__ __forceinline__ void search_kernel_body(const TreeView& tv, const hz_mlp_header_t& H, const SearchArgs& a) {
   extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
   constexpr int MT = 16 * RT;
@@ -169,7 +169,7 @@ __device__ __forceinline__ void search_kernel_body(const TreeView& tv, const hz_
   L.lds_q = reinterpret_cast<float*>(L.path_s + MT * (tv.S + 1));
   L.act_s = reinterpret_cast<int32_t*>(L.lds_q + MT * tv.S);
   L.ptab = (a.ptab && tv.S < 64) ? reinterpret_cast<float*>(L.act_s + MT + 2) + 128 : nullptr;  // (behind the half kernels' tab_s)
-  L.nextact_s = (RT == 1 && a.nextact && L.ptab != nullptr) ? reinterpret_cast<int32_t*>(L.ptab + hz_ptab_words(tv.S)) : nullptr;
+  L.nextact_s = (RT == 1 && RP && a.nextact && L.ptab != nullptr) ? reinterpret_cast<int32_t*>(L.ptab + hz_ptab_words(tv.S)) : nullptr;
   if (L.nextact_s != nullptr) L.nextact_s[threadIdx.x] = 0;
   if (threadIdx.x < 32) L.exp_s[threadIdx.x] = hz_exp2f_tab[threadIdx.x];
   if (L.ptab != nullptr) hz_ptab_fill(L.ptab, tv.pbc_tab, tv.S, (int)threadIdx.x, 1024);
@@ -221,7 +221,7 @@ __device__ __forceinline__ void search_kernel_body(const TreeView& tv, const hz_
 #pragma unroll
     for (int s = 0; s < RT; ++s)
       if (mine[s])
-        rows[s] = search_backup_descent<EL, RT == 1>(tv, H, a, L, row0, row0 + 16 * s + wave, lane_t, 16 * s + wave, sim, sim + 1 < a.sims,
+        rows[s] = search_backup_descent<EL, RT == 1 && RP>(tv, H, a, L, row0, row0 + 16 * s + wave, lane_t, 16 * s + wave, sim, sim + 1 < a.sims,
                                         tl[s], root_row[s]);
     p_tree += t1 - t0; p_wait1 += t2 - t1; p_mlp += t3 - t2; p_wait2 += t4 - t3;
     t0 = t4;
@@ -234,15 +234,17 @@ __device__ __forceinline__ void search_kernel_body(const TreeView& tv, const hz_
 #endif
 }
 
-template <class EL>
+// (RP = false: the same kernel without the descent along predicted lines -- its mere presence costs the plain walk 0.6 %, so a
+// caller whose trees stay shallow asks for this one: hz_search_set_predicted_lines)
+template <class EL, bool RP>
 __global__ __launch_bounds__(1024, 1) __attribute__((amdgpu_num_vgpr(HZ_ASMK_VGPRS))) void k_search(TreeView tv, hz_mlp_header_t H, SearchArgs a) {
-  search_kernel_body<EL, 1>(tv, H, a);
+  search_kernel_body<EL, 1, RP>(tv, H, a);
 }
 // the two trees of a wave one after the other: its register pressure peaks above the others', and amdgpu_num_vgpr is a budget the
 // allocator was seen to overdraw by four registers -- into the ring (tools/scan_ring_registers.py) -- so this one gets a lower one
 template <class EL>
 __global__ __launch_bounds__(1024, 1) __attribute__((amdgpu_num_vgpr(HZ_ASMK_VGPRS - 8))) void k_search_turn(TreeView tv, hz_mlp_header_t H, SearchArgs a) {
-  search_kernel_body<EL, 2>(tv, H, a);
+  search_kernel_body<EL, 2, false>(tv, H, a);
 }
 
 // Two trees per tree-owning wave, side by side in its two 32-lane halves (hz_tree_half_dev.h; A <= 32, hidden <= 512): the tree
@@ -250,7 +252,7 @@ __global__ __launch_bounds__(1024, 1) __attribute__((amdgpu_num_vgpr(HZ_ASMK_VGP
 // the inference); 8 -> 16 trees per workgroup, waves 8-15 sit the tree phase out -- the tree phase is bound by instruction
 // issue (the youngest of a SIMD's four waves takes twice as long as the oldest through the same work), so two streams per SIMD
 // instead of four take about half the time.
-template <class EL, int TW>
+template <class EL, int TW, bool RP>
 __global__ __launch_bounds__(1024, 1) __attribute__((amdgpu_num_vgpr(HZ_ASMK_VGPRS))) void k_search_half(TreeView tv, hz_mlp_header_t H, SearchArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
   constexpr int MT = 2 * TW;
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(1024, 1) __attribute__((amdgpu_num_vgpr(HZ_ASMK_VGP
   L.ptab = (a.ptab && tv.S < 64) ? reinterpret_cast<float*>(L.act_s + MT + 2) + 128 : nullptr;
   if (L.ptab != nullptr) hz_ptab_fill(L.ptab, tv.pbc_tab, tv.S, (int)threadIdx.x, 1024);
   // [MT][S] 16-bit words behind the table of exploration factors: the nodes' last selections (HalfTree::nextact), all "never passed"
-  uint16_t* nextact16_s = (TW == 16 && a.nextact && L.ptab != nullptr) ? reinterpret_cast<uint16_t*>(L.ptab + hz_ptab_words(tv.S)) : nullptr;
+  uint16_t* nextact16_s = (TW == 16 && RP && a.nextact && L.ptab != nullptr) ? reinterpret_cast<uint16_t*>(L.ptab + hz_ptab_words(tv.S)) : nullptr;
   if (nextact16_s != nullptr)
     for (int i = (int)threadIdx.x; i < MT * tv.S; i += 1024) nextact16_s[i] = 0;
   if (threadIdx.x < 32) L.exp_s[threadIdx.x] = hz_exp2f_tab[threadIdx.x];
@@ -351,10 +353,10 @@ __global__ __launch_bounds__(1024, 1) __attribute__((amdgpu_num_vgpr(HZ_ASMK_VGP
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
       hz_tree_descent_prio();
       int entry;
-      if (TW == 16 && __ballot(t.deep) != 0)
+      if (TW == 16 && RP && __ballot(t.deep) != 0)
         entry = traverse_half<2>(tv, q, t, sim + 1, mn, mx, root_row, tab_s, L.ptab, L.act_s + TW * q.h + wave, a.ix, a.iy, sim + 2 == a.sims);
       else
-        entry = traverse_half<TW == 16 ? 1 : 0>(tv, q, t, sim + 1, mn, mx, root_row, tab_s, L.ptab, L.act_s + TW * q.h + wave, a.ix, a.iy,
+        entry = traverse_half<(TW == 16 && RP) ? 1 : 0>(tv, q, t, sim + 1, mn, mx, root_row, tab_s, L.ptab, L.act_s + TW * q.h + wave, a.ix, a.iy,
                                                 sim + 2 == a.sims);
       if (t.mine) {
         const uint4* src = reinterpret_cast<const uint4*>(a.pool + ((size_t)entry * tv.N + t.tree) * (size_t)H.hidden);
@@ -372,11 +374,17 @@ __global__ __launch_bounds__(1024, 1) __attribute__((amdgpu_num_vgpr(HZ_ASMK_VGP
 #endif
 }
 
+extern "C" int hz_search_set_predicted_lines(hz_tree_t* t, int on) {
+  HZ_REQUIRE(t != nullptr, "hz_search_set_predicted_lines: tree is NULL");
+  t->predicted_lines = on ? 1 : 0;
+  return 0;
+}
+
 // What this library remembers per DEVICE (ordinal of the tree handle, not the calling thread's current device): the compute-
 // unit count and, per kernel variant, the dynamic-LDS limit already raised with hipFuncSetAttribute (a per-device attribute).
 struct SearchDevice {
   int n_cu;
-  size_t configured[8];
+  size_t configured[16];
 };
 static SearchDevice g_search_dev[64];
 
@@ -452,7 +460,7 @@ extern "C" int hz_search_run(hz_tree_t* t, int num_simulations, const hz_mlp_hea
   // kernel, [32][S] half-words in the side-by-side 32-tree kernel (which has 3 KB left), where they fit
   const bool halves_early = ((rows_wg == 32 && rows_per_workgroup != -32) || rows_per_workgroup == -16) && t->A <= 32 && H->hidden <= 512;
   const size_t nextact_bytes = rows_wg == 16 ? (size_t)16 * 64 * sizeof(int32_t) : (((size_t)32 * t->S * sizeof(uint16_t) + 15) & ~(size_t)15);
-  const bool use_nextact = use_ptab && ((rows_wg == 16 && rows_per_workgroup != -16) || (rows_wg == 32 && halves_early)) &&
+  const bool use_nextact = t->predicted_lines != 0 && use_ptab && ((rows_wg == 16 && rows_per_workgroup != -16) || (rows_wg == 32 && halves_early)) &&
                            lds_bytes + nextact_bytes <= 160 * 1024;
   if (use_nextact) lds_bytes += nextact_bytes;
   // two trees per tree-owning wave, side by side: the default with 32 trees per workgroup; with 16 only on request (-16) --
@@ -475,15 +483,17 @@ extern "C" int hz_search_run(hz_tree_t* t, int num_simulations, const hz_mlp_hea
   } while (0)
 #define HZ_SEARCH_LAUNCH_EL(V0, EL)                                                                  \
   do {                                                                                               \
-    if (halves && rows_wg == 32) HZ_SEARCH_LAUNCH(V0 + 2, (k_search_half<EL, 16>), (t->N + 31) / 32); \
-    else if (halves) HZ_SEARCH_LAUNCH(V0 + 3, (k_search_half<EL, 8>), (t->N + 15) / 16);             \
+    if (halves && rows_wg == 32 && use_nextact) HZ_SEARCH_LAUNCH(V0 + 4, (k_search_half<EL, 16, true>), (t->N + 31) / 32); \
+    else if (halves && rows_wg == 32) HZ_SEARCH_LAUNCH(V0 + 2, (k_search_half<EL, 16, false>), (t->N + 31) / 32); \
+    else if (halves) HZ_SEARCH_LAUNCH(V0 + 3, (k_search_half<EL, 8, false>), (t->N + 15) / 16);      \
     else if (rows_wg == 32) HZ_SEARCH_LAUNCH(V0 + 1, (k_search_turn<EL>), (t->N + 31) / 32);         \
-    else HZ_SEARCH_LAUNCH(V0, (k_search<EL>), (t->N + 15) / 16);                                     \
+    else if (use_nextact) HZ_SEARCH_LAUNCH(V0 + 5, (k_search<EL, true>), (t->N + 15) / 16);          \
+    else HZ_SEARCH_LAUNCH(V0, (k_search<EL, false>), (t->N + 15) / 16);                              \
   } while (0)
   int cur = -1;
   HZ_HIP(hipGetDevice(&cur));
   HZ_REQUIRE(cur == t->device, "hz_search_run: the calling thread's current device is %d, the tree lives on %d", cur, t->device);
-  if (H->dtype == HZ_F16) HZ_SEARCH_LAUNCH_EL(4, ElF16);
+  if (H->dtype == HZ_F16) HZ_SEARCH_LAUNCH_EL(8, ElF16);
   else HZ_SEARCH_LAUNCH_EL(0, ElBf16);
 #undef HZ_SEARCH_LAUNCH_EL
 #undef HZ_SEARCH_LAUNCH

@@ -205,6 +205,7 @@ extern "C" int hz_tree_create(hz_tree_t** out, int N, int A, int S, int device) 
   HZ_HIP(hipSetDevice(device));
   hz_tree* t = new hz_tree();
   memset(t, 0, sizeof(*t));
+  t->predicted_lines = 1;
   t->N = N; t->A = A; t->S = S; t->device = device;
   int rc = 0;
   rc |= dev_alloc(&t->rec, (size_t)N * S * A, &t->bytes);
@@ -455,7 +456,7 @@ extern "C" int hz_tree_copy(hz_tree_t* dst, const hz_tree_t* src, void* stream) 
 #undef HZ_CP
   dst->pb_c_base = src->pb_c_base; dst->pb_c_init = src->pb_c_init; dst->discount = src->discount;
   dst->delta = src->delta; dst->seed = src->seed; dst->id_base = src->id_base; dst->params_set = src->params_set;
-  dst->next_entry = src->next_entry;
+  dst->next_entry = src->next_entry; dst->predicted_lines = src->predicted_lines;
   return 0;
 }
 

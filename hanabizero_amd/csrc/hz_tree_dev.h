@@ -15,6 +15,7 @@ struct hz_tree {
   uint32_t id_base;
   int params_set;
   int next_entry;  // host-side guard: the entry the next backprop must create
+  int predicted_lines;  // hz_search_run launches the kernels that walk predicted lines (hz_search_set_predicted_lines; default 1)
   float4* rec;
   float* qsa;
   int32_t* ref;

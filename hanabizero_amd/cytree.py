@@ -238,6 +238,11 @@ class Roots:
         self._sim += int(num_simulations)
         return ix, iy, la
 
+    def set_predicted_lines(self, on):
+        """Which persistent kernels search_tensors launches for these roots (include/hz_search.h: the ones whose descent walks
+        predicted lines in trees that have grown deep -- the default -- or the plain ones).  Same results either way."""
+        check(lib.hz_search_set_predicted_lines(self._h, int(bool(on))), "hz_search_set_predicted_lines")
+
     def root_stats_tensors(self, counts=None, values=None):
         """(visit counts [N, A] i32, root values [N] f32) in one launch; optional caller-owned outputs."""
         if counts is None:

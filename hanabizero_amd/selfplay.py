@@ -45,9 +45,21 @@ def _stream():
 
 
 class SelfPlayActor:
+    # predicted_lines="auto": mean of the trees' `path_len` after a search (hz_tree_get_path_len: the LAST simulation's path) at which
+    # the lock-steps change kernels.  Measured at 4096 envs (`--net sharp:s`): policies whose searches end on paths
+    # of 4.3-4.6 (random-init nets, s = 5, 10) lose 0.6-1.1 % to the predicted-line kernels, 5.65 (s = 20) gains 2.3 %, 7.9 (s = 40) 20 %.
+    PATH_LINES_ON, PATH_LINES_OFF = 5.3, 5.0
+
     def __init__(self, config, engine, num_envs, rank=0, seed=0, device=None, use_graph=True, outbox_games=None,
-                 deterministic=False, env_id_base=None, stream=None, fused_tail=True):
+                 deterministic=False, env_id_base=None, stream=None, fused_tail=True, predicted_lines="auto"):
+        """predicted_lines: which persistent search kernels the lock-steps launch (include/hz_search.h::
+        hz_search_set_predicted_lines): True = the ones whose descent walks predicted lines in trees that have grown deep (what a
+        sharp policy needs), False = the plain ones (0.6-1 % faster while the trees stay shallow), "auto" = start plain and follow
+        the mean length of the searches' last paths, looked at whenever finished games are drained (`PATH_LINES_ON` /
+        `PATH_LINES_OFF`; a switch re-captures the lock-step's hipGraph).  Same records either way."""
         self.cfg, self.engine, self.N = config, engine, int(num_envs)
+        self.predicted_lines = predicted_lines
+        self._lines_on = predicted_lines is True
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         d, N = self.device, self.N
         # global id of this actor's env 0: keys the env seeds and the tie-break stream, so results do not depend on
@@ -64,6 +76,7 @@ class SelfPlayActor:
         self.S, self.stack, self.T = config.num_simulations, config.stacked_observations, config.max_moves
         self.W = self.env.packed_words
         self.roots = cytree.Roots(N, self.A, self.S, device=d, tie_seed=seed, tree_id_base=self.env_id_base)
+        self.roots.set_predicted_lines(self._lines_on)
         self.mcts = MCTS(config)
         dt = engine.dtype
         z = lambda *s, dtype: torch.zeros(s, dtype=dtype, device=d)
@@ -269,6 +282,8 @@ class SelfPlayActor:
         """Packed records of the games finished since the last drain (synchronises).  Returns a dict of numpy arrays
         with a leading games axis, or None.  Must be called at least once per `cap` finished games."""
         self._work_stream().synchronize()
+        if self.predicted_lines == "auto":
+            self._follow_path_lengths(float(self.roots.path_len_tensor().float().mean()))
         count = int(self.out_count[0].item())
         n = count - self._drained
         if n <= 0:
@@ -299,17 +314,22 @@ class SelfPlayActor:
             self._count_host = torch.zeros(2, dtype=torch.int64).pin_memory()
             self._count_snap = torch.zeros(2, dtype=torch.int64, device=self.device)
             self._giveups_host = torch.zeros(2, dtype=torch.int32).pin_memory()
+            self._plen_host = torch.zeros(1, dtype=torch.float32).pin_memory()
+            self._plen_snap = torch.zeros(1, dtype=torch.float32, device=self.device)
             from ._lib import poll_giveups
             self._giveups_seen = poll_giveups()  # (what the process had before this actor's first drain -- e.g. a test's broken table -- is not this actor's)
         assert self._snap is None, "drain_begin: the previous snapshot has not been consumed (drain_end)"
         ws = self._work_stream()
         with torch.cuda.stream(ws):
             self._count_snap.copy_(self.out_count)
+            if self.predicted_lines == "auto":  # (the last search's path lengths: what decides about the search kernels, drain_end)
+                self._plen_snap.copy_(self.roots.path_len_tensor().float().mean())
             taken = torch.cuda.Event()
             taken.record(ws)
         self.drain_stream.wait_event(taken)
         with torch.cuda.stream(self.drain_stream):
             self._count_host.copy_(self._count_snap, non_blocking=True)
+            self._plen_host.copy_(self._plen_snap, non_blocking=True)
             check(lib.hz_mlp_poll_giveups_async(self._giveups_host.data_ptr(), _stream()), "hz_mlp_poll_giveups_async")
             self._snap = torch.cuda.Event()
             self._snap.record(self.drain_stream)
@@ -325,6 +345,7 @@ class SelfPlayActor:
         self._snap.synchronize()
         self._snap = None
         count, moves_total = (int(x) for x in self._count_host.tolist())
+        self._follow_path_lengths(float(self._plen_host[0]))
         giveups = int(self._giveups_host[0]) + int(self._giveups_host[1])
         if giveups != self._giveups_seen:  # a wait on an arrival counter timed out: search results since the last drain are not to be trusted
             seen, self._giveups_seen = self._giveups_seen, giveups
@@ -344,6 +365,17 @@ class SelfPlayActor:
                                     _stream()), "hz_actor_pack")
         self._drained, self._moves_drained = count, moves_total
         return buf, n, moves
+
+    def _follow_path_lengths(self, mean_nodes):
+        """predicted_lines="auto": change the search kernels when the searches' last paths have grown long / short enough (the
+        next lock-step captures its hipGraph again: two eager moves and a capture, ~10 ms, rare)."""
+        if self.predicted_lines != "auto" or mean_nodes <= 0.0:
+            return
+        want = mean_nodes >= self.PATH_LINES_ON if not self._lines_on else mean_nodes > self.PATH_LINES_OFF
+        if want != self._lines_on:
+            self._lines_on = want
+            self.roots.set_predicted_lines(want)
+            self._graph = None
 
     def drain_packed(self):
         """drain_begin + drain_end in one blocking call: the games finished by the work enqueued so far, usable on the
@@ -369,11 +401,9 @@ class ActorGroup:
         self._graph = None
 
     def set_trained_steps(self, trained_steps):
-        """selfplay_worker.py:172-174: the visit-count temperature of the coming moves, from the learner's step counter
-        (config.visit_softmax_temperature_fn; 1.0 throughout while change_temperature is off, as in both Hanabi configs).  In place:
-        a captured lock-step picks it up at its next replay (fused tail; the launch-per-phase tail takes it at enqueue time)."""
-        self.temperature.fill_(float(self.cfg.visit_softmax_temperature_fn(0, int(trained_steps))))
-        self._temperature_host = float(self.cfg.visit_softmax_temperature_fn(0, int(trained_steps)))
+        """SelfPlayActor.set_trained_steps for every actor of the group."""
+        for a in self.actors:
+            a.set_trained_steps(trained_steps)
 
     def _capture(self):
         for a in self.actors:
@@ -400,8 +430,11 @@ class ActorGroup:
         self._graph = g
 
     def step(self):
+        if any(a._lines_on != on for a, on in zip(self.actors, getattr(self, "_lines_captured", ()))):
+            self._graph = None  # (an actor's drain has changed its search kernels: SelfPlayActor._follow_path_lengths)
         if self._graph is None:
             self._capture()
+            self._lines_captured = [a._lines_on for a in self.actors]
         for a in self.actors:
             a.total_moves += a.N
         self._graph.replay()

@@ -48,6 +48,12 @@ int hz_search_run(hz_tree_t* t, int num_simulations, const hz_mlp_header_t* H, c
                   int64_t plane_stride, int64_t row_stride, int32_t* ix, int32_t* iy, int32_t* la, float* rewards,
                   float* values, float* policy, int rows_per_workgroup, void* stream);
 
+/* Which kernels hz_search_run launches for this tree: on (the default) = the ones whose descent walks predicted lines in trees
+ * that have grown deep -- what a sharp policy needs (2.0 M against 1.67 M moves/s at 4096 envs, 3.0 M against 2.4 M at 8192);
+ * off = the same kernels without that code, whose mere presence costs trees that never grow deep 0.6 % (1.0 % at 8192 envs).
+ * The results are the same bits either way.  SelfPlayActor switches by the mean length of its searches' last paths. */
+int hz_search_set_predicted_lines(hz_tree_t* t, int on);
+
 /* hz_search_run's share of hz_mlp_poll_giveups (include/hz_mlp.h), which is the one to call. */
 int hz_search_poll_giveups(unsigned int* count);
 int hz_search_poll_giveups_async(unsigned int* host_pinned, void* stream);  /* hz_mlp_poll_giveups_async's share */

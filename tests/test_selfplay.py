@@ -246,8 +246,12 @@ def test_persistent_search_kernel_equals_launch_per_phase(game, N, sims, peaked,
     # launch per phase; the persistent kernel with 16 trees per workgroup: one per wavefront, or two side by side in the
     # halves of 8 wavefronts (-16; A <= 32); with 32: side by side or one after the other (-32; what A = 48 gets either way);
     # the library's own choice (32 once the trees outnumber 16 per compute unit: the last case)
-    for persistent in (False, 16, -16, 32, -32, "auto"):
+    # ... and the 16- / 32-tree kernels once more without the descent along predicted lines (hz_search_set_predicted_lines: "plain")
+    for persistent in (False, 16, -16, 32, -32, "auto", "plain16", "plain32"):
         roots = cytree.Roots(N, A, sims, tie_seed=5, tree_id_base=17)
+        if str(persistent).startswith("plain"):
+            roots.set_predicted_lines(False)
+            persistent = int(persistent[5:])
         roots.prepare(0.0 if peaked is True else cfg.root_exploration_fraction, noise, torch.zeros(N, device="cuda"), logits0, actor.legal)
         pool = torch.zeros(sims, N, eng.H, dtype=eng.dtype, device="cuda")
         MCTS(cfg, persistent=bool(persistent), rows_per_workgroup=0 if persistent in (False, "auto") else int(persistent)
@@ -484,3 +488,31 @@ def test_new_entry_points_report_bad_arguments():
         actor.step()
     torch.cuda.synchronize()
     assert int(actor.illegal_steps) == 0
+
+
+def test_actor_follows_path_lengths_to_the_predicted_line_kernels():
+    """predicted_lines="auto": an actor starts with the plain search kernels and changes to the predicted-line ones at the first
+    drain that sees long last paths (a sharp policy), captures its lock-step again, and stays there; with random-init nets it
+    stays plain.  The games do not depend on the kernels: after the same number of moves the same env states, windows and last
+    actions as an actor that used the other kernels throughout."""
+    for peaked, expect in (("sharp", True), (False, False)):
+        out = []
+        for mode in ("auto", not expect):
+            cfg, eng, actor = make("Hanabi-Full", 256, 50, 4, torch.float16, use_graph=True, peaked=peaked)
+            actor.predicted_lines = mode
+            actor._lines_on = mode is True
+            actor.roots.set_predicted_lines(actor._lines_on)
+            calls = 0
+            while actor.total_moves < 26 * actor.N:  # (a capture plays two moves of its own: count moves, not calls)
+                actor.step()
+                calls += 1
+                if calls % 5 == 0:
+                    actor.drain_packed()
+            torch.cuda.synchronize()
+            assert actor.total_moves == 26 * actor.N
+            if mode == "auto":
+                assert actor._lines_on == expect, float(actor.roots.path_len_tensor().float().mean())
+            out.append((actor.action.clone(), actor.env.snapshot(), actor.stack_buf.clone()))
+        assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][2], out[1][2])
+        for x, y in zip(out[0][1], out[1][1]):
+            assert torch.equal(x, y)

@@ -33,7 +33,7 @@ def main():
     net = sys.argv[2] if len(sys.argv) > 2 else "random"
     cfg = make_config("Hanabi-Full", simulations=50, stack=4)
     eng = bench.build_engine(cfg, torch.float16, "cuda", net=net)
-    actor = SelfPlayActor(cfg, eng, num_envs=N, rank=0, seed=1, use_graph=False)
+    actor = SelfPlayActor(cfg, eng, num_envs=N, rank=0, seed=1, use_graph=False, predicted_lines=True)
     lib = _lib.lib
     lib.hz_tree_level_profile_read.argtypes = [C.c_void_p]
     for _ in range(5):
