@@ -369,7 +369,7 @@ class SelfPlayActor:
     def _follow_path_lengths(self, mean_nodes):
         """predicted_lines="auto": change the search kernels when the searches' last paths have grown long / short enough (the
         next lock-step captures its hipGraph again: two eager moves and a capture, ~10 ms, rare)."""
-        if self.predicted_lines != "auto" or mean_nodes <= 0.0:
+        if self.predicted_lines != "auto" or mean_nodes <= 0.0 or self.A > 20:  # (the kernels walk predicted lines for A <= 20 only)
             return
         want = mean_nodes >= self.PATH_LINES_ON if not self._lines_on else mean_nodes > self.PATH_LINES_OFF
         if want != self._lines_on:
