@@ -402,7 +402,8 @@ class Run:
         # random-init play finishes a game every ~16 moves
         self.actors = [SelfPlayActor(self.cfg, self.engine, N // K, seed=0, device=device, use_graph=not args.no_graph,
                                      env_id_base=rank * N + k * (N // K), outbox_games=8 * (N // K),
-                                     stream=torch.cuda.Stream(device=device) if K > 1 else None) for k in range(K)]
+                                     stream=torch.cuda.Stream(device=device) if K > 1 else None,
+                                     predicted_lines={"auto": "auto", "on": True, "off": False}[args.predicted_lines]) for k in range(K)]
         for a in self.actors:
             a.mcts.rows_per_workgroup = rows_per_workgroup
         self.group = None
@@ -592,6 +593,8 @@ def main():
     ap.add_argument("--dtype", default="fp16", choices=["bf16", "fp16", "fp32"],
                     help="format of the nets (weights, activations, hidden-state pool; fp32 accumulate): fp16 = the reference's own search "
                          "precision (autocast, core/mcts.py:38-40; the default), bf16 = what BASELINE.json configs[2] names (measured under `also`)")
+    ap.add_argument("--predicted-lines", default="auto", choices=["auto", "on", "off"],
+                    help="the search kernels' build (hz_search_set_predicted_lines): auto = the actor follows its searches' path lengths (the product)")
     ap.add_argument("--net", default="random", help='"random" (SURVEY 8d) or "sharp[:scale]" (concentrated policy: deep paths)')
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for --gpus > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path on one GPU)")

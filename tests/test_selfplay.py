@@ -226,7 +226,8 @@ def test_select_action_kernel_edge_cases():
     ("Hanabi-Full", 4170, 8, False, torch.bfloat16), ("Hanabi-Full", 45, 50, True, torch.bfloat16),
     ("Hanabi-Small", 100, 12, False, torch.float16), ("Hanabi-Full", 1000, 20, False, torch.float16),
     ("Hanabi-Full-5p", 70, 30, False, torch.float16), ("Hanabi-Full", 45, 50, True, torch.float16),
-    ("Hanabi-Full", 700, 50, "sharp", torch.bfloat16), ("Hanabi-Full", 700, 50, "sharp", torch.float16)])
+    ("Hanabi-Full", 700, 50, "sharp", torch.bfloat16), ("Hanabi-Full", 700, 50, "sharp", torch.float16),
+    ("Hanabi-Full-5p", 300, 50, "sharp", torch.float16)])  # (A = 48: no predicted lines there, long paths all the same)
 def test_persistent_search_kernel_equals_launch_per_phase(game, N, sims, peaked, dtype):
     """hz_search_run (all simulations in one persistent kernel, a workgroup per 16 trees) against the launch-per-phase
     search (hz_tree_traverse -> hz_mlp_recurrent -> hz_tree_backprop_traverse ...): bit-identical trees, hidden-state
@@ -267,7 +268,7 @@ def test_persistent_search_kernel_equals_launch_per_phase(game, N, sims, peaked,
     assert int(a[0].sum()) == N * (sims - 1)
     assert poll_giveups() == giveups_before, "a wave gave up waiting for an arrival counter (include/hz_mlp.h)"
     if peaked == "sharp":  # (the 16-tree kernel walks long repeated paths sixteen levels at a time: hz_tree_replay_dev.h)
-        assert int(a[4].max()) > 12 and float(a[4].float().mean()) > 4, (int(a[4].max()), float(a[4].float().mean()))
+        assert int(a[4].max()) > (12 if game == "Hanabi-Full" else 8) and float(a[4].float().mean()) > 4, (int(a[4].max()), float(a[4].float().mean()))
     if peaked is True and dtype == torch.bfloat16:  # paths longer than the 32 lanes a tree has in the side-by-side kernel: its backup
         assert int(a[4].max()) > 34, int(a[4].max())  # runs in two chunks (in fp16 the 49-deep chain of random nets turns NaN first)
 
