@@ -34,7 +34,8 @@ __device__ __forceinline__ int hz_quad_or(int v) {  // OR over the four lanes of
 
 // What the replay needs of TreeView / TreeLocal, by value.  (Measured at 4096 envs, random-init nets, where replays are rare: with
 // the two structs passed by reference the mere presence of the inlined code cost the ordinary descent 1.4 % -- 25 more
-// scalar-register spills in the kernel; with this struct 0.6 %; as a real function, called: 4.4 %, and a third of the gain lost.)
+// scalar-register spills in the kernel; with this struct 0.6 %; as a real function, called: 4.4 %, and a third of the gain lost.
+// Hence two builds of the search kernels, with and without all of this: hz_search.hip, hz_search_set_predicted_lines.)
 struct ReplayIn {
   int A, S, tree, sim;
   float mn, mx, discount, delta_floor;
