@@ -97,6 +97,10 @@ struct TraverseOut {
 #ifndef HZ_TREE_REPLAY
 #define HZ_TREE_REPLAY 1
 #endif
+#ifndef HZ_REPLAY_G  // lanes per level / children per lane of a pass (A <= 20 needs G C >= 20): 4, 5 = sixteen levels per pass; 8, 3 = eight
+#define HZ_REPLAY_G 4
+#define HZ_REPLAY_C 5
+#endif
 #ifndef HZ_TREE_REPLAY_MIN  // levels of a descent from which on the tree's descents look for predicted lines
 #define HZ_TREE_REPLAY_MIN 6
 #endif
@@ -275,7 +279,7 @@ __device__ __forceinline__ void traverse_body(const TreeView& tv, int tree, int 
     // the last backup's stores to the records must have landed (the ordinary walk waits for them behind its root level)
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     while (true) {
-      const ReplayOut ro = traverse_replay<5>(in, e, depth, parent_q, pvc);
+      const ReplayOut ro = traverse_replay<HZ_REPLAY_G, HZ_REPLAY_C>(in, e, depth, parent_q, pvc);
       // (said to the compiler in so many words: all of this is wave-uniform -- what it cannot prove it computes per lane,
       // and the ordinary walk below would inherit that)
       e = hz_uniform(ro.e);

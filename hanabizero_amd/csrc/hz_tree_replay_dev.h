@@ -31,6 +31,27 @@ __device__ __forceinline__ int hz_quad_or(int v) {  // OR over the four lanes of
   v |= HZ_QUAD(v, 0x4E);  // quad_perm:[2,3,0,1]
   return v;
 }
+// ... over the G = 4 | 8 lanes of a level's group (8: the two quads of a half row swap through row_half_mirror), in all of them
+template <int G>
+__device__ __forceinline__ int hz_group_or(int v) {
+  v = hz_quad_or(v);
+  if (G == 8) v |= HZ_QUAD(v, 0x141);
+  return v;
+}
+template <int G>
+__device__ __forceinline__ int hz_group_add(int v) {
+  v += HZ_QUAD(v, 0xB1);
+  v += HZ_QUAD(v, 0x4E);
+  if (G == 8) v += HZ_QUAD(v, 0x141);
+  return v;
+}
+template <int G>
+__device__ __forceinline__ float hz_group_max(float v) {
+  v = fmaxf(v, __int_as_float(HZ_QUAD(__float_as_int(v), 0xB1)));
+  v = fmaxf(v, __int_as_float(HZ_QUAD(__float_as_int(v), 0x4E)));
+  if (G == 8) v = fmaxf(v, __int_as_float(HZ_QUAD(__float_as_int(v), 0x141)));
+  return v;
+}
 
 // What the replay needs of TreeView / TreeLocal, by value.  (Measured at 4096 envs, random-init nets, where replays are rare: with
 // the two structs passed by reference the mere presence of the inlined code cost the ordinary descent 1.4 % -- 25 more
@@ -53,11 +74,14 @@ struct ReplayIn {
 // a node's last selection: bit 16 = "has been passed", bits 8-15 = child entry + 1 (0: not expanded then), bits 0-7 = action
 #define HZ_NEXTACT(child_e, action) (0x10000 | (((child_e) + 1) << 8) | (action))
 
-template <int C>  // children per lane: lane 4 j + g of the wave owns children g C .. g C + C - 1 of level slot j  (A <= 4 C)
+// G lanes per level, C children per lane: lane G j + g of the wave owns children g C .. g C + C - 1 of level slot j (A <= G C);
+// 64 / G levels per pass
+template <int G, int C>
 __device__ __forceinline__ ReplayOut traverse_replay(const ReplayIn in, int start, int depth0, float mq_in, int pvc_in) {
   const int lane = (int)(threadIdx.x & 63);
   const int A = in.A, S = in.S, tree = in.tree, sim = in.sim;
-  const int g = lane & 3, j = lane >> 2;
+  constexpr int LG = G == 4 ? 2 : 3, SLOTS = 64 / G;
+  const int g = lane & (G - 1), j = lane >> LG;
   const float discount = in.discount, mn = in.mn, mx = in.mx;
   const float delta = mx - mn;
   const float dn = delta < in.delta_floor ? in.delta_floor : delta;
@@ -71,12 +95,12 @@ __device__ __forceinline__ ReplayOut traverse_replay(const ReplayIn in, int star
     const int J1 = ((na_mine & 0x10000) && c1) ? c1 - 1 : 63;
     const int J2 = __builtin_amdgcn_ds_bpermute(4 * J1, J1);
     const int J4 = __builtin_amdgcn_ds_bpermute(4 * J2, J2);
-    const int J8 = __builtin_amdgcn_ds_bpermute(4 * J4, J4);
+    const int J8 = SLOTS > 8 ? __builtin_amdgcn_ds_bpermute(4 * J4, J4) : 63;
     int n = start;
     { const int t = __builtin_amdgcn_ds_bpermute(4 * n, J1); if (j & 1) n = t; }
     { const int t = __builtin_amdgcn_ds_bpermute(4 * n, J2); if (j & 2) n = t; }
     { const int t = __builtin_amdgcn_ds_bpermute(4 * n, J4); if (j & 4) n = t; }
-    { const int t = __builtin_amdgcn_ds_bpermute(4 * n, J8); if (j & 8) n = t; }
+    if (SLOTS > 8) { const int t = __builtin_amdgcn_ds_bpermute(4 * n, J8); if (j & 8) n = t; }
     const bool lvl = n != 63;
     const int na_n = __builtin_amdgcn_ds_bpermute(4 * n, na_mine);
     const int ap = (lvl && (na_n & 0x10000)) ? (na_n & 255) : -1;  // the node's last selection (none: never passed)
@@ -107,8 +131,9 @@ __device__ __forceinline__ ReplayOut traverse_replay(const ReplayIn in, int star
     // get_mean_q's sum over the visited children in action order: through the level's four lanes, one after the other
     float s = 0.0f;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {  // (every lane folds its children onto what the lane below holds; lane t keeps the result in round t)
-      float f = t == 0 ? 0.0f : __int_as_float(HZ_QUAD(__float_as_int(s), 0x90));  // quad_perm:[0,0,1,2]: the lane below
+    for (int t = 0; t < G; ++t) {  // (every lane folds its children onto what the lane below holds; lane t keeps the result in round t)
+      // the lane below: quad_perm:[0,0,1,2] inside a quad, row_shr:1 inside a group of eight (lane 0 of a group takes none)
+      float f = t == 0 ? 0.0f : __int_as_float(G == 4 ? HZ_QUAD(__float_as_int(s), 0x90) : HZ_QUAD(__float_as_int(s), 0x111));
 #pragma unroll
       for (int i = 0; i < C; ++i) {
         const uint32_t w = __float_as_uint(R[i].w);
@@ -117,12 +142,12 @@ __device__ __forceinline__ ReplayOut traverse_replay(const ReplayIn in, int star
       }
       s = g == t ? f : s;
     }
-    const float total = __int_as_float(HZ_QUAD(__float_as_int(s), 0xFF));  // quad_perm:[3,3,3,3]
-    nv += HZ_QUAD(nv, 0xB1);
-    nv += HZ_QUAD(nv, 0x4E);
-    wprev = hz_quad_or(wprev);  // (visits << 16 | child + 1) of the edge the last descent took from here
+    const float total = G == 4 ? __int_as_float(HZ_QUAD(__float_as_int(s), 0xFF))  // quad_perm:[3,3,3,3]: the group's last lane
+                               : __int_as_float(__builtin_amdgcn_ds_bpermute(4 * (lane | (G - 1)), __float_as_int(s)));
+    nv = hz_group_add<G>(nv);
+    wprev = hz_group_or<G>(wprev);  // (visits << 16 | child + 1) of the edge the last descent took from here
     // visit count of the edge INTO this level's node: the level above holds it
-    int pvc = __builtin_amdgcn_ds_bpermute(4 * (lane - 4), wprev >> 16);
+    int pvc = __builtin_amdgcn_ds_bpermute(4 * (lane - G), wprev >> 16);
     if (j == 0) pvc = pvc_in;
     if (!lvl) pvc = 0;
     TPP(2);
@@ -131,12 +156,12 @@ __device__ __forceinline__ ReplayOut traverse_replay(const ReplayIn in, int star
     {
       const bool rootm = k == 0 && nv > 0;
       const float den = (float)(rootm ? nv : nv + 1);
-      const int steps = __popcll((unsigned long long)__ballot(lvl)) >> 2;  // (a line's nodes fill the slots from 0 up)
+      const int steps = __popcll((unsigned long long)__ballot(lvl)) >> LG;  // (a line's nodes fill the slots from 0 up)
       float pq = mq_in;
       for (int t = 0; t < steps; ++t) {
         const float cand = (rootm ? total : pq + total) / den;
         if (j == t) mq = cand;
-        pq = hz_readlane_f(cand, 4 * t);
+        pq = hz_readlane_f(cand, G * t);
       }
     }
     TPP(3);
@@ -161,8 +186,7 @@ __device__ __forceinline__ ReplayOut traverse_replay(const ReplayIn in, int star
       score[i] = valid ? sc : -INFINITY;
       M = fmaxf(M, score[i]);
     }
-    M = fmaxf(M, __int_as_float(HZ_QUAD(__float_as_int(M), 0xB1)));
-    M = fmaxf(M, __int_as_float(HZ_QUAD(__float_as_int(M), 0x4E)));
+    M = hz_group_max<G>(M);
     TPP(4);
     // cselect_child: {first arg-max} U {later children within epsilon of the max}, the draw among them
     const float thr = M - 0.000001f;
@@ -173,8 +197,8 @@ __device__ __forceinline__ ReplayOut traverse_replay(const ReplayIn in, int star
       if (valid && score[i] == M) eqb |= 1 << (g * C + i);
       if (valid && score[i] >= thr) cb |= 1 << (g * C + i);
     }
-    eqb = hz_quad_or(eqb);
-    uint32_t cand = (uint32_t)hz_quad_or(cb);
+    eqb = hz_group_or<G>(eqb);
+    uint32_t cand = (uint32_t)hz_group_or<G>(cb);
     int action = 0;
     if (eqb != 0) {
       const int first = __ffs(eqb) - 1;
@@ -191,13 +215,13 @@ __device__ __forceinline__ ReplayOut traverse_replay(const ReplayIn in, int star
 #pragma unroll
     for (int i = 0; i < C; ++i)
       if (g * C + i == action) wsel = (int)__float_as_uint(R[i].w);
-    wsel = hz_quad_or(wsel);
+    wsel = hz_group_or<G>(wsel);
     TPP(5);
     // the pass ends at the first level that chose differently from the prediction (or at the line's last node)
     const uint64_t lb = __ballot(lvl);
-    const int last = (64 - __clzll((unsigned long long)lb) - 1) >> 2;  // (slot 0 always holds `start`)
+    const int last = (64 - __clzll((unsigned long long)lb) - 1) >> LG;  // (slot 0 always holds `start`)
     const uint64_t sb = __ballot(lvl && action != ap);
-    const int first_off = sb ? ((__ffsll((unsigned long long)sb) - 1) >> 2) : 15;
+    const int first_off = sb ? ((__ffsll((unsigned long long)sb) - 1) >> LG) : SLOTS - 1;
     const int mslot = min(first_off, last);
     const bool commit = lvl && j <= mslot;
     if (commit && g == 0) {
@@ -208,7 +232,7 @@ __device__ __forceinline__ ReplayOut traverse_replay(const ReplayIn in, int star
 #pragma unroll
     for (int i = 0; i < C; ++i)
       if (commit && g * C + i == action) in.prec[k] = R[i];
-    const int src = 4 * mslot;
+    const int src = G * mslot;
     const uint32_t wv = (uint32_t)hz_readlane_i(wsel, src);
     const int child_e = (int)(wv & 0xffffu) - 1;
     out.action = hz_readlane_i(action, src);
