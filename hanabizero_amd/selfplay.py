@@ -252,6 +252,7 @@ class SelfPlayActor:
                 self.total_moves += self.N
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize(self.device)
+        self._retired_graph = None  # (nothing of a graph that _follow_path_lengths retired is in flight any more)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, capture_error_mode="thread_local"):  # other threads (e.g. the RCCL watchdog) may call HIP meanwhile
             self._step_body()
@@ -375,7 +376,9 @@ class SelfPlayActor:
         if want != self._lines_on:
             self._lines_on = want
             self.roots.set_predicted_lines(want)
-            self._graph = None
+            # (replays of the old graph may still be in flight behind this drain: it stays alive until the next capture has
+            # synchronised the device)
+            self._retired_graph, self._graph = self._graph, None
 
     def drain_packed(self):
         """drain_begin + drain_end in one blocking call: the games finished by the work enqueued so far, usable on the
@@ -417,6 +420,7 @@ class ActorGroup:
                     a.total_moves += a.N
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize(self.device)
+        self._retired_graph = None
         branches = [torch.cuda.Stream(device=self.device) for _ in self.actors]
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, capture_error_mode="thread_local"):  # other threads (e.g. the RCCL watchdog) may call HIP meanwhile
@@ -431,7 +435,9 @@ class ActorGroup:
 
     def step(self):
         if any(a._lines_on != on for a, on in zip(self.actors, getattr(self, "_lines_captured", ()))):
-            self._graph = None  # (an actor's drain has changed its search kernels: SelfPlayActor._follow_path_lengths)
+            # (an actor's drain has changed its search kernels: SelfPlayActor._follow_path_lengths; the old graph lives until
+            # _capture has synchronised the device)
+            self._retired_graph, self._graph = self._graph, None
         if self._graph is None:
             self._capture()
             self._lines_captured = [a._lines_on for a in self.actors]
