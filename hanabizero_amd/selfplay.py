@@ -372,8 +372,10 @@ class SelfPlayActor:
         next lock-step captures its hipGraph again: two eager moves and a capture, ~10 ms, rare)."""
         if self.predicted_lines != "auto" or mean_nodes <= 0.0 or self.A > 20:  # (the kernels walk predicted lines for A <= 20 only)
             return
+        self._lines_hold = max(0, getattr(self, "_lines_hold", 0) - 1)
         want = mean_nodes >= self.PATH_LINES_ON if not self._lines_on else mean_nodes > self.PATH_LINES_OFF
-        if want != self._lines_on:
+        if want != self._lines_on and self._lines_hold == 0:
+            self._lines_hold = 4  # (a change costs a capture: the next four drains' readings are not acted on)
             self._lines_on = want
             self.roots.set_predicted_lines(want)
             # (replays of the old graph may still be in flight behind this drain: it stays alive until the next capture has
