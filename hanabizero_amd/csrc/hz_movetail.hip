@@ -242,10 +242,11 @@ template <>
 __device__ __forceinline__ uint32_t obs_one<uint32_t>(int) { return 0x3f800000u; }
 
 // One row of bytes moved by ONE wave, eight 16-B requests in flight per lane.  A finished game's rows are 160 B .. 16 KB and most
-// of them only 4-byte aligned: gfx950 (unaligned access mode, the ROCm default) takes dwordx4 accesses at any dword boundary,
-// which the packed type below makes the compiler emit; a load -> store round trip per 256 B would be 60 dependent trips for the
-// observation row alone.
-struct __attribute__((packed, aligned(4))) Dwords4 {
+// of them only 4-byte aligned -- with an odd number of actions (Hanabi-Small: 11) the legal-mask rows not even that: gfx950
+// (unaligned access mode, the ROCm default: the target feature the compiler itself relies on) takes dwordx4 accesses at any byte
+// address, which the packed, 1-aligned type below makes the compiler emit (same ISA as with aligned(4)); a load -> store round
+// trip per 256 B would be 60 dependent trips for the observation row alone.
+struct __attribute__((packed, aligned(1))) Dwords4 {
   uint32_t x, y, z, w;
 };
 __device__ __forceinline__ uint4 load_dwords4(const uint8_t* p) {  // (values travel as uint4: arrays of the packed type end up in scratch)
@@ -257,6 +258,11 @@ __device__ __forceinline__ void store_dwords4(uint8_t* p, uint4 v) {
   t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
   *reinterpret_cast<Dwords4*>(p) = t;
 }
+struct __attribute__((packed, aligned(1))) Dword1 {
+  uint32_t x;
+};
+__device__ __forceinline__ uint32_t load_dword1(const uint8_t* p) { return reinterpret_cast<const Dword1*>(p)->x; }
+__device__ __forceinline__ void store_dword1(uint8_t* p, uint32_t v) { reinterpret_cast<Dword1*>(p)->x = v; }
 __device__ __forceinline__ void copy_row_wave(const uint8_t* a, uint8_t* b, long long n, int lane) {
   if ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)n) & 3) == 0) {
     const long long n16 = n & ~15ll;
@@ -282,7 +288,7 @@ __device__ __forceinline__ void copy_row_wave(const uint8_t* a, uint8_t* b, long
 // The seven rows of a finished game moved by a whole workgroup (256 threads) with every load of every row requested before the
 // first store: ONE round trip to memory for a Hanabi-Full game (16 KB of observations, 11 KB in the six other rows) instead of one
 // per 2 KB.  Row BIG (the observations) has NB 16-B pieces per thread and round, the others NS; longer rows take further rounds.
-// Lengths are multiples of 4 B, addresses 4-B aligned.
+// Any length, any alignment: 16-B pieces, then up to three dwords (threads 0..2), then up to three bytes (threads 64..66).
 template <int BIG, int NB, int NS>
 __device__ __forceinline__ void copy_rows_block(const FlushRows& fr, size_t row, size_t slot, int tid) {
   bool more = true;
@@ -309,7 +315,8 @@ __device__ __forceinline__ void copy_rows_block(const FlushRows& fr, size_t row,
         }
         if ((long long)(r + 1) * NS * 256 * 16 < n16) more = true;
       }
-      if (r == 0 && tid < (int)((n - n16) >> 2)) tail[k] = *reinterpret_cast<const uint32_t*>(a + n16 + 4 * tid);
+      if (r == 0 && tid < (int)((n - n16) >> 2)) tail[k] = load_dword1(a + n16 + 4 * tid);
+      if (r == 0 && tid >= 64 && tid < 64 + (int)(n & 3)) tail[k] = a[(n & ~3ll) + (tid - 64)];
     }
 #pragma unroll
     for (int k = 0; k < 7; ++k) {
@@ -328,7 +335,8 @@ __device__ __forceinline__ void copy_rows_block(const FlushRows& fr, size_t row,
           if (off < n16) store_dwords4(bdst + off, vs[k][u]);
         }
       }
-      if (r == 0 && tid < (int)((n - n16) >> 2)) *reinterpret_cast<uint32_t*>(bdst + n16 + 4 * tid) = tail[k];
+      if (r == 0 && tid < (int)((n - n16) >> 2)) store_dword1(bdst + n16 + 4 * tid, tail[k]);
+      if (r == 0 && tid >= 64 && tid < 64 + (int)(n & 3)) bdst[(n & ~3ll) + (tid - 64)] = (uint8_t)tail[k];
     }
   }
 }

@@ -73,7 +73,7 @@ def gather_records(rec, dst=0, group=None, device=None):
         off += sizes[k]
     t = _to_dev(buf, device)
     bufs = [torch.empty_like(t) for _ in range(world)] if rank == dst else None
-    dist.gather(t, bufs, dst=dst, group=group)
+    dist.gather(t, bufs, dst=dst if group is None else dist.get_global_rank(group, dst), group=group)  # (`dst`: a rank of `group`)
     if rank != dst:
         return None
     out = {k: [] for k in _FIELDS}
@@ -135,7 +135,9 @@ def gather_packed(packed, A, W, dst=0, group=None):
     with games -- `unpack_packed` views them without a copy; the buffers are reused by the next call -- elsewhere None.
     Works without a process group (world 1).  Everything is enqueued on the CALLER's current stream and only that stream is
     waited for, so called under ``with torch.cuda.stream(actor.drain_stream)`` the gather overlaps the lock-steps queued on
-    the main stream."""
+    the main stream.  `dst` is a rank OF `group` (translated to the global rank the point-to-point calls want).  Stream contract
+    for `packed[0]` on the sending ranks: under "nccl" the send is only ordered on the caller's stream when this returns, so the
+    buffer may be rewritten by work enqueued on that same stream (what SelfPlayActor.drain_end's next pack is) and by nothing else."""
     import time
     from .selfplay import packed_layout
     n, moves = (0, 0) if packed is None else (int(packed[1]), int(packed[2]))
@@ -152,6 +154,7 @@ def gather_packed(packed, A, W, dst=0, group=None):
         last_gather["landing_s"] = time.perf_counter() - t0
         return [(host.numpy(), n, moves)]
     world, rank = dist.get_world_size(group), dist.get_rank(group)
+    peer = (lambda r: r) if group is None else (lambda r: dist.get_global_rank(group, r))  # P2POp's `peer` is a global rank
     backend = dist.get_backend(group)
     device = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
     mine = torch.tensor([n, moves], dtype=torch.int64, device=device)
@@ -164,14 +167,14 @@ def gather_packed(packed, A, W, dst=0, group=None):
         for r in range(world):
             if sizes[r] and r != rank:
                 recv[r] = _staging_bytes(("recv", r), sizes[r], device)
-                ops.append(dist.P2POp(dist.irecv, recv[r], r, group=group))
+                ops.append(dist.P2POp(dist.irecv, recv[r], peer(r), group=group))
         if sizes[rank]:
             recv[rank] = packed[0][:sizes[rank]]
     elif n:
         send = packed[0][:sizes[rank]]
         if send.device != device:  # (a gloo rehearsal of device-resident records: through the host)
             send = _staging_bytes(("send",), sizes[rank], device).copy_(send)
-        ops.append(dist.P2POp(dist.isend, send.contiguous(), dst, group=group))
+        ops.append(dist.P2POp(dist.isend, send.contiguous(), peer(dst), group=group))
     if ops:
         for w in dist.batch_isend_irecv(ops):
             w.wait()
@@ -206,7 +209,7 @@ def broadcast_weights(state_dict, src=0, group=None, device=None):
     for dt in sorted({state_dict[k].dtype for k in keys}, key=str):
         ks = [k for k in keys if state_dict[k].dtype == dt]
         flat = torch.cat([state_dict[k].detach().reshape(-1).to(device) for k in ks]) if ks else None
-        dist.broadcast(flat, src=src, group=group)
+        dist.broadcast(flat, src=src if group is None else dist.get_global_rank(group, src), group=group)  # (`src`: a rank of `group`)
         off = 0
         for k in ks:
             m = state_dict[k].numel()

@@ -186,12 +186,15 @@ class SelfPlayActor:
         self.roots.prepare(cfg.root_exploration_fraction, self.noise, self.zeros_n, logits0, self.legal)
         self.mcts.run_multi(self.roots, self.engine, hidden0, pool=self.pool)
 
+    def _tail_is_fused(self):
+        return self.fused_tail and self.Dp * self.stack_buf.element_size() % 16 == 0
+
     def _tail_part(self, draw=True):
         """Everything after the search: read-out, action, env step, history, finished games, reset, next observation and window
         (and, draw=True, the next move's draws)."""
         cfg, N = self.cfg, self.N
         b, st = C.byref(self.bufs), _stream()
-        if draw and self.fused_tail and self.Dp * self.stack_buf.element_size() % 16 == 0:
+        if draw and self._tail_is_fused():
             # read-out, action, env step, history append | hand-over of finished games, reset, observation, window, next draws
             from .hanabi_env import _OBS_DTYPES
             env, es = self.env, self.stack_buf.element_size()
@@ -239,8 +242,13 @@ class SelfPlayActor:
         """selfplay_worker.py:172-174: the visit-count temperature of the coming moves, from the learner's step counter
         (config.visit_softmax_temperature_fn; 1.0 throughout while change_temperature is off, as in both Hanabi configs).  In place:
         a captured lock-step picks it up at its next replay (fused tail; the launch-per-phase tail takes it at enqueue time)."""
-        self.temperature.fill_(float(self.cfg.visit_softmax_temperature_fn(0, int(trained_steps))))
-        self._temperature_host = float(self.cfg.visit_softmax_temperature_fn(0, int(trained_steps)))
+        t = float(self.cfg.visit_softmax_temperature_fn(0, int(trained_steps)))
+        with torch.cuda.stream(self._work_stream()):  # (ordered with the lock-steps already enqueued on the actor's own stream)
+            self.temperature.fill_(t)
+        if t != getattr(self, "_temperature_host", None) and self._graph is not None and not self._tail_is_fused():
+            # (the launch-per-phase tail takes the temperature as a by-value argument: a captured graph has the old one baked in)
+            self._retired_graph, self._graph = self._graph, None
+        self._temperature_host = t
 
     def _capture(self):
         self.roots.set_params(self.cfg.pb_c_base, self.cfg.pb_c_init, self.cfg.discount, self.cfg.value_delta_max)
@@ -372,9 +380,10 @@ class SelfPlayActor:
         next lock-step captures its hipGraph again: two eager moves and a capture, ~10 ms, rare)."""
         if self.predicted_lines != "auto" or mean_nodes <= 0.0 or self.A > 20:  # (the kernels walk predicted lines for A <= 20 only)
             return
-        self._lines_hold = max(0, getattr(self, "_lines_hold", 0) - 1)
+        hold = getattr(self, "_lines_hold", 0)
+        self._lines_hold = max(0, hold - 1)
         want = mean_nodes >= self.PATH_LINES_ON if not self._lines_on else mean_nodes > self.PATH_LINES_OFF
-        if want != self._lines_on and self._lines_hold == 0:
+        if want != self._lines_on and hold == 0:
             self._lines_hold = 4  # (a change costs a capture: the next four drains' readings are not acted on)
             self._lines_on = want
             self.roots.set_predicted_lines(want)

@@ -115,13 +115,31 @@ def _wide_errors(eng, ac, obs_width, device):
     return res
 
 
-def search_divergence(game, dtype, roots=256, simulations=50, device="cuda", seed=0):
+def search_fixture(game):
+    """tests/golden/search_<game>_autocast.npz (tools/gen_golden.py::gen_search_autocast): 512 roots searched by the REFERENCE's
+    nets + tree in fp32 and under fp16 autocast."""
+    import os
+    return dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "search_%s_autocast.npz" % game)))
+
+
+def _divergence(d0, v0, d1, v1, sims):
+    d0, d1 = np.asarray(d0, np.float64), np.asarray(d1, np.float64)
+    tv = 0.5 * np.abs(d0 - d1).sum(1) / sims
+    return {"argmax_agreement": float((d0.argmax(1) == d1.argmax(1)).mean()), "visit_tv_mean": float(tv.mean()),
+            "visit_tv_max": float(tv.max()), "identical_visit_counts": float((tv == 0).mean()),
+            "root_value_abs_diff_mean": float(np.abs(np.asarray(v0, np.float64) - np.asarray(v1, np.float64)).mean())}
+
+
+def search_divergence(game, dtype, roots=512, simulations=50, device="cuda", seed=0):
     """What the inference format does to the quantity the search produces: the same `roots` root positions (random binary
     observation windows, the golden weight recipe) searched `simulations - 1` times with the fp32 engine (launch-per-phase
     search, hipBLASLt GEMMs: inside north_star's 1e-3 of the reference nets) and with the engine bench.py times in `dtype`
     (the persistent kernel with the fused MFMA inference), same Dirichlet noise, same tie-break seed.
     Returns the share of roots whose most-visited action agrees, the mean / max total-variation distance between the two
-    visit distributions, and the mean |root value difference|."""
+    visit distributions, and the mean |root value difference|.
+    With the default root set (512 roots, seed 0, 50 simulations: the one tools/gen_golden.py::gen_search_autocast searched with
+    the reference's own nets and tree) the result also carries, under "reference", the same figures for the REFERENCE's fp16-autocast
+    search against its fp32 search -- the yardstick -- and each engine's search against the reference's search of its precision."""
     import torch
     from hanabizero_amd import cytree
     from hanabizero_amd.config import make_config
@@ -134,11 +152,17 @@ def search_divergence(game, dtype, roots=256, simulations=50, device="cuda", see
     net.eval()
     rng = np.random.RandomState(seed)
     A = cfg.action_space_size
-    obs = torch.from_numpy((rng.rand(roots, cfg.obs_shape) < 0.3).astype(np.float32)).to(device)
-    noise = torch.from_numpy(rng.dirichlet([cfg.root_dirichlet_alpha] * A, roots).astype(np.float32)).to(device)
-    legal = torch.from_numpy((rng.rand(roots, A) < 0.7).astype(np.uint8))
-    legal[:, 0] = 1
-    legal = legal.to(device)
+    obs_h = (rng.rand(roots, cfg.obs_shape) < 0.3)
+    noise_h = rng.dirichlet([cfg.root_dirichlet_alpha] * A, roots).astype(np.float32)
+    legal_h = (rng.rand(roots, A) < 0.7).astype(np.uint8)
+    legal_h[:, 0] = 1
+    fx = search_fixture(game) if (roots, seed, simulations) == (512, 0, 50) else None
+    if fx is not None:  # (the fixture's inputs ARE this recipe's: checked, then used)
+        assert np.array_equal(np.unpackbits(fx["obs_bits"], axis=1)[:, :cfg.obs_shape].astype(bool), obs_h)
+        assert np.array_equal(fx["noise"], noise_h) and np.array_equal(fx["legal"], legal_h) and int(fx["tie_seed"]) == seed + 1
+    obs = torch.from_numpy(obs_h.astype(np.float32)).to(device)
+    noise = torch.from_numpy(noise_h).to(device)
+    legal = torch.from_numpy(legal_h).to(device)
     res = {}
     for name, dt in (("ref", torch.float32), ("got", dtype)):
         eng = InferenceEngine(net, cfg.value_support.max, dtype=dt, device=device)
@@ -149,7 +173,15 @@ def search_divergence(game, dtype, roots=256, simulations=50, device="cuda", see
         res[name] = (r.distributions_tensor().cpu().numpy().astype(np.float64), r.values_tensor().cpu().numpy().astype(np.float64))
     (d0, v0), (d1, v1) = res["ref"], res["got"]
     assert (d0.sum(1) == simulations - 1).all() and (d1.sum(1) == simulations - 1).all()
-    tv = 0.5 * np.abs(d0 - d1).sum(1) / (simulations - 1)
-    return {"roots": roots, "simulations": simulations - 1, "argmax_agreement": float((d0.argmax(1) == d1.argmax(1)).mean()),
-            "visit_tv_mean": float(tv.mean()), "visit_tv_max": float(tv.max()), "identical_visit_counts": float((tv == 0).mean()),
-            "root_value_abs_diff_mean": float(np.abs(v0 - v1).mean())}
+    out = {"roots": roots, "simulations": simulations - 1}
+    out.update(_divergence(d0, v0, d1, v1, simulations - 1))
+    if fx is not None:
+        out["reference"] = {
+            # the reference's own fp16-autocast search against its fp32 search (core/mcts.py:38-40): the yardstick
+            "autocast_vs_fp32": _divergence(fx["dist_fp32"], fx["values_fp32"], fx["dist_autocast"], fx["values_autocast"], simulations - 1),
+            # the fp32 engine's search against the reference's fp32 search (nets 7e-5 apart: a near-tie flips now and then)
+            "fp32_engine_vs_reference_fp32": _divergence(fx["dist_fp32"], fx["values_fp32"], d0, v0, simulations - 1),
+            # the benched engine's search against the reference's search at each precision
+            "engine_vs_reference_fp32": _divergence(fx["dist_fp32"], fx["values_fp32"], d1, v1, simulations - 1),
+            "engine_vs_reference_autocast": _divergence(fx["dist_autocast"], fx["values_autocast"], d1, v1, simulations - 1)}
+    return out

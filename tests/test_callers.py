@@ -18,31 +18,26 @@ def _engine(game, sims, stack, dtype=torch.float32):
 
 
 def _oracle_search(cfg, eng, tree, hidden0, sims):
-    """run_multi of the non-fused engine path replayed through the oracle tree."""
-    N, A = tree.N, tree.A
-    pool = [hidden0]
-    for sim in range(sims - 1):
-        ix, iy, la = tree.traverse(sim, cfg.pb_c_base, cfg.pb_c_init, cfg.discount)
-        hid = torch.stack([pool[x][y] for x, y in zip(ix, iy)])
-        net_in = torch.zeros(N, eng.H + eng.onehot_cols, dtype=eng.dtype, device="cuda")
-        net_in[:, :eng.H] = hid
-        net_in[torch.arange(N), eng.H + torch.from_numpy(la).long()] = 1
-        h = torch.empty(N, eng.H, dtype=eng.dtype, device="cuda")
-        r_log, v_log, p_log = eng.recurrent_heads(net_in, h)
-        pool.append(h)
-        r, v = eng.support_to_scalar(r_log), eng.support_to_scalar(v_log)
-        lg = torch.nan_to_num(p_log[:, :A].float(), nan=0.0, posinf=float("inf"), neginf=float("-inf"))
-        tree.backprop(sim + 1, cfg.discount, r.cpu().numpy(), v.cpu().numpy(), lg.cpu().numpy())
+    """run_multi replayed through the oracle tree (tests/oracle_replay.py): the GEMM chain per simulation for fp32 engines, the
+    stand-alone fused MFMA inference for the 16-bit ones."""
+    from tests.oracle_replay import oracle_search
+    oracle_search(cfg, eng, tree, hidden0, sims)
 
 
-def test_evaluation_loop_matches_oracle_replay():
-    """core/test.py protocol: no noise, deterministic actions -> fully reproducible; 12 Hanabi-Small games to the end."""
+# fp32: the launch-per-phase search; fp16: the benched engine -- root inference through the fused tail, ONE persistent search kernel
+ENGINES = [("Hanabi-Small", torch.float32), ("Hanabi-Small", torch.float16), ("Hanabi-Full", torch.float16)]
+
+
+@pytest.mark.parametrize("game,dtype", ENGINES)
+def test_evaluation_loop_matches_oracle_replay(game, dtype):
+    """core/test.py protocol: no noise, deterministic actions -> fully reproducible; every game played to its end."""
     from hanabizero_amd.evaluate import test as run_test
     from oracle.cport import OracleEnv, OracleTree
-    cfg, eng = _engine("Hanabi-Small", 10, 2)
-    E, A, S, stack = 12, cfg.action_space_size, cfg.num_simulations, cfg.stacked_observations
+    cfg, eng = _engine(game, 10 if game == "Hanabi-Small" else 16, 2 if game == "Hanabi-Small" else 4, dtype)
+    assert (eng.fused is not None) == (dtype != torch.float32)
+    E, A, S, stack = 12 if game == "Hanabi-Small" else 21, cfg.action_space_size, cfg.num_simulations, cfg.stacked_observations
     scores, steps = run_test(cfg, eng, test_episodes=E, tie_seed=5)
-    env = OracleEnv("Hanabi-Small", np.arange(E))
+    env = OracleEnv(game, np.arange(E))
     env.reset()
     obs, legal = env.observe()
     windows = [[obs[i].copy() for _ in range(stack)] for i in range(E)]
@@ -67,10 +62,11 @@ def test_evaluation_loop_matches_oracle_replay():
     assert scores == final.tolist() and steps == nsteps.tolist()
 
 
-def test_reanalyze_policy_targets_match_oracle_replay():
+@pytest.mark.parametrize("game,dtype", ENGINES)
+def test_reanalyze_policy_targets_match_oracle_replay(game, dtype):
     from hanabizero_amd.reanalyze import prepare_policy_re
     from oracle.cport import OracleTree
-    cfg, eng = _engine("Hanabi-Small", 12, 2)
+    cfg, eng = _engine(game, 12 if game == "Hanabi-Small" else 50, 2 if game == "Hanabi-Small" else 4, dtype)
     A, U = cfg.action_space_size, cfg.num_unroll_steps + 1
     P = 5
     B = P * U

@@ -131,8 +131,14 @@ NET_ERROR_BOUND = {
 }
 # search level (tests/netgold.py::search_divergence, 512 roots x 49 simulations against the fp32 engine's search):
 # (minimum share of roots with the same most-visited action, maximum mean total-variation distance of the visit distributions)
-# measured r03 over several root sets: fp16 0.961-0.986 / 0.0016-0.0080, bf16 0.857-0.927 / 0.0097-0.029
-SEARCH_DIVERGENCE_BOUND = {torch.float16: (0.93, 0.015), torch.bfloat16: (0.78, 0.05)}
+# fp16 -- the reference's own search precision -- is held to a yardstick DERIVED FROM THE REFERENCE (r04): the same 512 roots searched
+# by the reference's nets + tree in fp32 and under fp16 autocast (tests/golden/search_*_autocast.npz, tools/gen_golden.py::
+# gen_search_autocast: Small 0.975 / 0.0027, Full 0.951 / 0.0094).  bf16 is not a format the reference searches in: its bound stays
+# the measured one (r03 over several root sets: 0.857-0.927 / 0.0097-0.029).
+SEARCH_DIVERGENCE_BOUND = {torch.bfloat16: (0.78, 0.05)}
+# one binomial standard deviation of an agreement share near 0.95 measured on 512 roots: the two searches being compared are
+# different computations of the same roots, each flipping its own near-ties
+SEARCH_AGREEMENT_SLACK, SEARCH_TV_SLACK = 0.01, 1.1
 
 
 @pytest.mark.gpu
@@ -180,8 +186,20 @@ def test_search_level_divergence_of_the_16_bit_engines(game, dtype):
     from tests.netgold import search_divergence
     d = search_divergence(game, dtype, roots=512)
     print("search divergence %s %s: %s" % (game, dtype, d))
-    agree, tv = SEARCH_DIVERGENCE_BOUND[dtype]
-    assert d["argmax_agreement"] >= agree and d["visit_tv_mean"] <= tv, d
+    ref = d["reference"]
+    # the fp32 engine's search IS the reference's fp32 search up to the rare near-tie that nets 7e-5 apart flip
+    assert ref["fp32_engine_vs_reference_fp32"]["argmax_agreement"] >= 0.99 and ref["fp32_engine_vs_reference_fp32"]["visit_tv_mean"] <= 0.002, ref
+    if dtype == torch.float16:
+        # no further from the fp32 search than the reference's own fp16-autocast search is from its fp32 search ...
+        y = ref["autocast_vs_fp32"]
+        assert d["argmax_agreement"] >= y["argmax_agreement"] - SEARCH_AGREEMENT_SLACK, (d, y)
+        assert d["visit_tv_mean"] <= y["visit_tv_mean"] * SEARCH_TV_SLACK, (d, y)
+        # ... and measured against the REFERENCE's fp32 search itself (not the fp32 engine's) no worse either
+        e = ref["engine_vs_reference_fp32"]
+        assert e["argmax_agreement"] >= y["argmax_agreement"] - SEARCH_AGREEMENT_SLACK and e["visit_tv_mean"] <= y["visit_tv_mean"] * SEARCH_TV_SLACK, (e, y)
+    else:
+        agree, tv = SEARCH_DIVERGENCE_BOUND[dtype]
+        assert d["argmax_agreement"] >= agree and d["visit_tv_mean"] <= tv, d
 
 
 @pytest.mark.gpu

@@ -10,12 +10,14 @@ pytestmark = pytest.mark.gpu
 from tests.restate import ref_select_action  # noqa: E402  (checked against the reference: tests/test_reference_callers.py)
 
 
-def make(game, N, sims, stack, dtype, use_graph, seed=3, peaked=False, fused_tail=True):
+def make(game, N, sims, stack, dtype, use_graph, seed=3, peaked=False, fused_tail=True, max_moves=None):
     from hanabizero_amd.config import make_config
     from hanabizero_amd.model import InferenceEngine
     from hanabizero_amd.selfplay import SelfPlayActor
     from tests.netgold import fill_state_dict
     cfg = make_config(game, simulations=sims, stack=stack, p_mcts_num=N)
+    if max_moves is not None:  # (trajectory rows of another length: the row copies' alignment cases)
+        cfg.max_moves = cfg.test_max_moves = max_moves
     net = cfg.get_uniform_network()
     net.load_state_dict({k: torch.from_numpy(v) for k, v in fill_state_dict(net.state_dict()).items()})
     if peaked is True:  # a policy head that all but always proposes one action and constant values / rewards: every simulation
@@ -112,6 +114,99 @@ def test_actor_matches_oracle_replay(game, N, sims, stack, steps):
         assert len(gh) == r["len"] and gh.obs_history.shape == (r["len"] + stack, D)
         assert (gh.obs_history[stack - 1:] == np.array(h["obs"])).all()
         assert np.allclose(gh.child_visits.sum(1), 1.0) and gh.legal_actions.shape == (r["len"] + 1, A)
+
+
+@pytest.mark.parametrize("game,N,sims,stack,steps,dtype,use_graph", [
+    ("Hanabi-Full", 48, 50, 4, 30, torch.float16, True),     # the benched lock-step: fp16 fused engine, k_search, fused tail, hipGraph
+    ("Hanabi-Small", 40, 12, 2, 45, torch.float16, True),    # (A = 11: byte-misaligned legal rows in the hand-over; several games per env)
+    ("Hanabi-Full-5p", 24, 16, 4, 45, torch.float16, True),
+    ("Hanabi-Full", 24, 12, 4, 20, torch.bfloat16, False)])  # the same kernels enqueued one by one
+def test_benched_lock_step_matches_oracle_replay(game, N, sims, stack, steps, dtype, use_graph):
+    """The exact lock-step bench.py times -- root inference (hipBLASLt + the fused MFMA tail), k_prepare, ONE persistent search
+    kernel, k_move_tail_a / k_move_tail_b with the next move's draws, replayed as a hipGraph -- against an independent replay of
+    every move through the ORACLE tree + ORACLE env + the numpy restatement of select_action, fed by the stand-alone recurrent
+    inference (tests/oracle_replay.py).  The actor is only LOOKED at between lock-steps (noise / uniforms it drew for the coming
+    move, its window and legal masks, the actions it chose); nothing of its state enters the oracle side except the draws."""
+    from oracle.cport import OracleEnv, OracleTree
+    from hanabizero_amd.game import GameHistory
+    from hanabizero_amd.selfplay import unpack_record
+    from tests.oracle_replay import oracle_search
+    cfg, eng, actor = make(game, N, sims, stack, dtype, use_graph=use_graph, seed=3)
+    assert eng.fused is not None and actor._tail_is_fused()
+    A, D = cfg.action_space_size, cfg.obs_dim
+    snaps = []
+
+    def snap():
+        torch.cuda.synchronize()
+        snaps.append({k: getattr(actor, k).clone() for k in ("noise", "uniform", "stack_buf", "legal", "action", "entropy")})
+
+    body = actor._step_body
+
+    def looked_at(draw=True):  # (the two eager lock-steps inside the graph capture are moves like any other)
+        body(draw)
+        if not torch.cuda.is_current_stream_capturing():
+            snap()
+
+    actor._step_body = looked_at
+    actor._draw()
+    actor._drawn = True
+    snap()
+    while actor.total_moves < steps * N:
+        actor.step()
+        if actor.use_graph:
+            snap()
+    assert len(snaps) == steps + 1 and (not use_graph or actor._graph is not None)
+    assert int(actor.illegal_steps) == 0
+    # ---- the oracle plays the same moves
+    oenv = OracleEnv(game, 3 + np.arange(N))
+    oenv.reset()
+    obs, legal = oenv.observe()
+    windows = [[obs[i].copy() for _ in range(stack)] for i in range(N)]
+    hist = [dict(obs=[obs[i].copy()], legal=[legal[i].copy()], action=[], reward=[], visits=[], value=[]) for i in range(N)]
+    finished = []
+    for step in range(steps):
+        pre, post = snaps[step], snaps[step + 1]
+        noise, uni = pre["noise"].cpu().numpy(), pre["uniform"].cpu().numpy()
+        stack_in = np.stack([np.concatenate(w) for w in windows]).astype(np.float32)
+        assert (pre["stack_buf"][:, :, :D].reshape(N, -1).float().cpu().numpy() == stack_in).all(), step
+        assert (pre["legal"].cpu().numpy() == legal).all(), step
+        win = np.zeros((N, stack, actor.Dp), np.float32)
+        win[:, :, :D] = stack_in.reshape(N, stack, D)
+        _, l0, h0 = eng.initial(torch.from_numpy(win.reshape(N, -1)).cuda(), padded=actor.Dp != D)
+        tree = OracleTree(N, A, sims, seed=3, value_delta_max=cfg.value_delta_max)
+        tree.prepare(cfg.root_exploration_fraction, noise, np.zeros(N, np.float32), l0.cpu().numpy(), legal)
+        oracle_search(cfg, eng, tree, h0, sims)
+        dist, vals = tree.distributions(), tree.values()
+        acts = np.zeros(N, np.int32)
+        for i in range(N):
+            a, ent, masked = ref_select_action(dist[i], legal[i], uni[i])
+            acts[i] = a
+            hist[i]["visits"].append(masked), hist[i]["value"].append(vals[i]), hist[i]["action"].append(a)
+            assert abs(ent - float(post["entropy"][i])) < 1e-12
+        assert (post["action"].cpu().numpy() == acts).all(), (step, post["action"].cpu().numpy(), acts)
+        rew, done, score = oenv.step(acts)
+        obs, legal = oenv.observe()
+        for i in range(N):
+            hist[i]["reward"].append(rew[i]), hist[i]["obs"].append(obs[i].copy()), hist[i]["legal"].append(legal[i].copy())
+            windows[i] = windows[i][1:] + [obs[i].copy()]
+        if done.any():
+            oenv.reset(done)
+            obs, legal = oenv.observe()
+            for i in np.nonzero(done)[0]:
+                finished.append((i, score[i], hist[i]))
+                hist[i] = dict(obs=[obs[i].copy()], legal=[legal[i].copy()], action=[], reward=[], visits=[], value=[])
+                windows[i] = [obs[i].copy() for _ in range(stack)]
+    rec = actor.drain()
+    assert len(finished) > 0 and rec is not None and rec["meta"].shape[0] == len(finished)
+    for g, (i, score, h) in enumerate(finished):
+        r = unpack_record(rec, g)
+        assert (r["env_id"], r["score"], r["len"]) == (i, score, len(h["action"]))
+        assert (r["action"] == h["action"]).all() and (r["reward"] == h["reward"]).all()
+        assert (r["visits"] == np.array(h["visits"])).all()
+        assert (r["value"].view(np.uint32) == np.array(h["value"], np.float32).view(np.uint32)).all()
+        assert (r["legal"] == np.array(h["legal"])).all()
+        gh = GameHistory.from_packed(r, None, cfg)
+        assert (gh.obs_history[stack - 1:] == np.array(h["obs"])).all()
 
 
 def test_graph_replay_equals_eager():
@@ -374,11 +469,17 @@ def test_packed_drain_equals_drain():
             assert again[k].dtype == ragged[k].dtype and np.array_equal(again[k], ragged[k]), k
 
 
-@pytest.mark.parametrize("game,N,stack,dtype,moves", [("Hanabi-Small", 96, 2, torch.bfloat16, 28), ("Hanabi-Full", 70, 4, torch.float16, 28),
-                                                       ("Hanabi-Full-5p", 37, 4, torch.float32, 70),
-                                                       # (enough envs that the slot prefix of a late workgroup takes several trips)
-                                                       ("Hanabi-Small", 2501, 1, torch.float16, 9)])
-def test_fused_launches_equal_their_separate_calls(game, N, stack, dtype, moves):
+@pytest.mark.parametrize("game,N,stack,dtype,moves,max_moves", [
+    ("Hanabi-Small", 96, 2, torch.bfloat16, 28, None), ("Hanabi-Full", 70, 4, torch.float16, 28, None),
+    ("Hanabi-Full-5p", 37, 4, torch.float32, 70, None),
+    # (enough envs that the slot prefix of a late workgroup takes several trips)
+    ("Hanabi-Small", 2501, 1, torch.float16, 9, None),
+    # trajectory rows whose lengths are not multiples of 4 bytes (A = 11: legal rows of 6 * 11 = 66 B at byte-misaligned addresses,
+    # action / reward rows of 5 or 13 B) in games that DO reach the last row (longer ones clamp to it, the same way in all
+    # three forms): the hand-over must move every byte of every row (r03's copy_rows_block dropped the last n % 4)
+    # (Hanabi-Small has one life: random-init play ends most games within five moves; Hanabi-Full's action rows are 13 B here)
+    ("Hanabi-Small", 96, 2, torch.bfloat16, 20, 5), ("Hanabi-Full", 70, 4, torch.float16, 40, 13)])
+def test_fused_launches_equal_their_separate_calls(game, N, stack, dtype, moves, max_moves):
     """The lock-step's tail three ways: (tail) the two launches of include/hz_movetail.h, one wave per env from the root read-out
     to the next move's window; (fused) one launch per phase with the fusions of r01 (hz_actor_begin_move_draw; hz_env_reset_rows
     carrying the flush); (separate) every entry point on its own (hz_actor_draw + hz_actor_begin_move; hz_actor_flush +
@@ -388,7 +489,7 @@ def test_fused_launches_equal_their_separate_calls(game, N, stack, dtype, moves)
     import ctypes as C
     recs, states = [], []
     for form in ("tail", "fused", "separate"):
-        cfg, eng, actor = make(game, N, 10, stack, dtype, use_graph=False, seed=21, fused_tail=form == "tail")
+        cfg, eng, actor = make(game, N, 10, stack, dtype, use_graph=False, seed=21, fused_tail=form == "tail", max_moves=max_moves)
         if form == "separate":
             def reset_then(mask, rows=None, _env=actor.env, _actor=actor):  # flush and reset as two launches
                 check(lib.hz_actor_flush(C.byref(_actor.bufs), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "flush")
@@ -407,9 +508,15 @@ def test_fused_launches_equal_their_separate_calls(game, N, stack, dtype, moves)
                     noise=actor.noise, uniform=actor.uniform, move_count=actor.move_count, out_count=actor.out_count,
                     counts=actor.counts, values=actor.values, action=actor.action, slot=actor.slot,
                     num_finished=actor.num_finished, illegal=actor.illegal_steps, **{"traj_" + k: v for k, v in actor.traj.items()})
+        n_out = min(int(actor.out_count[0]), actor.cap)  # the outbox slots in use, whole rows: every byte the hand-over moved
+        live.update({"out_" + k: v[:n_out] for k, v in actor.out.items()})
+        live["out_meta"] = actor.out_meta[:n_out]
         states.append({k: v.clone() for k, v in live.items()})
         recs.append(actor.drain())
     assert recs[0]["meta"].shape[0] > (20 if game == "Hanabi-Small" else 3)
+    if max_moves is not None:  # (the case is about the last row: games did reach it, and its last bytes are not all zero)
+        assert int(recs[0]["meta"][:, 0].max()) >= max_moves
+        assert int(states[0]["out_legal"][:, max_moves, -3:].sum()) > 0 and int(states[0]["out_action"][:, max_moves - 1].abs().sum()) > 0
     for other in (1, 2):
         for k in recs[0]:
             assert np.array_equal(recs[0][k], recs[other][k]), (other, k)

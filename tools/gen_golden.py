@@ -13,7 +13,10 @@ The fixtures are DATA: inputs and the reference's outputs.  No reference source 
   nets_<game>.npz   reference MuZeroNet / MuZeroNetFull (config/hanabi_control/model.py, loaded by file path)
                     state_dict + inputs + initial/recurrent inference outputs, CPU fp32, eval mode.
 
-Usage: python tools/gen_golden.py [--only tree|env|nets|nets_autocast]
+  search_<game>_autocast.npz   512 roots searched by the reference's nets + tree in fp32 and under fp16 autocast (visit counts,
+                    root values): the search-level yardstick of the 16-bit engines.
+
+Usage: python tools/gen_golden.py [--only tree|env|nets|nets_autocast|search_autocast]
 """
 import argparse
 import os
@@ -317,6 +320,70 @@ def gen_nets_autocast():
         print("nets autocast(fp16)", game, "worst |autocast - fp32| / max(1, |fp32|) = %.3g" % worst)
 
 
+def search_inputs(game, roots, seed):
+    """The root set of tests/netgold.py::search_divergence (same generator calls, same order)."""
+    D, A, stack = {"Hanabi-Small": (193, 11, 1), "Hanabi-Full": (785, 20, 4)}[game]
+    rng = np.random.RandomState(seed)
+    obs = (rng.rand(roots, D * stack) < 0.3)
+    noise = rng.dirichlet([0.3] * A, roots).astype(np.float32)
+    legal = (rng.rand(roots, A) < 0.7).astype(np.uint8)
+    legal[:, 0] = 1
+    return obs, noise, legal
+
+
+def gen_search_autocast(roots=512, S=50, seed=0):
+    """Search-level yardstick: the same `roots` root positions searched S - 1 simulations by the REFERENCE -- its nets
+    (config/hanabi_control/model.py, unmodified) driving its tree (core/ctree through oracle/_ref, tie-breaks bound to
+    include/hz_tiebreak.h) with the loop of core/mcts.py:11-57 and the root preparation of core/selfplay_worker.py:268-282 --
+    once in fp32 and once under fp16 autocast, the precision the reference searches with (mcts.py:38-40, selfplay_worker.py:
+    269-271).  What the fixture pins: how far the reference's OWN fp16 search moves from its fp32 search on these roots (visit
+    counts, root values); tests/test_model.py holds the fp16 engine's divergence from the fp32 engine to that."""
+    import contextlib
+    import importlib.util
+    import torch
+    sys.path.insert(0, "/root/reference")
+    spec = importlib.util.spec_from_file_location("ref_hanabi_model", "/root/reference/config/hanabi_control/model.py")
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    from tests.netgold import fill_state_dict
+    for game, cls, sup in [("Hanabi-Small", m.MuZeroNet, 25), ("Hanabi-Full", m.MuZeroNetFull, 100)]:
+        obs, noise, legal = search_inputs(game, roots, seed)
+        A = noise.shape[1]
+        inv = lambda x, s=sup: inverse_scalar_transform(x.float(), -s, s)
+        net = cls(obs.shape[1], A, 2 * sup + 1, 2 * sup + 1, inv, inv)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in fill_state_dict(net.state_dict()).items()})
+        net.eval()
+        out = dict(obs_bits=np.packbits(obs, axis=1), noise=noise, legal=legal, roots=roots, simulations=S, seed=seed, tie_seed=seed + 1)
+        for tag in ("fp32", "autocast"):
+            ctx = (lambda: torch.autocast("cpu", dtype=torch.float16)) if tag == "autocast" else contextlib.nullcontext
+            with torch.no_grad():
+                with ctx():
+                    o0 = net.initial_inference(torch.from_numpy(obs).float())             # selfplay_worker.py:269-273
+                logits0 = np.asarray(o0.policy_logits, np.float32)
+                tree = RefTree(roots, A, S, mode=1, seed=seed + 1, value_delta_max=DELTA)
+                tree.prepare(FRAC, noise, np.zeros(roots, np.float32), logits0, legal.astype(np.int32))  # :278-280 (reward_pool = zeros)
+                pool = [o0.hidden_state]                                                   # mcts.py:18
+                for sim in range(S - 1):                                                   # mcts.py:24-26
+                    ix, iy, la = tree.traverse(sim, PB_C_BASE, PB_C_INIT, DISCOUNT)
+                    hid = np.asarray([pool[x][y] for x, y in zip(ix, iy)])                 # mcts.py:31-33
+                    with ctx():
+                        o = net.recurrent_inference(torch.from_numpy(hid), torch.from_numpy(np.asarray(la)).unsqueeze(1).long())
+                    lg = np.array(o.policy_logits, np.float32)
+                    lg[np.isnan(lg)] = 0.0                                                 # mcts.py:48-49
+                    pool.append(o.hidden_state)
+                    tree.backprop(sim + 1, DISCOUNT, np.asarray(o.reward, np.float32).reshape(-1), np.asarray(o.value, np.float32).reshape(-1), lg)
+                if tag == "autocast":
+                    assert pool[-1].dtype == np.float16, "autocast did not reach the nets"
+                out["dist_" + tag], out["values_" + tag] = tree.distributions().astype(np.int16), tree.values()
+                out["logits0_" + tag] = logits0
+        d0, d1 = out["dist_fp32"].astype(np.float64), out["dist_autocast"].astype(np.float64)
+        assert (d0.sum(1) == S - 1).all() and (d1.sum(1) == S - 1).all()
+        tv = 0.5 * np.abs(d0 - d1).sum(1) / (S - 1)
+        print("search autocast(fp16) vs fp32, reference nets + reference tree, %s: same most-visited action %.4f, mean TV %.5f, "
+              "identical visit counts %.4f" % (game, (d0.argmax(1) == d1.argmax(1)).mean(), tv.mean(), (tv == 0).mean()))
+        np.savez_compressed(os.path.join(GOLD, "search_%s_autocast.npz" % game), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -344,6 +411,8 @@ def main():
         gen_nets()
     if args.only in ("", "nets", "nets_autocast"):
         gen_nets_autocast()
+    if args.only in ("", "search_autocast"):
+        gen_search_autocast()
 
 
 if __name__ == "__main__":

@@ -4,7 +4,8 @@
 The kernels that inline the hand-scheduled k-loop (hz_mlp_dev.h: k_search*, k_mlp_recurrent16) keep weight fragments in flight in
 the fixed registers v[96:127], named only inside inline asm; the kernels are compiled with amdgpu_num_vgpr(96), which is a
 budget, not a guarantee: under register pressure the allocator was seen to place an address computation in v[96:99] (r03, the
-in-turn 32-row kernel).  This compiles the two translation units to assembly and fails if any instruction OUTSIDE an inline-asm
+in-turn 32-row kernel).  This compiles the two translation units to assembly -- with the compiler and the flags csrc/Makefile builds the library with
+(`make print-flags`) -- and fails if any instruction OUTSIDE an inline-asm
 block of those kernels names a register >= v96.  __graft_entry__.build() runs it."""
 import os
 import re
@@ -17,14 +18,24 @@ SRC = os.path.join(ROOT, "hanabizero_amd", "csrc")
 PAT = re.compile(r"\bv(9[6-9]|1[01][0-9]|12[0-7])\b|v\[(9[6-9]|1[01][0-9]|12[0-7]):")
 
 
+def build_flags():
+    """(hipcc, flags) the library itself is built with, asked of csrc/Makefile (`make print-flags`): one flag list, not two."""
+    ask = lambda target: subprocess.check_output(["make", "-s", "--no-print-directory", "-C", SRC, target], text=True).split()
+    hipcc, flags = ask("print-hipcc"), ask("print-flags")
+    assert len(hipcc) == 1 and "--offload-arch=gfx950" in flags and "-O3" in flags, (hipcc, flags)
+    return hipcc[0], flags
+
+
 def scan():
     bad, seen = [], 0
+    hipcc, flags = build_flags()
     with tempfile.TemporaryDirectory() as tmp:
         for unit in ("hz_search.hip", "hz_mlp.hip"):
             out = os.path.join(tmp, unit + ".s")
-            subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
-                                   "-fhip-fp32-correctly-rounded-divide-sqrt", "-w", "-I" + SRC, "-I" + os.path.join(ROOT, "include"),
-                                   "-S", "--cuda-device-only", "-o", out, os.path.join(SRC, unit)], stderr=subprocess.DEVNULL)
+            run = subprocess.run([hipcc] + flags + ["-w", "-S", "--cuda-device-only", "-o", out, os.path.join(SRC, unit)],
+                                 stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            if run.returncode != 0:
+                raise RuntimeError("scan_ring_registers: %s did not compile to assembly:\n%s" % (unit, run.stdout[-4000:]))
             txt = open(out).read()
             for name in re.findall(r"^(_Z\w*k_(?:search|mlp_recurrent16)\w*):", txt, re.M):
                 i = txt.index("\n" + name + ":")
