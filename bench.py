@@ -112,7 +112,14 @@ def cpu_baseline(game, A, S, trees, moves, workload, max_procs):
     t0 = time.perf_counter()
     rs = [result(p) for p in [spawn("both", per, max(2, moves // 2)) for _ in range(procs)]]
     wall = time.perf_counter() - t0
-    return {"value": one["moves_per_s"], "unit": "moves/s", "cores": 1, "kind": "port",
+    ref = None
+    try:  # the genuine reference beside the port, timed where the reference exists (tools/gen_golden.py --only cpu_rates); a pointer
+        # with its provenance, like roofline.traffic_source -- nothing of it is measured in this run
+        ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_cpu_reference_vs_port.json")))
+        ref["source"] = "profiles/r04_cpu_reference_vs_port.json"
+    except (OSError, ValueError):
+        pass
+    return {"value": one["moves_per_s"], "unit": "moves/s", "cores": 1, "kind": "port", "reference_in_container": ref,
             "sample": "oracle tree+env (no nets), %d envs x %d moves x %d sims, %.1f s on 1 core" % (trees, moves, S - 1, one["seconds"]),
             "cpu_model": cpu_model(), "machine_cores": os.cpu_count(), "cores_available": avail,
             "tree_only": {"value": tree["moves_per_s"], "unit": "root-searches/s", "cores": 1,
@@ -817,6 +824,11 @@ def main():
             r.release()
             del r
         out["also"] = also
+        # the other 16-bit format's figure for the SAME workload, at the top level beside `value` (BASELINE's configs name bf16, the
+        # reference's own search runs in fp16: both are measured in every default run)
+        for name, entry in also.items():
+            if entry["workload"] == args.workload and entry["net"] == args.net and entry["dtype"] != args.dtype:
+                out["value_" + entry["dtype"]] = entry["value"]
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:  # (rank 0 at N = 1 only)
         cfgA = {"Hanabi-Small": 11, "Hanabi-Full": 20, "Hanabi-Full-5p": 48}[game]

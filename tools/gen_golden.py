@@ -16,7 +16,7 @@ The fixtures are DATA: inputs and the reference's outputs.  No reference source 
   search_<game>_autocast.npz   512 roots searched by the reference's nets + tree in fp32 and under fp16 autocast (visit counts,
                     root values): the search-level yardstick of the 16-bit engines.
 
-Usage: python tools/gen_golden.py [--only tree|env|nets|nets_autocast|search_autocast]
+Usage: python tools/gen_golden.py [--only tree|env|nets|nets_autocast|search_autocast|cpu_rates]
 """
 import argparse
 import os
@@ -384,6 +384,84 @@ def gen_search_autocast(roots=512, S=50, seed=0):
         np.savez_compressed(os.path.join(GOLD, "search_%s_autocast.npz" % game), **out)
 
 
+def gen_cpu_rates(N=1024, A=20, S=50, moves=2, env_steps=30):
+    """The baseline's baseline: bench.py's `cpu_baseline` times the plain-C PORT
+    (oracle/*.c) on the GPU box, where the reference cannot travel.  Here, in the authoring container, the GENUINE reference
+    (oracle/_ref: core/ctree/cnode.cpp + cminimax.cpp; envs/hanabi through its C API, driven per env as envs/hanabi/rl_env.py
+    drives it) and the port run the same bounded workload on ONE core, so that the port's speed can be read against the thing
+    it stands in for.  Written to profiles/r04_cpu_reference_vs_port.json; bench.py attaches it as
+    cpu_baseline.reference_in_container with its provenance."""
+    import json
+    import subprocess
+    import time
+    from oracle.cport import OracleEnv, OracleTree
+    rng = np.random.RandomState(0)
+    noises = rng.dirichlet([0.3] * A, N).astype(np.float32)
+    logits0 = rng.randn(N, A).astype(np.float32)
+    legal = (rng.rand(N, A) < 0.7).astype(np.int32)
+    legal[:, 0] = 1
+    rew = (rng.randint(-1, 2, (S - 1, N)) * (rng.rand(S - 1, N) < 0.3)).astype(np.float32)
+    val = (rng.rand(S - 1, N) * 25).astype(np.float32)
+    lg = rng.randn(S - 1, N, A).astype(np.float32)
+    zeros = np.zeros(N, np.float32)
+
+    def tree_rate(make):
+        best = 0.0
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for m in range(moves):
+                tree = make()
+                tree.prepare(FRAC, noises, zeros, logits0, legal)
+                for sim in range(S - 1):
+                    tree.traverse(sim, PB_C_BASE, PB_C_INIT, DISCOUNT)
+                    tree.backprop(sim + 1, DISCOUNT, rew[sim], val[sim], lg[sim])
+                d = tree.distributions()
+            best = max(best, N * moves / (time.perf_counter() - t0))
+        return best, d
+    ref_tree, d_ref = tree_rate(lambda: RefTree(N, A, S, mode=1, seed=0, value_delta_max=DELTA))
+    port_tree, d_port = tree_rate(lambda: OracleTree(N, A, S, seed=0, value_delta_max=DELTA))
+    assert np.array_equal(d_ref, d_port), "the two searches being timed differ"
+
+    # env: E games, scripted legal actions (the cpu_worker's rule), step + deals + the current player's observation + legal mask
+    E = 256
+    envs = [RefHanabiEnv("Hanabi-Full", seed=i) for i in range(E)]
+    legal_r = np.stack([e.reset()[2] for e in envs])
+    t0 = time.perf_counter()
+    for m in range(env_steps):
+        act = (legal_r * (1 + (np.arange(A) * 7 + m) % A)).argmax(1)
+        for i, e in enumerate(envs):
+            share, obs, r, done, score, lgl = e.step(int(act[i]))
+            if done:
+                share, obs, lgl = e.reset()
+            legal_r[i] = lgl
+    ref_env = E * env_steps / (time.perf_counter() - t0)
+    penv = OracleEnv("Hanabi-Full", np.arange(E))
+    penv.reset()
+    _, legal_p = penv.observe()
+    t0 = time.perf_counter()
+    for m in range(env_steps * 40):
+        act = (legal_p * (1 + (np.arange(A) * 7 + m) % A)).argmax(1).astype(np.int32)
+        _, done, _ = penv.step(act)
+        if done.any():
+            penv.reset(done)
+        _, legal_p = penv.observe()
+    port_env = E * env_steps * 40 / (time.perf_counter() - t0)
+    cpu = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][:1]
+    head = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
+    out = {"where": "authoring container (no GPU), one core, best of 3 (tree) / one pass (env)", "cpu_model": cpu[0] if cpu else "unknown",
+           "commit": head, "workload": "Hanabi-Full 2p: A = %d, %d trees x %d moves x %d simulations; %d envs" % (A, N, moves, S - 1, E),
+           "tree_only_root_searches_per_s": {"reference_cnode_cpp": ref_tree, "port_tree_oracle_c": port_tree, "port_over_reference": port_tree / ref_tree,
+                                             "note": "both through array-in/array-out C drivers (oracle/ref_tree_harness.cpp, oracle/tree_oracle.c): no Python list conversion, "
+                                                     "which is what the reference's Cython binding adds on top (cytree.pyx:87-94)"},
+           "env_only_steps_per_s": {"reference_c_api_per_env_via_ctypes": ref_env, "port_env_oracle_c_batched": port_env, "port_over_reference": port_env / ref_env,
+                                    "note": "reference: one StateApplyMove + deals + NewObservation + EncodeObservation (ASCII) + legal-move getters per env per step, the call "
+                                            "sequence of envs/hanabi/rl_env.py:292-442 for the current player only (rl_env.py encodes ALL players and builds dicts: slower still); "
+                                            "port: one C call per batch, bit-packed state"}}
+    path = os.path.join(ROOT, "profiles", "r04_cpu_reference_vs_port.json")
+    json.dump(out, open(path, "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -413,6 +491,8 @@ def main():
         gen_nets_autocast()
     if args.only in ("", "search_autocast"):
         gen_search_autocast()
+    if args.only == "cpu_rates":  # (a timing, not a fixture: only on request)
+        gen_cpu_rates()
 
 
 if __name__ == "__main__":
