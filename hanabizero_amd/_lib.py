@@ -109,6 +109,8 @@ def _load():
         "hz_mlp_poll_giveups": [C.POINTER(C.c_uint)],
         "hz_mlp_poll_giveups_async": [V, V],
         "hz_search_poll_giveups_async": [V, V],
+        # include/hz_replay.h
+        "hz_replay_windows": [V, I, V, V, I, I, I, V, I64, I64, I, V],
         # include/hz_netglue.h
         "hz_add_relu": [V, I64, V, I64, I, I, I, V],
         "hz_test_expf": [V, V, I64, V],

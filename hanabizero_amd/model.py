@@ -274,7 +274,7 @@ class InferenceEngine:
         self.dyn1_act = self._put(w1[:, self.H:].t())  # [A, H]
         # ... and the same layer over the [state | one-hot | 0-pad] rows the traverse kernel writes (K padded to 32)
         self.onehot_cols = ((self.A + 31) // 32) * 32
-        w1p = torch.zeros(w1.shape[0], self.H + self.onehot_cols)
+        w1p = torch.zeros(w1.shape[0], self.H + self.onehot_cols, device=w1.device)
         w1p[:, :w1.shape[1]] = w1
         self.dyn1p = _Lin(w1p, b1, self._put)
         self.dyn2, self.dyn3 = L(dyn.fc2, dyn.bn2), L(dyn.fc3, dyn.bn3)
@@ -288,8 +288,8 @@ class InferenceEngine:
         self.hp = self.h + 32
         wpad, bpad = [], []
         for w, b in zip(ws, bs):
-            wpad.append(torch.cat((w, torch.zeros(32, w.shape[1])), 0))
-            one = torch.zeros(32)
+            wpad.append(torch.cat((w, torch.zeros(32, w.shape[1], device=w.device)), 0))
+            one = torch.zeros(32, device=w.device)
             one[0] = 1.0
             bpad.append(torch.cat((b, one), 0))
         self.heads1p = _Lin(torch.cat(wpad, 0), torch.cat(bpad, 0), self._put)
@@ -313,9 +313,9 @@ class InferenceEngine:
                 self.fused_tail = FusedInitialTail(net, self, 16, 2) if self.full else None  # (the shape that has the arrival counters)
             else:  # same job tables, new numbers: into the tensors the kernels (and captured graphs) already point at
                 for (waves, tiles), chain in self._fused_shapes.items():
-                    chain.reload(FusedRecurrent(net, self, waves, tiles, host_only=True))
+                    chain.reload(FusedRecurrent(net, self, waves, tiles, values_only=True))
                 if self.fused_tail is not None:
-                    self.fused_tail.reload(FusedInitialTail(net, self, 16, 2, host_only=True))
+                    self.fused_tail.reload(FusedInitialTail(net, self, 16, 2, values_only=True))
             self.fused = self._fused_shapes[(4, 4)]
         self.version += 1
 
@@ -328,7 +328,7 @@ class InferenceEngine:
         Dp = (D + multiple - 1) // multiple * multiple
         w, b = self._rep0_folded
         assert w.shape[1] == stack * D, (w.shape, stack, D)
-        wp = torch.zeros(w.shape[0], stack, Dp)
+        wp = torch.zeros(w.shape[0], stack, Dp, device=w.device)
         wp[:, :, :D] = w.view(w.shape[0], stack, D)
         put = lambda t, _names=iter(("rep0p.w", "rep0p.b")): self._put(t, name=next(_names))
         self.rep0p = _Lin(wp.reshape(w.shape[0], stack * Dp), b, put)
@@ -348,7 +348,7 @@ class InferenceEngine:
         """[(W [o, h], b [o])] * 3 -> Wt [3, hp, out_width] in the engine dtype for torch.bmm over the three head
         blocks: rows 0..h-1 = W^T, row h = b (multiplied by the constant-one input column), other rows 0; with
         carry_one the output keeps a constant-one column at index h for the next layer's bias."""
-        out = torch.zeros(3, self.hp, out_width)
+        out = torch.zeros(3, self.hp, out_width, device=folded[0][0].device)
         for k, (w, b) in enumerate(folded):
             out[k, :w.shape[1], :w.shape[0]] = w.t()
             out[k, self.h, :b.shape[0]] = b
@@ -487,34 +487,48 @@ MLP_RELU, MLP_ACTION_ROW, MLP_BARRIER, MLP_STORE_HIDDEN, MLP_SIGNAL, MLP_BLOCKWI
 MLP_F32_OUT = 2048
 
 
+_FRAG_INDEX = {}
+
+
 def _pack_fragments(wblk, ks, tiles=4):
     """W [<=16*tiles, <=32*ks] fp32 -> [ks][tiles][64 lanes][8] (the A-operand fragments of
     v_mfma_f32_16x16x32_bf16: lane l of tile t at k-step s holds W[16t + (l & 15)][32s + 8(l >> 4) + j], j = 0..7),
-    flattened."""
-    Wp = torch.zeros(16 * tiles, 32 * ks)
+    flattened.  Runs where `wblk` lives (the host at the first build, the GPU when a learner's weights are taken over in place:
+    InferenceEngine.load); the gather index of a (ks, tiles) shape is built once per device."""
+    dev = wblk.device
+    key = (ks, tiles, dev)
+    flat = _FRAG_INDEX.get(key)
+    if flat is None:
+        s = torch.arange(ks).view(ks, 1, 1, 1)
+        t = torch.arange(tiles).view(1, tiles, 1, 1)
+        lane = torch.arange(64).view(1, 1, 64, 1)
+        j = torch.arange(8).view(1, 1, 1, 8)
+        n = (16 * t + (lane & 15)).expand(ks, tiles, 64, 8)
+        k = (32 * s + 8 * (lane >> 4) + j).expand(ks, tiles, 64, 8)
+        flat = _FRAG_INDEX[key] = (n * (32 * ks) + k).reshape(-1).to(dev)
+    if tuple(wblk.shape) == (16 * tiles, 32 * ks):
+        return wblk.reshape(-1)[flat] if wblk.is_contiguous() else wblk.contiguous().view(-1)[flat]
+    Wp = torch.zeros(16 * tiles, 32 * ks, device=dev)
     Wp[:wblk.shape[0], :wblk.shape[1]] = wblk
-    s = torch.arange(ks).view(ks, 1, 1, 1)
-    t = torch.arange(tiles).view(1, tiles, 1, 1)
-    lane = torch.arange(64).view(1, 1, 64, 1)
-    j = torch.arange(8).view(1, 1, 1, 8)
-    n = (16 * t + (lane & 15)).expand(ks, tiles, 64, 8)
-    k = (32 * s + 8 * (lane >> 4) + j).expand(ks, tiles, 64, 8)
-    return Wp[n, k].reshape(-1)
+    return Wp.view(-1)[flat]
 
 
 class _FusedChain:
     """A chain of Linear(+folded BN)(+residual)(+ReLU) layers as the job table + per-wave weight streams of the fused
     MFMA kernel (include/hz_mlp.h).  Subclasses describe the layers with add_dense / add_group and call _finish."""
 
-    def __init__(self, engine, waves, tiles, host_only=False):
+    def __init__(self, engine, waves, tiles, host_only=False, values_only=False):
         """waves x tiles: the workgroup shape of the kernel -- `waves` wavefronts, each producing `tiles` 16-column
         MFMA tiles per job (4 x 4 stand-alone, 16 x 2 inside the persistent search kernel).  Same arithmetic per
         output column either way (k accumulates in the same order), so the shapes give identical bits.
-        host_only: build the tables on the host only (the source of another chain's reload())."""
+        host_only: build the tables without moving them to the engine's device (the source of another chain's reload()).
+        values_only (implies host_only): only the NUMBERS -- weight streams, biases, action table -- wherever the module's
+        parameters live (on the GPU for a learner's module: nothing crosses PCIe); the job table and its synchronisation plan
+        (mlp_sync: two thirds of a full build's host time) depend on the layer shapes alone and are the built chain's."""
         assert engine.dtype in (torch.bfloat16, torch.float16), "the fused kernel computes in bf16 or fp16 (fp32 accumulate)"
         assert (waves, tiles) in ((4, 4), (8, 4), (16, 2))
         self.engine, self.device, self.waves, self.tiles = engine, engine.device, waves, tiles
-        self.host_only = host_only
+        self.host_only, self.values_only = host_only or values_only, values_only
         self.cw = 16 * tiles   # output columns of one job
         self._jobs = []        # [pass] -> dict(entries [wave] -> dict or None, barrier, store_hidden)
         self.blockwise = (waves, tiles) == (16, 2) and os.environ.get("HANABIZERO_MLP_BLOCKWISE", "1") != "0"
@@ -622,6 +636,8 @@ class _FusedChain:
                     load[w] += e["ks"]
                 assert all(e["ks"] == ents[0]["ks"] for e in ents), "jobs of one pass share their K"
             rows.append(row)
+        if self.values_only:
+            return self._values_only(rows, A)
         # synchronisation between the passes: barriers, except -- 16 x 2 shape -- blockwise boundaries (decided in add_dense)
         # and per-job waits (decided here from the jobs' column ranges, and proven race-free: mlp_sync)
         pass_flags = [(MLP_BARRIER if job["barrier"] else 0) | (MLP_STORE_HIDDEN if job["store_hidden"] else 0) |
@@ -666,7 +682,7 @@ class _FusedChain:
                 assert e["ks"] % 8 == 0, "K must be a multiple of 256 (8 k-steps)"
                 streams[wave].append(_pack_fragments(e["w"], e["ks"], tiles))
                 bias_off = cw * len(bias_chunks)
-                bc = torch.zeros(cw)
+                bc = torch.zeros(cw, device=e["b"].device)
                 bc[:e["b"].shape[0]] = e["b"]
                 bias_chunks.append(bc)
                 if e["act"] is not None:
@@ -682,22 +698,7 @@ class _FusedChain:
                 table.append(MlpJob(ks=e["ks"], src_off=e["src"], dst_off=e["dst"],
                                     res_off=-1 if e["res"] is None else e["res"], bias_off=bias_off, flags=flags,
                                     reserved0=pass_ks, producer=producer))
-        biases = torch.cat(bias_chunks)
-        # the additive term of every output column, by action: the accumulators of the kernel START from a row of this table
-        # (row A = the bias alone: what jobs without an action row take; row a < A = bias + the action's column of the first
-        # dynamics layer), so its epilogue adds nothing
-        act_table = biases.unsqueeze(0).repeat(A + 1, 1)
-        for off, blk in act_rows:                           # blk [n <= cw, A] = columns of the action block
-            act_table[:A, off:off + blk.shape[0]] += blk.t()
-        # weight streams, interleaved k-step by k-step: [k-step][wave][tiles * 512]; at any moment the waves of a
-        # workgroup (all near the same k-step) read one contiguous region
-        frag = tiles * 512
-        steps = [sum(x.numel() for x in st) // frag for st in streams]
-        P = max(steps) + 8                                  # 8 k-steps of zeros behind each stream (ring overrun)
-        W = torch.zeros(P, waves, frag)
-        for wave in range(waves):
-            if streams[wave]:
-                W[:steps[wave], wave] = torch.cat(streams[wave]).view(-1, frag)
+        biases, act_table, W, frag = self._assemble(bias_chunks, act_rows, streams, A)
         hdr = MlpHeader(n_jobs=len(jobs), row_stride=rs, hidden=hidden, state_off=state_off, hidden_off=hidden_off,
                         off_reward=off_r, off_value=off_v, off_policy=off_p, support_size=V, support_min=-engine.support,
                         num_actions=A, action_table_stride=biases.numel(), in_width=in_width,
@@ -721,14 +722,55 @@ class _FusedChain:
         self.weight_bytes_per_wg = int(sum(sum(x.numel() for x in s) for s in streams) * 2)
         self._jobs = None
 
+    def _assemble(self, bias_chunks, act_rows, streams, A):
+        """(biases, action table, interleaved weight streams, fragment size) from the per-job pieces, on the pieces' device."""
+        waves, tiles = self.waves, self.tiles
+        biases = torch.cat(bias_chunks)
+        # the additive term of every output column, by action: the accumulators of the kernel START from a row of this table
+        # (row A = the bias alone: what jobs without an action row take; row a < A = bias + the action's column of the first
+        # dynamics layer), so its epilogue adds nothing
+        act_table = biases.unsqueeze(0).repeat(A + 1, 1)
+        for off, blk in act_rows:                           # blk [n <= cw, A] = columns of the action block
+            act_table[:A, off:off + blk.shape[0]] += blk.t()
+        # weight streams, interleaved k-step by k-step: [k-step][wave][tiles * 512]; at any moment the waves of a
+        # workgroup (all near the same k-step) read one contiguous region
+        frag = tiles * 512
+        steps = [sum(x.numel() for x in st) // frag for st in streams]
+        P = max(steps) + 8                                  # 8 k-steps of zeros behind each stream (ring overrun)
+        W = torch.zeros(P, waves, frag, device=biases.device)
+        for wave in range(waves):
+            if streams[wave]:
+                W[:steps[wave], wave] = torch.cat(streams[wave]).view(-1, frag)
+        return biases, act_table, W, frag
+
+    def _values_only(self, rows, A):
+        """The numbers of an already laid-out chain (same walk over the jobs as _finish's table loop, nothing else)."""
+        cw, tiles = self.cw, self.tiles
+        streams = [[] for _ in range(self.waves)]
+        bias_chunks, act_rows = [], []
+        for row in rows:
+            for wave, e in enumerate(row):
+                if e is None:
+                    continue
+                streams[wave].append(_pack_fragments(e["w"], e["ks"], tiles))
+                bc = torch.zeros(cw, device=e["b"].device)
+                bc[:e["b"].shape[0]] = e["b"]
+                if e["act"] is not None:
+                    act_rows.append((cw * len(bias_chunks), e["act"]))
+                bias_chunks.append(bc)
+        biases, act_table, W, _ = self._assemble(bias_chunks, act_rows, streams, A)
+        self.n_jobs = len(rows)
+        self._host = dict(weights=W.reshape(-1).to(self.engine.dtype), biases=biases.float(), act_table=act_table.float())
+        self._jobs = None
+
     def reload(self, other):
         """New weights into the device tensors this chain (and any hipGraph captured over it) already uses: `other` is the
-        same chain built host_only from the updated module."""
+        same chain built host_only (or values_only: no job table) from the updated module."""
         assert other.host_only and (other.waves, other.tiles, other.n_jobs) == (self.waves, self.tiles, self.n_jobs)
-        assert bytes(other.header) == bytes(self.header), "reload(): the layer chain changed shape"
+        assert other.values_only or bytes(other.header) == bytes(self.header), "reload(): the layer chain changed shape"
         for k, v in other._host.items():
             cur = getattr(self, k)
-            assert cur.shape == v.shape and cur.dtype == v.dtype, k
+            assert cur.shape == v.shape and cur.dtype == v.dtype, (k, tuple(cur.shape), tuple(v.shape))
             cur.copy_(v)
 
     def lds_bytes(self, rows_per_wg):
@@ -759,8 +801,8 @@ class FusedRecurrent(_FusedChain):
     __call__(pool [S, N, H] bf16, ix [N] i32, actions [N] i32, hidden_out [N, H] bf16, out_reward [N], out_value [N],
              out_policy [N, A])   (fp32 outputs; buffers supplied by the caller, nothing is allocated)"""
 
-    def __init__(self, net, engine, waves=4, tiles=4, host_only=False):
-        super().__init__(engine, waves, tiles, host_only)
+    def __init__(self, net, engine, waves=4, tiles=4, host_only=False, values_only=False):
+        super().__init__(engine, waves, tiles, host_only, values_only)
         add_dense, add_group = self.add_dense, self.add_group
         H, A, h, full, V = engine.H, engine.A, engine.h, engine.full, 2 * engine.support + 1
         dyn, rw, ac, va = net._dynamics_state, net._dynamics_reward, net._prediction_actor, net._prediction_value
@@ -861,8 +903,8 @@ class FusedInitialTail(_FusedChain):
 
     __call__(x [N, 1024] bf16, hidden_out [N, H] bf16, out_value [N] f32, out_policy [N, A] f32)"""
 
-    def __init__(self, net, engine, waves=4, tiles=4, host_only=False):
-        super().__init__(engine, waves, tiles, host_only)
+    def __init__(self, net, engine, waves=4, tiles=4, host_only=False, values_only=False):
+        super().__init__(engine, waves, tiles, host_only, values_only)
         assert engine.full, "laid out for MuZeroNetFull"
         add_dense, add_group = self.add_dense, self.add_group
         H, A, h, V = engine.H, engine.A, engine.h, 2 * engine.support + 1

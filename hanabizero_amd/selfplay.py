@@ -51,8 +51,11 @@ class SelfPlayActor:
     PATH_LINES_ON, PATH_LINES_OFF = 5.3, 5.0
 
     def __init__(self, config, engine, num_envs, rank=0, seed=0, device=None, use_graph=True, outbox_games=None,
-                 deterministic=False, env_id_base=None, stream=None, fused_tail=True, predicted_lines="auto"):
-        """predicted_lines: which persistent search kernels the lock-steps launch (include/hz_search.h::
+                 deterministic=False, env_id_base=None, stream=None, fused_tail=True, predicted_lines="auto", root_noise=True,
+                 tie_seed=None):
+        """root_noise=False + deterministic=True: the evaluation protocol (core/test.py:93, 105: prepare_no_noise, first arg-max of the
+        legal-masked visit counts) on the same lock-step; tie_seed: the tree's tie-break stream if not `seed`.
+        predicted_lines: which persistent search kernels the lock-steps launch (include/hz_search.h::
         hz_search_set_predicted_lines): True = the ones whose descent walks predicted lines in trees that have grown deep (what a
         sharp policy needs), False = the plain ones (0.6-1 % faster while the trees stay shallow), "auto" = start plain and follow
         the mean length of the searches' last paths, looked at whenever finished games are drained (`PATH_LINES_ON` /
@@ -75,7 +78,8 @@ class SelfPlayActor:
         assert self.A == config.action_space_size and self.D == config.obs_dim
         self.S, self.stack, self.T = config.num_simulations, config.stacked_observations, config.max_moves
         self.W = self.env.packed_words
-        self.roots = cytree.Roots(N, self.A, self.S, device=d, tie_seed=seed, tree_id_base=self.env_id_base)
+        self.root_noise = bool(root_noise)
+        self.roots = cytree.Roots(N, self.A, self.S, device=d, tie_seed=seed if tie_seed is None else tie_seed, tree_id_base=self.env_id_base)
         self.roots.set_predicted_lines(self._lines_on)
         self.mcts = MCTS(config)
         dt = engine.dtype
@@ -183,7 +187,10 @@ class SelfPlayActor:
         the env and writes only the trees and the pool)."""
         cfg = self.cfg
         value0, logits0, hidden0 = self.root_inference(state_out=self.pool[0])
-        self.roots.prepare(cfg.root_exploration_fraction, self.noise, self.zeros_n, logits0, self.legal)
+        if self.root_noise:
+            self.roots.prepare(cfg.root_exploration_fraction, self.noise, self.zeros_n, logits0, self.legal)
+        else:
+            self.roots.prepare_no_noise(self.zeros_n, logits0, self.legal)
         self.mcts.run_multi(self.roots, self.engine, hidden0, pool=self.pool)
 
     def _tail_is_fused(self):

@@ -43,9 +43,12 @@ def test_evaluation_loop_matches_oracle_replay(game, dtype):
     windows = [[obs[i].copy() for _ in range(stack)] for i in range(E)]
     done = np.zeros(E, bool)
     final, nsteps = np.zeros(E, np.int64), np.zeros(E, np.int64)
+    D = cfg.obs_dim
+    Dp = eng.pad_observations(D, stack)  # (the actor's window layout: slots padded to 16-B multiples, zero weights on the pad)
     while not done.all():
-        stack_in = torch.from_numpy(np.stack([np.concatenate(w) for w in windows]).astype(np.float32)).cuda()
-        _, l0, h0 = eng.initial(stack_in)
+        win = np.zeros((E, stack, Dp), np.float32)
+        win[:, :, :D] = np.stack([np.concatenate(w) for w in windows]).reshape(E, stack, D)
+        _, l0, h0 = eng.initial(torch.from_numpy(win.reshape(E, -1)).cuda(), padded=Dp != D)
         tree = OracleTree(E, A, S, seed=5, value_delta_max=cfg.value_delta_max)
         tree.prepare_no_noise(np.zeros(E, np.float32), l0.cpu().numpy(), legal)
         _oracle_search(cfg, eng, tree, h0, S)

@@ -94,8 +94,19 @@ def main():
     scores, steps = run_test(cfg, engine, test_episodes=1000)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    from hanabizero_amd import evaluate
     out["evaluation_1000_episodes"] = {"s": dt, "moves": int(np.sum(steps)), "moves_per_s": float(np.sum(steps)) / dt,
-                                       "mean_score": float(np.mean(scores)), "longest_game": int(np.max(steps))}
+                                       "mean_score": float(np.mean(scores)), "longest_game": int(np.max(steps)),
+                                       # the batch keeps all 1000 envs moving until the longest episode has ended (as the reference's loop
+                                       # keeps them in its model / MCTS batch, core/test.py:99-100): the lock-steps' own rate, incl. capture
+                                       "lock_steps": evaluate.last_run.get("lock_steps"),
+                                       "batch_moves_per_s": evaluate.last_run.get("lock_steps", 0) * 1000 / dt}
+    t0 = time.perf_counter()
+    scores4, steps4 = run_test(cfg, engine, test_episodes=4096)
+    dt = time.perf_counter() - t0
+    out["evaluation_4096_episodes"] = {"s": dt, "moves": int(np.sum(steps4)), "moves_per_s": float(np.sum(steps4)) / dt,
+                                       "mean_score": float(np.mean(scores4)), "lock_steps": evaluate.last_run.get("lock_steps"),
+                                       "batch_moves_per_s": evaluate.last_run.get("lock_steps", 0) * 4096 / dt}
     print(json.dumps(out, indent=1))
 
 
