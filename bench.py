@@ -563,8 +563,9 @@ def git_head():
         return None
 
 
-def spawn_ranks(n):
-    """Launcher of `python bench.py --gpus N` (no torch.distributed.run around it): N children of this same command line, rank r
+def spawn_ranks(n, script=None):
+    """Launcher of `python bench.py --gpus N` (no torch.distributed.run around it; `script`: another entry point with the same
+    contract, tools/loop_bench.py): N children of this same command line, rank r
     on GPU r, rendezvous on 127.0.0.1 at a free port; their stdout / stderr pass straight through (only rank 0 prints the JSON
     line).  Returns the worst exit code; if a rank dies the others are terminated rather than left at a barrier."""
     import socket
@@ -575,7 +576,7 @@ def spawn_ranks(n):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(script or __file__)] + sys.argv[1:], env=env))
     worst, live = 0, list(procs)
     while live:
         time.sleep(0.2)

@@ -53,6 +53,7 @@ class _HanabiConfig:
         self.reward_support = DiscreteSupport(-support, support, delta=1)
         self.training_steps, self.last_steps = training_steps, last_steps
         self.checkpoint_interval, self.test_episodes = checkpoint_interval, test_episodes
+        self.target_model_interval = 200  # config/hanabi_control/__init__.py:20, 138 (both games)
         self.self_play_moves_ratio = 1
         self.clip_reward = self.image_based = self.cvt_string = self.state_norm = self.use_epsilon_greedy = False
         self.change_temperature = False

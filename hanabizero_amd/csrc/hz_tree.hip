@@ -244,8 +244,12 @@ extern "C" int hz_tree_set_params(hz_tree_t* t, int pb_c_base, float pb_c_init, 
                                   float value_delta_max, uint64_t tie_seed, uint32_t tree_id_base) {
   HZ_REQUIRE(t != nullptr, "hz_tree_set_params: NULL handle");
   HZ_REQUIRE(pb_c_base > 0, "hz_tree_set_params: pb_c_base must be > 0");
+  // (a caller that only moves to another tie-break stream -- the reanalyze search takes a new seed per learner step -- must not
+  // pay the table's synchronous upload below: on the null stream it would wait for every other stream of the device)
+  const bool same_table = t->params_set && t->pb_c_base == pb_c_base && t->pb_c_init == pb_c_init;
   t->pb_c_base = pb_c_base; t->pb_c_init = pb_c_init; t->discount = discount; t->delta = value_delta_max;
   t->seed = tie_seed; t->id_base = tree_id_base;
+  if (same_table) return 0;
   // pb_c's first factor depends only on the parent visit count n <= S: tabulate it with the host libm logf
   // the reference links against (cnode.cpp:385), same expression, same fp32 roundings.
   float* tab = new float[t->S + 1];

@@ -126,7 +126,7 @@ def _staging_bytes(key, nbytes, device):
 last_gather = {"exchange_s": 0.0, "landing_s": 0.0}  # host seconds the last gather_packed spent in its two halves (bench.py adds them up)
 
 
-def gather_packed(packed, A, W, dst=0, group=None):
+def gather_packed(packed, A, W, dst=0, group=None, to_host=True):
     """The device-resident form of gather_records: `packed` = SelfPlayActor.drain_packed() (uint8 device tensor, n games, their total moves)
     or None.  One all_gather of (n, moves), then every rank with games sends its byte buffer -- its exact size, no padding --
     straight to `dst` (point-to-point, batched: device to device over xGMI's direct peer links under "nccl"; the sending
@@ -137,7 +137,10 @@ def gather_packed(packed, A, W, dst=0, group=None):
     waited for, so called under ``with torch.cuda.stream(actor.drain_stream)`` the gather overlaps the lock-steps queued on
     the main stream.  `dst` is a rank OF `group` (translated to the global rank the point-to-point calls want).  Stream contract
     for `packed[0]` on the sending ranks: under "nccl" the send is only ordered on the caller's stream when this returns, so the
-    buffer may be rewritten by work enqueued on that same stream (what SelfPlayActor.drain_end's next pack is) and by nothing else."""
+    buffer may be rewritten by work enqueued on that same stream (what SelfPlayActor.drain_end's next pack is) and by nothing else.
+    to_host=False: `dst` gets the buffers as they arrived -- torch uint8 tensors on the device under "nccl" (host tensors in a
+    gloo rehearsal) -- for a replay that lives in HBM (hanabizero_amd.device_replay.DeviceReplay.ingest_packed): nothing is copied
+    to the host at all; the receive buffers are reused by the next call, so ingest them on the calling stream before it."""
     import time
     from .selfplay import packed_layout
     n, moves = (0, 0) if packed is None else (int(packed[1]), int(packed[2]))
@@ -147,6 +150,9 @@ def gather_packed(packed, A, W, dst=0, group=None):
         if not n:
             last_gather["landing_s"] = 0.0
             return []
+        if not to_host:
+            last_gather["landing_s"] = 0.0
+            return [(packed[0], n, moves)]
         host = _pinned_bytes(("r", 0), packed[0].numel())
         host.copy_(packed[0], non_blocking=True)
         if packed[0].is_cuda:  # (this stream only: lock-steps queued on other streams keep running)
@@ -183,6 +189,9 @@ def gather_packed(packed, A, W, dst=0, group=None):
     if rank != dst:
         last_gather["landing_s"] = 0.0
         return None
+    if not to_host:
+        last_gather["landing_s"] = 0.0
+        return [(recv[r], int(every[r, 0]), int(every[r, 1])) for r in range(world) if sizes[r]]
     out = []
     for r in range(world):
         if sizes[r]:

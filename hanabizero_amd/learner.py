@@ -322,6 +322,14 @@ class GraphedUpdate:
         self._graph = g
         # the capture itself does not execute: nothing to undo
 
+    def run(self):
+        """One step on what the static input tensors hold (obs, action, target_reward, target_value, target_policy, weights:
+        written in place by DeviceReplay.assemble / LearnerPipeline): the graph replay and nothing else -- no copy from the host,
+        nothing read back.  Results stay in `self.priority` [B] and `self.out` [7] (losses, as update_weights orders them)."""
+        if self._graph is None:
+            self._capture()
+        self._graph.replay()
+
     def __call__(self, batch):
         (obs_batch_ori, action_batch, mask_batch, indices, weights, make_time), (target_reward, target_value, target_policy) = batch
         cfg = self.config
@@ -339,3 +347,117 @@ class GraphedUpdate:
         loss_data = (float(o[0]), float(o[1]), float(o[2]), 0, float(o[3]), float(o[4]), float(o[5]), 0.0)
         return loss_data, self.priority.cpu().numpy()
 
+
+
+# ---- the learner side as one device pipeline -----------------------------------------------------------------------------
+class _Slot:
+    """One batch in flight: the tensors DeviceReplay.assemble fills (same names as GraphedUpdate's static inputs)."""
+
+    def __init__(self, like, R, U, A, win_shape, win_dtype):
+        for k in ("obs", "action", "target_reward", "target_value", "target_policy", "weights", "priority"):
+            setattr(self, k, torch.zeros_like(getattr(like, k)))
+        d = like.obs.device
+        self.ids = torch.zeros(like.weights.shape[0], dtype=torch.int64, device=d)
+        self.value_windows = torch.zeros(win_shape, dtype=win_dtype, device=d)
+        self.re_windows = torch.zeros((R * (U + 1), win_shape[1]), dtype=win_dtype, device=d) if R else None
+        self.ready, self.done = torch.cuda.Event(), torch.cuda.Event()
+        self.used = False
+
+
+class LearnerPipeline:
+    """What the reference spreads over BatchWorker_CPU x cpu_actor, BatchWorker_GPU x gpu_actor, the BatchStorage queue and
+    the learner process (/root/reference/core/train.py:317-431, 440-481; core/reanalyze_worker.py:402-440) as two streams of ONE
+    GPU with nothing on the host but the enqueueing:
+
+        prepare stream   priorities of step k - 2 back into the replay -> sample ids / weights -> re-searched policy targets for the
+                         first R rows with the TARGET model (policy_re_device) -> DeviceReplay.assemble into slot k % 2
+        learner stream   slot -> the captured step's static inputs -> lr -> GraphedUpdate.run -> new priorities into the slot
+
+    so batch k + 1 is searched and assembled while step k trains (the reference's queue of prepared batches, depth 2).
+    Cadences as train.py:392-398: `on_checkpoint(step)` every checkpoint_interval steps (the caller hands the weights to the
+    actors), the target model takes the learner's weights of one target_model_interval ago every target_model_interval steps.
+    Nothing synchronises the host; `losses()` reads the last step's loss tuple (one small read-back) when somebody wants it."""
+
+    def __init__(self, config, replay, model, target_engine, batch_size=None, reanalyze_share=0.5, amp=torch.bfloat16, beta=0.4,
+                 on_checkpoint=None, seed=0):
+        from .device_replay import policy_re_device
+        self._policy_re = policy_re_device
+        self.cfg, self.replay, self.model, self.target = config, replay, model, target_engine
+        self.B = int(batch_size or config.batch_size)
+        self.R = int(self.B * reanalyze_share)
+        self.beta, self.on_checkpoint = beta, on_checkpoint
+        dev = next(model.parameters()).device
+        self.optimizer = make_optimizer(model, config, capturable=True)
+        self.graphed = GraphedUpdate(model, self.optimizer, config, self.B, amp=amp)
+        U, A = config.num_unroll_steps, config.action_space_size
+        self.Dp = target_engine.pad_observations(replay.D, replay.stack)
+        win = (self.B * (U + 1), replay.stack * self.Dp)
+        self.slots = [_Slot(self.graphed, self.R, U, A, win, target_engine.dtype) for _ in range(2)]
+        self.prep, self.learn = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        self.steps = 0
+        self._recent = None
+        self._re_roots = None
+        self.gen = torch.Generator(device=dev)
+        self.gen.manual_seed(int(seed))
+        import copy
+        self._recent_net = copy.deepcopy(model)  # train.py:396-398: the target model runs one interval behind
+        cur = torch.cuda.current_stream(dev)
+        self.prep.wait_stream(cur)
+        self.learn.wait_stream(cur)
+        with torch.cuda.stream(self.learn):
+            self.graphed._capture()             # (now, not inside the first step: a capture synchronises the device)
+
+    def _value_fn(self, windows):
+        return self.target.initial(windows, padded=self.Dp != self.replay.D)[0]
+
+    def step(self):
+        """Enqueue learner step number self.steps (both halves).  Returns nothing; never blocks the host."""
+        cfg, rp, k = self.cfg, self.replay, self.steps
+        slot = self.slots[k % 2]
+        if slot.used:
+            slot.done.synchronize()             # (back-pressure: the host enqueues at most two steps ahead of the one training)
+        with torch.cuda.stream(self.prep), torch.no_grad():
+            if slot.used:                       # step k - 2 has trained on this slot: its priorities go back, the slot is free
+                self.prep.wait_event(slot.done)
+                rp.update_priorities(slot.ids, slot.priority)
+            if k % cfg.target_model_interval == 0 and k > 0:   # train.py:396-398
+                prev = self.slots[(k - 1) % 2]
+                self.prep.wait_event(prev.done)                # (the learner's weights as of step k - 1 are complete)
+                self.target.load(self._recent_net)
+                self._recent_net.load_state_dict(self.model.state_dict())
+                self._weights_taken = torch.cuda.Event()
+                self._weights_taken.record(self.prep)
+                self.learn.wait_event(self._weights_taken)     # (the next update must not overwrite what is being copied)
+            ids, w = rp.sample(self.B, self.beta)
+            slot.ids.copy_(ids)
+            slot.weights.copy_(w)
+            inside = rp.assemble(ids, self._value_fn, slot, value_windows=slot.value_windows, slot_elems=self.Dp)
+            if self.R:
+                legal, mask = rp.policy_re_inputs(ids[:self.R], slot.re_windows, slot_elems=self.Dp)
+                if self._re_roots is None:
+                    from . import cytree
+                    self._re_roots = cytree.Roots(slot.re_windows.shape[0], cfg.action_space_size, cfg.num_simulations,
+                                                  device=slot.obs.device)
+                pol = self._policy_re(cfg, self.target, slot.re_windows, legal, mask, generator=self.gen, tie_seed=k,
+                                      padded=self.Dp != rp.D, roots=self._re_roots)
+                slot.target_policy[:self.R] = pol.view(self.R, cfg.num_unroll_steps + 1, -1)   # [reanalyzed | stored], :412-419
+            slot.ready.record(self.prep)
+        with torch.cuda.stream(self.learn):
+            self.learn.wait_event(slot.ready)
+            g = self.graphed
+            for name in ("obs", "action", "target_reward", "target_value", "target_policy", "weights"):
+                getattr(g, name).copy_(getattr(slot, name), non_blocking=True)
+            adjust_lr(cfg, self.optimizer, k)
+            g.run()
+            slot.priority.copy_(g.priority, non_blocking=True)
+            slot.done.record(self.learn)
+        slot.used = True
+        self.steps = k + 1
+        if self.on_checkpoint is not None and self.steps % cfg.checkpoint_interval == 0:   # train.py:392-393
+            self.on_checkpoint(self.steps, slot.done)
+
+    def losses(self):
+        """(total, weighted, mean loss, 0, mean policy, mean reward, mean value, 0.0) of the last finished step (synchronises)."""
+        self.learn.synchronize()
+        o = self.graphed.out.cpu().numpy()
+        return (float(o[0]), float(o[1]), float(o[2]), 0, float(o[3]), float(o[4]), float(o[5]), 0.0)

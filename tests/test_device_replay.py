@@ -28,7 +28,7 @@ def _both(cfg, bufs, capacity=None):
     from hanabizero_amd.replay import ReplayBuffer
     rb = ReplayBuffer(cfg)
     total = sum(b[2] for b in bufs)
-    dr = DeviceReplay(cfg, capacity or total + 64)
+    dr = DeviceReplay(cfg, capacity or total + 64, games_capacity=total + 64)  # (Hanabi-Small games are a few moves long: nearly a frame row per position extra)
     for buf, n, moves in bufs:
         rb.ingest_packed(buf.cpu().numpy(), n, moves)
         dr.ingest_packed(buf, n, moves)
@@ -209,3 +209,70 @@ def test_policy_re_on_the_device_equals_the_host_context_path():
     got = policy_re_device(cfg, eng, win, legal, mask, noises=torch.from_numpy(noises).cuda(), tie_seed=4)
     assert np.array_equal(got.cpu().numpy().reshape(16, U + 1, A), want.astype(np.float32))
     assert (mask.cpu().numpy() == 0).any(), "no position of the sample ran past its game's end: the masked branch was not exercised"
+
+
+def test_learner_pipeline_equals_its_single_stream_schedule():
+    """learner.LearnerPipeline (two streams, batch k + 1 prepared while step k trains, priorities written back two steps later,
+    target model refreshed one interval behind) leaves the same weights, priorities and target model as the SAME sequence of
+    operations enqueued on one stream -- where ordering is trivially right: any missing event between the streams shows here."""
+    import copy
+    from hanabizero_amd.learner import LearnerPipeline
+    from hanabizero_amd.model import InferenceEngine
+    cfg, eng, actor, bufs = _selfplay("Hanabi-Small", 64, 30, sims=10)
+    cfg.batch_size, cfg.target_model_interval, cfg.checkpoint_interval = 32, 4, 5
+    results = []
+    for pipelined in (True, False):
+        _, dr = _both(cfg, bufs)
+        torch.manual_seed(1)
+        model = copy.deepcopy(eng._net).cuda()
+        target = InferenceEngine(copy.deepcopy(eng._net), cfg.value_support.max, dtype=torch.float16, device="cuda")
+        calls = []
+        pipe = LearnerPipeline(cfg, dr, model, target, reanalyze_share=0.5, on_checkpoint=lambda step, ev: calls.append(step), seed=3)
+        if not pipelined:
+            pipe.prep = pipe.learn = torch.cuda.current_stream()
+        for _ in range(11):
+            pipe.step()
+        torch.cuda.synchronize()
+        assert pipe.steps == 11 and calls == [5, 10]
+        losses = pipe.losses()
+        assert all(np.isfinite(x) for x in losses)
+        results.append(([p.detach().clone() for p in model.parameters()], dr.priority[:dr.head].clone(),
+                        [t.clone() for t in target._dev.values()], losses))
+        assert not torch.equal(results[-1][1], torch.ones_like(results[-1][1])), "no priority was written back"
+    for a, b in zip(results[0][0], results[1][0]):
+        assert torch.equal(a, b), "the pipelined learner's weights differ from the single-stream schedule's"
+    assert torch.equal(results[0][1], results[1][1])
+    for a, b in zip(results[0][2], results[1][2]):
+        assert torch.equal(a, b)
+    assert results[0][3] == results[1][3]
+
+
+@pytest.mark.parametrize("ranks", [1, 2])
+def test_config5_loop_roles_on_one_gpu(ranks):
+    """tools/loop_bench.py, the configs[4] loop as DESIGN.md section 5 lays it out -- at one rank (learner + actor in one process,
+    three streams) and as a two-rank rehearsal on the test box's one GPU over gloo (rank 0 learns, rank 1 acts: packed games
+    gathered into the device replay, weights broadcast back and taken over in place) -- small enough for a test: every role's
+    hand-offs happen at least once and the one JSON line adds up."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, "tools/loop_bench.py", "--gpus", str(ranks), "--game", "Hanabi-Full-5p", "--envs", "256", "--rounds", "3",
+           "--warm-rounds", "8", "--flush-every", "10", "--ratio", "0.004", "--batch-size", "64", "--simulations", "20",
+           "--checkpoint-interval", "8", "--target-interval", "6", "--replay-capacity", "200000"]
+    if ranks > 1:
+        cmd += ["--backend", "gloo", "--share-device"]
+    p = subprocess.run(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-4000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == ranks and d["roles"]["acting_ranks"] == 1 and d["roles"]["learner_acts"] == (ranks == 1)
+    moves = 3 * 10 * 256
+    assert d["learner_steps"] == int(moves * 0.004) >= 28 and d["replay_ratio_achieved"] == pytest.approx(0.004, rel=0.05)
+    assert d["selfplay_moves_per_s"] == pytest.approx(moves / d["wall_s"], rel=1e-6)
+    assert d["games_ingested"] > 50 and d["replay_positions"] > 1000 and d["weight_handovers_in_run"] >= 2
+    assert d["loss_last"] is not None and np.isfinite(d["loss_last"]) and d["weight_handover_ms"] > 0

@@ -1,154 +1,268 @@
 #!/usr/bin/env python3
-"""tools/loop_bench.py -- BASELINE.json configs[4] timed as ONE loop on ONE GPU, one JSON line.
+"""tools/loop_bench.py -- BASELINE.json configs[4] timed as ONE loop per rank, one JSON line: Hanabi-Full 5 players (A = 48,
+D = 1385, mdp global), 50 simulations per move, self-play + reanalyze + learner batch 256, on N GPUs of one node.
 
-Hanabi-Full 5 players (A = 48, D = 1385, mdp global), 50 simulations per move: self-play (SelfPlayActor under its hipGraph) ->
-drain -> ReplayBuffer.ingest_packed -> prioritised sampling -> reanalyze of a share of every batch with the target model
-(policy_re_context + prepare_policy_re: the search kernels' second caller) -> make_batch -> GraphedUpdate (batch 256, 5 unroll
-steps, bf16 autocast) -> priorities back -> every checkpoint_interval learner steps the actor's engine takes the learner's
-weights in place.  What the reference runs as Ray actors (/root/reference/core/train.py:317-431, reanalyze_worker.py:307-422,
-selfplay_worker.py:91-393) is here a single synchronous loop: no control plane, no service.
+Role map (what the reference runs as Ray actors: /root/reference/core/train.py:317-431, 440-481,
+core/reanalyze_worker.py:45-86, 249-304, 307-440, core/selfplay_worker.py:91-393 -- here one loop per rank, no control plane):
 
-The schedule is the reference's replay ratio (README.md:51: 0.008 learner steps per self-play move): after every lock-step the
-loop owes `envs * ratio` learner steps and pays them before the next one.  Reported: self-play moves/s and learner steps/s of the
-whole loop, the ratio achieved, and where the wall time went (self-play launch + wait, drain + ingest, sampling, reanalyze,
-make_batch, update) -- which answers whether the search is what limits this configuration (it is not: the learner side is).
---ratio 0 runs self-play + ingest only (what the actors alone sustain)."""
+  rank 0            the LEARNER rank: owns the replay (hanabizero_amd.device_replay.DeviceReplay: the actors' packed records,
+                    bit-packed, in HBM), the target model (reanalyze searches + value targets), the learner's module and its
+                    captured step (learner.LearnerPipeline: batch k + 1 is sampled, re-searched and assembled on one stream
+                    while step k trains on another; nothing on the host but the enqueueing).  At N = 1 it is also the actor.
+  ranks 1 .. N - 1  ACTORS: one SelfPlayActor each under its hipGraph (env ids keyed by rank: no two ranks play the same game).
+  a round           every actor plays `--flush-every` lock-steps; its finished games go to rank 0 as ONE packed buffer that never
+                    leaves the devices (dist.gather_packed(to_host=False): RCCL point-to-point into reused receive buffers) and
+                    are appended to the replay on the device; rank 0 then trains `ratio x moves of the round` steps (the
+                    reference's replay ratio, README.md:51: 0.008 learner steps per self-play move); the round ends with a
+                    two-number broadcast (trained steps, "weights follow") and, every checkpoint_interval steps, the weights
+                    (dist.broadcast_weights: one flat buffer per dtype) which every actor takes over IN PLACE on its device
+                    (InferenceEngine.load from a device-resident module: no host copy, the captured lock-step sees them).
+
+Why actors wait for the learner: one MI355X plays 1.1 M Hanabi-Full-5p moves/s; at ratio 0.008 that is owed 9 k learner steps/s,
+and a learner step (256 x 6 inferences forward and backward, ~1.7 k small kernels) takes ~8 ms.  At the reference's ratio the
+configuration is LEARNER-bound by two orders of magnitude on any number of GPUs -- the actors of a round are done in
+`flush_every x 2 ms` and wait; `--ratio` sets another exchange rate, `--ratio 0` free-runs the actors (self-play + ingest only).
+Reported: learner steps/s, self-play moves/s of the whole job, the ratio achieved, the host's share (time spent enqueueing),
+one weight hand-over timed on its own.
+
+Launch: `python tools/loop_bench.py --gpus N` starts its own N ranks (as bench.py does); under torch.distributed.run it reads
+RANK / LOCAL_RANK / WORLD_SIZE.  `--backend gloo --share-device` rehearses N ranks on one GPU."""
 import argparse
 import json
 import os
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import bench  # noqa: E402
-from hanabizero_amd.config import make_config  # noqa: E402
-from hanabizero_amd.dist import gather_packed  # noqa: E402
-from hanabizero_amd.learner import GraphedUpdate, adjust_lr, make_batch, make_optimizer  # noqa: E402
-from hanabizero_amd.model import InferenceEngine  # noqa: E402
-from hanabizero_amd.reanalyze import policy_re_context, prepare_policy_re  # noqa: E402
-from hanabizero_amd.replay import ReplayBuffer  # noqa: E402
-from hanabizero_amd.selfplay import SelfPlayActor  # noqa: E402
 
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--game", default="Hanabi-Full-5p")
-    ap.add_argument("--envs", type=int, default=2048)
-    ap.add_argument("--lock-steps", type=int, default=40)
-    ap.add_argument("--warm-steps", type=int, default=60, help="self-play only, to fill the replay buffer")
-    ap.add_argument("--ratio", type=float, default=0.008, help="learner steps per self-play move (reference README.md:51)")
+    ap.add_argument("--envs", type=int, default=2048, help="per acting rank")
+    ap.add_argument("--rounds", type=int, default=4, help="timed rounds of --flush-every lock-steps each")
+    ap.add_argument("--warm-rounds", type=int, default=6, help="self-play only, to fill the replay (the reference waits for start_window_size positions, train.py:352-359)")
+    ap.add_argument("--flush-every", type=int, default=10)
+    ap.add_argument("--ratio", type=float, default=0.008, help="learner steps per self-play move (reference README.md:51); 0: self-play + ingest only")
+    ap.add_argument("--max-steps-per-round", type=int, default=0, help="cap on the learner steps of one round (0: none)")
     ap.add_argument("--reanalyze-share", type=float, default=0.5, help="share of every batch whose policy targets are re-searched")
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
-    ap.add_argument("--flush-every", type=int, default=10)
-    ap.add_argument("--obs-float32", action="store_true", help="make_batch in the reference's float32 layout (default: frames stay bytes until they are on the device)")
-    ap.add_argument("--checkpoint-interval", type=int, default=0, help="learner steps between weight hand-overs to the actor (0: the config's, 2000 for Hanabi-Full; one hand-over is timed after the loop either way)")
+    ap.add_argument("--checkpoint-interval", type=int, default=0, help="learner steps between weight hand-overs to the actors (0: the config's)")
+    ap.add_argument("--target-interval", type=int, default=0, help="learner steps between target-model refreshes (0: the config's, 200)")
+    ap.add_argument("--batch-size", type=int, default=256)
+    ap.add_argument("--simulations", type=int, default=50)
+    ap.add_argument("--replay-capacity", type=int, default=4_000_000, help="positions the device replay holds (Hanabi-Full 5p: ~330 B each)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--share-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--learner-acts", action="store_true", help="N > 1: rank 0 plays too (default: it only learns)")
     args = ap.parse_args()
-    device = torch.device("cuda", 0)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import bench
+        sys.exit(bench.spawn_ranks(args.gpus, script=__file__))
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import bench
+    from hanabizero_amd.config import make_config
+    from hanabizero_amd.device_replay import DeviceReplay
+    from hanabizero_amd.dist import broadcast_weights, gather_packed
+    from hanabizero_amd.learner import LearnerPipeline
+    from hanabizero_amd.selfplay import SelfPlayActor
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = 0 if args.share_device else int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            assert args.share_device or torch.cuda.device_count() >= world
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    coll_dev = device if (world == 1 or args.backend == "nccl") else torch.device("cpu")
     dtype = {"fp16": torch.float16, "bf16": torch.bfloat16}[args.dtype]
-    cfg = make_config(args.game, simulations=50, stack=4, p_mcts_num=args.envs, batch_size=256)
-    engine = bench.build_engine(cfg, dtype, device)
-    target = bench.build_engine(cfg, dtype, device)  # the reanalyze workers' target model
-    actor = SelfPlayActor(cfg, engine, args.envs, seed=0, device=device)
-    rb = ReplayBuffer(cfg)
-    t = dict(selfplay=0.0, drain=0.0, sample=0.0, reanalyze=0.0, make_batch=0.0, update=0.0, weights=0.0)
+    cfg = make_config(args.game, simulations=args.simulations, stack=4, p_mcts_num=args.envs, batch_size=args.batch_size)
+    if args.checkpoint_interval:
+        cfg.checkpoint_interval = args.checkpoint_interval
+    if args.target_interval:
+        cfg.target_model_interval = args.target_interval
+    learns = rank == 0
+    acts = world == 1 or rank > 0 or args.learner_acts
+    n_actors = world if (world == 1 or args.learner_acts) else world - 1
+    actor_index = rank if (world == 1 or args.learner_acts) else rank - 1
 
-    def drain():
+    engine = actor = None
+    if acts:
+        engine = bench.build_engine(cfg, dtype, device)
+        actor = SelfPlayActor(cfg, engine, args.envs, rank=actor_index, seed=0, device=device)
+        net_dev = cfg.get_uniform_network().to(device)  # the module the broadcast weights land in (in place, on the device)
+        net_dev.eval()
+    pipe = replay = None
+    handover = {"pending": False, "count": 0, "ms": []}
+    if learns:
+        replay = DeviceReplay(cfg, args.replay_capacity, device=device)
+        target = bench.build_engine(cfg, dtype, device)
+        learner = cfg.get_uniform_network().to(device)
+        learner.load_state_dict((engine or target)._net.state_dict())
+
+        def on_checkpoint(step, done_event):
+            handover["pending"], handover["event"] = True, done_event
+        pipe = LearnerPipeline(cfg, replay, learner, target, batch_size=cfg.batch_size, reanalyze_share=args.reanalyze_share,
+                               on_checkpoint=on_checkpoint)
+    A = cfg.action_space_size
+    W = (cfg.obs_dim + 31) // 32
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    t_host = dict(selfplay=0.0, drain_gather=0.0, ingest=0.0, learner_enqueue=0.0, weights=0.0)
+    totals = dict(moves=0, games=0)
+
+    def hand_weights_over():
+        """Every acting rank ends up with the learner's current weights in its engine, in place."""
         t0 = time.perf_counter()
-        for buf, n, moves in gather_packed(actor.drain_packed(), actor.A, actor.W):
-            rb.ingest_packed(buf, n, moves)
-        t["drain"] += time.perf_counter() - t0
+        if world == 1:
+            ws = actor._work_stream()
+            with torch.cuda.stream(ws):
+                ws.wait_event(handover["event"])
+                engine.load(pipe.model)
+                taken = torch.cuda.Event()
+                taken.record(ws)
+            pipe.learn.wait_event(taken)  # (the next update must not overwrite what is being folded)
+        else:
+            state = None
+            if learns:
+                pipe.learn.synchronize()
+                state = {k: v.detach() for k, v in pipe.model.state_dict().items()}
+            else:
+                state = {k: v.detach() for k, v in net_dev.state_dict().items()}
+            if coll_dev.type == "cpu":
+                state = {k: v.cpu() for k, v in state.items()}
+            got = broadcast_weights(state, src=0, device=coll_dev)
+            if acts:
+                with torch.cuda.stream(actor._work_stream()):
+                    net_dev.load_state_dict({k: v.to(device) for k, v in got.items()})
+                    engine.load(net_dev)
+        handover["pending"] = False
+        handover["count"] += 1
+        handover["ms"].append(1e3 * (time.perf_counter() - t0))
 
-    for k in range(args.warm_steps):
-        actor.step()
-        if (k + 1) % args.flush_every == 0:
-            drain()
-    torch.cuda.synchronize()
-    drain()
-    learner = cfg.get_uniform_network().to(device)
-    learner.load_state_dict(engine._net.state_dict())
-    handover = cfg.get_uniform_network()  # host copy the weights travel through (selfplay_worker.py:177-184: set_weights)
-    handover.eval()
-    opt = make_optimizer(learner, cfg, capturable=True)
-    graphed = GraphedUpdate(learner, opt, cfg, cfg.batch_size)
-    value_fn = lambda o: target.initial(torch.from_numpy(o).to(device))[0].float().cpu().numpy()
-    R = int(cfg.batch_size * args.reanalyze_share)
-
-    def learner_step(it):
+    def one_round(train):
         t0 = time.perf_counter()
-        games, pos, idx, w, mt = rb.prepare_batch_context(cfg.batch_size, beta=0.4)
+        packed = None
+        if acts:
+            for _ in range(args.flush_every):
+                actor.step()
+            packed = actor.drain_packed()   # (blocks for this rank's lock-steps; the learner's streams keep running)
         t1 = time.perf_counter()
-        pol_re = None
-        if R:
-            ctx = policy_re_context(cfg, games[:R], pos[:R], idx[:R])
-            pol_re = prepare_policy_re(cfg, target, ctx, tie_seed=it)
+        got = gather_packed(packed, A, W, dst=0, to_host=False)
         t2 = time.perf_counter()
-        batch = make_batch(games, pos, cfg, value_fn, weights=w, rng=np.random.RandomState(it), policy_re=pol_re, obs_dtype=np.float32 if args.obs_float32 else np.uint8)
-        t3 = time.perf_counter()
-        adjust_lr(cfg, opt, it)
-        loss_data, prio = graphed(batch)
-        rb.update_priorities(idx, prio, mt)
-        t4 = time.perf_counter()
-        t["sample"] += t1 - t0
-        t["reanalyze"] += t2 - t1
-        t["make_batch"] += t3 - t2
-        t["update"] += t4 - t3
-        return loss_data
+        round_moves = torch.tensor([args.flush_every * args.envs if acts else 0], dtype=torch.int64, device=coll_dev)
+        if world > 1:
+            dist.all_reduce(round_moves)
+        moves = int(round_moves)
+        steps = 0
+        if learns:
+            with torch.cuda.stream(pipe.prep):
+                pipe.prep.wait_stream(torch.cuda.current_stream(device))
+                for buf, n, mv in got:
+                    replay.ingest_packed(buf, n, mv)
+                    totals["games"] += n
+            t3 = time.perf_counter()
+            if train:
+                one_round.owed += moves * args.ratio
+                while one_round.owed >= 1.0 and (not args.max_steps_per_round or steps < args.max_steps_per_round):
+                    pipe.step()
+                    steps += 1
+                    one_round.owed -= 1.0
+                    if handover["pending"] and world == 1:
+                        hand_weights_over()
+                if pipe.steps and pipe.steps % 200 < steps:
+                    replay.remove_to_fit()  # train.py:367-368
+            t4 = time.perf_counter()
+            t_host["ingest"] += t3 - t2
+            t_host["learner_enqueue"] += t4 - t3
+        if world > 1:  # the round's closing exchange: (trained steps, weights follow)
+            flag = torch.tensor([pipe.steps if learns else 0, int(handover["pending"]) if learns else 0], dtype=torch.int64, device=coll_dev)
+            dist.broadcast(flag, src=0)
+            if int(flag[1]):
+                hand_weights_over()
+        t_host["selfplay"] += t1 - t0
+        t_host["drain_gather"] += t2 - t1
+        totals["moves"] += moves
+        return steps
+    one_round.owed = 0.0
 
-    for it in range(2):  # (captures the learner's graph, first shapes of the reanalyze search)
-        learner_step(it)
-    torch.cuda.synchronize()
-    for k in t:
-        t[k] = 0.0
-    owed, steps_done, losses = 0.0, 0, []
-    games_before = int(actor.out_count[0].item())
+    for _ in range(args.warm_rounds):
+        one_round(train=False)
+    if learns and args.ratio > 0:
+        assert replay.get_total_len() > cfg.batch_size, "the warm rounds finished too few games (%d positions)" % replay.get_total_len()
+        for _ in range(3):   # (first shapes of the reanalyze search, hipBLASLt workspaces)
+            pipe.step()
+        pipe.learn.synchronize()
+    torch.cuda.synchronize(device)
+    barrier()
+    for k in t_host:
+        t_host[k] = 0.0
+    totals.update(moves=0, games=0)
+    steps0 = pipe.steps if learns else 0
     t_start = time.perf_counter()
-    for k in range(args.lock_steps):
-        t0 = time.perf_counter()
-        actor.step()
-        if args.ratio > 0:
-            torch.cuda.synchronize()  # (a synchronous loop: the learner's work below does not overlap the move)
-        t["selfplay"] += time.perf_counter() - t0
-        if (k + 1) % args.flush_every == 0:
-            drain()
-        owed += args.envs * args.ratio
-        while owed >= 1.0:
-            losses.append(learner_step(2 + steps_done)[1])
-            steps_done += 1
-            owed -= 1.0
-            if steps_done % (args.checkpoint_interval or cfg.checkpoint_interval) == 0:
-                t0 = time.perf_counter()
-                handover.load_state_dict({k: v.detach().cpu() for k, v in learner.state_dict().items()})
-                engine.load(handover)  # in place: the actor's captured graph sees the new weights from its next replay on
-                t["weights"] += time.perf_counter() - t0
-    torch.cuda.synchronize()
-    drain()
+    for r in range(args.rounds):
+        one_round(train=args.ratio > 0)
+    if learns:
+        pipe.learn.synchronize()
+        pipe.prep.synchronize()
+    torch.cuda.synchronize(device)
+    barrier()
     wall = time.perf_counter() - t_start
-    t0 = time.perf_counter()  # one weight hand-over, timed on its own (outside `wall` unless the interval fell inside the run)
-    handover.load_state_dict({k: v.detach().cpu() for k, v in learner.state_dict().items()})
-    engine.load(handover)
-    torch.cuda.synchronize()
+    wall_t = torch.tensor([wall], dtype=torch.float64, device=coll_dev)
+    if world > 1:
+        dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
+    wall = float(wall_t)
+    # one weight hand-over timed on its own
+    if learns:
+        handover["event"] = pipe.slots[(pipe.steps - 1) % 2].done if pipe.steps else torch.cuda.Event()
+        if not pipe.steps:
+            handover["event"].record(pipe.learn)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    hand_weights_over()
+    torch.cuda.synchronize(device)
     handover_ms = 1e3 * (time.perf_counter() - t0)
-    for _ in range(3):
-        actor.step()
-    torch.cuda.synchronize()
-    moves = args.envs * args.lock_steps
-    out = {"workload": "%s, %d envs, 50 sims/move, %s nets: self-play + reanalyze (%.0f %% of each batch) + learner batch %d on ONE GPU, one synchronous loop"
-                       % (args.game, args.envs, args.dtype, 100 * args.reanalyze_share, cfg.batch_size),
-           "lock_steps": args.lock_steps, "selfplay_moves_per_s": moves / wall, "learner_steps_per_s": steps_done / wall,
-           "learner_steps": steps_done, "replay_ratio_target": args.ratio, "replay_ratio_achieved": steps_done / moves,
-           "reference": {"replay_ratio": 0.008, "learner_steps_per_s": 1000 / 160.0, "selfplay_moves_per_s_derived": 1000 / 160.0 / 0.008,
-                         "hardware": "4 x RTX 3090 + 96 CPU cores, Hanabi-Small", "source": "/root/reference/README.md:51"},
-           "wall_s": wall, "games_finished": int(actor.out_count[0].item()) - games_before, "replay_positions": rb.get_total_len(),
-           "ms_per_lock_step": {k: 1e3 * v / args.lock_steps for k, v in t.items()},
-           "ms_per_learner_step": ({k: 1e3 * t[k] / steps_done for k in ("sample", "reanalyze", "make_batch", "update")} if steps_done else None),
-           "weight_handover_ms": handover_ms, "checkpoint_interval": args.checkpoint_interval or cfg.checkpoint_interval,
-           "loss_first_last": [float(losses[0]), float(losses[-1])] if losses else None,
-           "illegal_steps": int(actor.illegal_steps)}
-    print(json.dumps(out), flush=True)
+    if acts:
+        for _ in range(3):
+            actor.step()
+        torch.cuda.synchronize(device)
+        assert int(actor.illegal_steps) == 0
+    if learns:
+        steps_done = pipe.steps - steps0
+        losses = pipe.losses() if pipe.steps else None
+        out = {"workload": "%s, %d envs x %d acting rank(s), %d sims/move, %s nets: self-play + reanalyze (%.0f %% of each batch) + learner batch %d; "
+                           "replay, batch maker and learner on the device of rank 0" % (args.game, args.envs, n_actors, args.simulations, args.dtype,
+                                                                                       100 * args.reanalyze_share, cfg.batch_size),
+               "n_gpus": world, "backend": args.backend if world > 1 else None, "share_device": bool(args.share_device),
+               "roles": {"learner_rank": 0, "acting_ranks": n_actors, "learner_acts": bool(world == 1 or args.learner_acts)},
+               "rounds": args.rounds, "lock_steps_per_round": args.flush_every,
+               "selfplay_moves_per_s": totals["moves"] / wall, "learner_steps_per_s": steps_done / wall, "learner_steps": steps_done,
+               "replay_ratio_target": args.ratio, "replay_ratio_achieved": steps_done / max(1, totals["moves"]),
+               "reference": {"replay_ratio": 0.008, "learner_steps_per_s": 1000 / 160.0, "selfplay_moves_per_s_derived": 1000 / 160.0 / 0.008,
+                             "hardware": "4 x RTX 3090 + 96 CPU cores, Hanabi-Small", "source": "/root/reference/README.md:51"},
+               "wall_s": wall, "games_ingested": totals["games"], "replay_positions": replay.get_total_len(), "replay_hbm_bytes": replay.hbm_bytes,
+               "host_ms_per_round": {k: 1e3 * v / args.rounds for k, v in t_host.items()},
+               "host_ms_per_learner_step_enqueue": (1e3 * t_host["learner_enqueue"] / steps_done) if steps_done else None,
+               "weight_handover_ms": handover_ms, "weight_handovers_in_run": handover["count"] - 1,
+               "checkpoint_interval": cfg.checkpoint_interval, "target_model_interval": cfg.target_model_interval,
+               "loss_last": losses[1] if losses else None}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
