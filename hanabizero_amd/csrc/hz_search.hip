@@ -216,12 +216,16 @@ __device__ __forceinline__ void search_kernel_body(const TreeView& tv, const hz_
     __syncthreads();  // leaf outputs visible; the row image is free again
     unsigned long long t4 = SP_NOW();
     hz_tree_phase_prio();
-    int lane_t = lane;  // (opaque: lane-derived values of the tree phase are recomputed per simulation, not spilled)
-    asm volatile("" : "+v"(lane_t));
+    int tid_t = threadIdx.x;  // (opaque: thread-derived values of the tree phase are recomputed per simulation, not spilled)
+    asm volatile("" : "+v"(tid_t));
+    const int lane_t = tid_t & 63;
+    // (in-turn kernel: the wave number too -- kept across the inference, the two trees' global indices were the kernel's only
+    // values in scratch: copied into vector registers for want of scalar ones, spilled, reloaded for the last descent's publish)
+    const int wave_t = RT == 1 ? wave : __builtin_amdgcn_readfirstlane(tid_t >> 6);
 #pragma unroll
     for (int s = 0; s < RT; ++s)
       if (mine[s])
-        rows[s] = search_backup_descent<EL, RT == 1 && RP>(tv, H, a, L, row0, row0 + 16 * s + wave, lane_t, 16 * s + wave, sim, sim + 1 < a.sims,
+        rows[s] = search_backup_descent<EL, RT == 1 && RP>(tv, H, a, L, row0, row0 + 16 * s + wave_t, lane_t, 16 * s + wave_t, sim, sim + 1 < a.sims,
                                         tl[s], root_row[s]);
     p_tree += t1 - t0; p_wait1 += t2 - t1; p_mlp += t3 - t2; p_wait2 += t4 - t3;
     t0 = t4;
@@ -241,7 +245,10 @@ __global__ __launch_bounds__(1024, 1) __attribute__((amdgpu_num_vgpr(HZ_ASMK_VGP
   search_kernel_body<EL, 1, RP>(tv, H, a);
 }
 // the two trees of a wave one after the other: its register pressure peaks above the others', and amdgpu_num_vgpr is a budget the
-// allocator was seen to overdraw by four registers -- into the ring (tools/scan_ring_registers.py) -- so this one gets a lower one
+// allocator was seen to overdraw by four registers -- into the ring (tools/scan_ring_registers.py) -- so this one gets a lower one.
+// It keeps workgroup barriers at the layer boundaries (mlp_body<.., BW = false>): with the arrival counters compiled in, the two
+// trees' state that lives across the inference no longer fits -- 57 vector registers spilled, 34 scratch accesses spread over
+// both phases, at any budget from 88 to 96 (r04, measured on the ISA; a scratch reload drains the weight ring)
 template <class EL>
 __global__ __launch_bounds__(1024, 1) __attribute__((amdgpu_num_vgpr(HZ_ASMK_VGPRS - 8))) void k_search_turn(TreeView tv, hz_mlp_header_t H, SearchArgs a) {
   search_kernel_body<EL, 2, false>(tv, H, a);

@@ -395,6 +395,7 @@ class LearnerPipeline:
         self.slots = [_Slot(self.graphed, self.R, U, A, win, target_engine.dtype) for _ in range(2)]
         self.prep, self.learn = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
         self.steps = 0
+        self.host_wait_s = 0.0                  # what the host spent waiting for a slot (the GPU being the slower side)
         self._recent = None
         self._re_roots = None
         self.gen = torch.Generator(device=dev)
@@ -415,7 +416,10 @@ class LearnerPipeline:
         cfg, rp, k = self.cfg, self.replay, self.steps
         slot = self.slots[k % 2]
         if slot.used:
+            import time
+            t0 = time.perf_counter()
             slot.done.synchronize()             # (back-pressure: the host enqueues at most two steps ahead of the one training)
+            self.host_wait_s += time.perf_counter() - t0
         with torch.cuda.stream(self.prep), torch.no_grad():
             if slot.used:                       # step k - 2 has trained on this slot: its priorities go back, the slot is free
                 self.prep.wait_event(slot.done)

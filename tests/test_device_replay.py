@@ -274,5 +274,5 @@ def test_config5_loop_roles_on_one_gpu(ranks):
     moves = 3 * 10 * 256
     assert d["learner_steps"] == int(moves * 0.004) >= 28 and d["replay_ratio_achieved"] == pytest.approx(0.004, rel=0.05)
     assert d["selfplay_moves_per_s"] == pytest.approx(moves / d["wall_s"], rel=1e-6)
-    assert d["games_ingested"] > 50 and d["replay_positions"] > 1000 and d["weight_handovers_in_run"] >= 2
+    assert d["games_ingested"] > 50 and d["replay_positions"] > 1000 and d["weight_handovers_in_run"] >= 2 and d["weight_handover_first_ms"] > 0
     assert d["loss_last"] is not None and np.isfinite(d["loss_last"]) and d["weight_handover_ms"] > 0

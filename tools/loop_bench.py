@@ -230,11 +230,15 @@ def main():
         handover["event"] = pipe.slots[(pipe.steps - 1) % 2].done if pipe.steps else torch.cuda.Event()
         if not pipe.steps:
             handover["event"].record(pipe.learn)
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    hand_weights_over()
-    torch.cuda.synchronize(device)
-    handover_ms = 1e3 * (time.perf_counter() - t0)
+    handover_each = []
+    for _ in range(3):   # (the first one of a process also builds the fragment-gather indices on the device: reported apart)
+        torch.cuda.synchronize(device)
+        barrier()
+        t0 = time.perf_counter()
+        hand_weights_over()
+        torch.cuda.synchronize(device)
+        handover_each.append(1e3 * (time.perf_counter() - t0))
+    handover_ms = min(handover_each[1:])
     if acts:
         for _ in range(3):
             actor.step()
@@ -256,7 +260,8 @@ def main():
                "wall_s": wall, "games_ingested": totals["games"], "replay_positions": replay.get_total_len(), "replay_hbm_bytes": replay.hbm_bytes,
                "host_ms_per_round": {k: 1e3 * v / args.rounds for k, v in t_host.items()},
                "host_ms_per_learner_step_enqueue": (1e3 * t_host["learner_enqueue"] / steps_done) if steps_done else None,
-               "weight_handover_ms": handover_ms, "weight_handovers_in_run": handover["count"] - 1,
+               "weight_handover_ms": handover_ms, "weight_handover_first_ms": handover_each[0], "weight_handovers_in_run": handover["count"] - 3,
+               "host_wait_for_the_gpu_ms_per_learner_step": (1e3 * pipe.host_wait_s / max(1, pipe.steps)),
                "checkpoint_interval": cfg.checkpoint_interval, "target_model_interval": cfg.target_model_interval,
                "loss_last": losses[1] if losses else None}
         print(json.dumps(out), flush=True)

@@ -27,7 +27,8 @@ def main():
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     cfg = make_config("Hanabi-Full", simulations=50, stack=4)
     eng = bench.build_engine(cfg, torch.bfloat16, "cuda", net=os.environ.get("NET", "random"))  # NET=sharp: deep paths
-    actor = SelfPlayActor(cfg, eng, num_envs=N, rank=0, seed=1, use_graph=False)
+    actor = SelfPlayActor(cfg, eng, num_envs=N, rank=0, seed=1, use_graph=False,
+                          predicted_lines={"on": True, "off": False}.get(os.environ.get("LINES", "auto"), "auto"))  # LINES=on|off
     actor.mcts.rows_per_workgroup = int(os.environ.get("ROWS", "0"))  # ROWS=16|32 forces
     for _ in range(3):
         actor.step()
