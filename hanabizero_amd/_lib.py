@@ -111,6 +111,9 @@ def _load():
         "hz_search_poll_giveups_async": [V, V],
         # include/hz_replay.h
         "hz_replay_windows": [V, I, V, V, I, I, I, V, I64, I64, I, V],
+        # include/hz_train.h
+        "hz_bn_act_forward": [V, I64, V, I64, V, I64, I, I, V, V, V, V, F, F, V, V, I, I, V],
+        "hz_bn_act_backward": [V, I64, V, I64, V, I64, V, I64, V, I64, I, I, V, V, V, V, V, I, I, V],
         # include/hz_netglue.h
         "hz_add_relu": [V, I64, V, I64, I, I, I, V],
         "hz_test_expf": [V, V, I64, V],

@@ -1,0 +1,284 @@
+// hz_train.hip -- BatchNorm1d (training) + residual + ReLU behind the learner's GEMMs, forward and backward (include/hz_train.h).
+// Latency-bound work: a learner batch is 256 rows, a layer 256..1024 columns.  One workgroup per 32 columns; column sums meet in LDS.
+#include "hz_common.h"
+#include "hz_tree.h"
+#include "hz_train.h"
+
+template <int DT>
+__device__ __forceinline__ float tr_load(const uint16_t* p) {
+  const uint32_t b = *p;
+  if (DT == HZ_BF16) return __uint_as_float(b << 16);
+  const uint16_t h = (uint16_t)b;
+  return (float)*reinterpret_cast<const _Float16*>(&h);
+}
+template <int DT>
+__device__ __forceinline__ uint16_t tr_round(float v) {
+  if (DT == HZ_BF16) {  // round to nearest even, NaN kept quiet (torch's float -> bfloat16)
+    uint32_t u = __float_as_uint(v);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+  }
+  const _Float16 h = (_Float16)v;  // round to nearest even
+  return *reinterpret_cast<const uint16_t*>(&h);
+}
+
+template <int DT>
+__device__ __forceinline__ float tr_requant(float v) {  // through the element format and back: where PyTorch materialises a 16-bit tensor
+  const uint16_t h = tr_round<DT>(v);
+  return tr_load<DT>(&h);
+}
+
+// Thread (g, p) = (tid >> 2, tid & 3) of a 256-thread workgroup owns column pair p of the workgroup's 8 columns (one 4-B access per
+// row) in rows g, g + 64, g + 128, ...: C / 8 workgroups (64 .. 128 for a layer), few dependent steps each.  Up to TR_HOLD rows per
+// thread stay in registers between the passes (the learner's batch of 256: every row, so each input is read from memory ONCE, all
+// loads of a thread in flight together); beyond that the later passes read again (L2).  Column sums: four xor-shuffles across a
+// wave's 16 row groups, then the four waves meet in LDS.
+constexpr int TR_COLS = 8, TR_GROUPS = 64, TR_HOLD = 4;
+
+template <int DT>
+__device__ __forceinline__ float2 tr_load2(const uint16_t* p, bool both) {  // two adjacent elements (4-B aligned when both exist)
+  if (both) {
+    const uint32_t w = *reinterpret_cast<const uint32_t*>(p);
+    const uint16_t lo = (uint16_t)(w & 0xffffu), hi = (uint16_t)(w >> 16);
+    return make_float2(tr_load<DT>(&lo), tr_load<DT>(&hi));
+  }
+  return make_float2(tr_load<DT>(p), 0.0f);
+}
+template <int DT>
+__device__ __forceinline__ void tr_store2(uint16_t* p, float a, float b, bool both) {
+  if (both) *reinterpret_cast<uint32_t*>(p) = (uint32_t)tr_round<DT>(a) | ((uint32_t)tr_round<DT>(b) << 16);
+  else *p = tr_round<DT>(a);
+}
+// sums over the 64 row groups of a workgroup, per column pair (lane & 3); every thread gets its column pair's totals
+__device__ __forceinline__ float4 tr_reduce(float4 v, float4 (*s)[4]) {
+#pragma unroll
+  for (int m = 4; m < 64; m <<= 1) {
+    v.x += __shfl_xor(v.x, m);
+    v.y += __shfl_xor(v.y, m);
+    v.z += __shfl_xor(v.z, m);
+    v.w += __shfl_xor(v.w, m);
+  }
+  const int wave = threadIdx.x >> 6, p = threadIdx.x & 3;
+  if ((threadIdx.x & 63) < 4) s[wave][p] = v;
+  __syncthreads();
+  float4 t = s[0][p];
+#pragma unroll
+  for (int k = 1; k < 4; ++k) {
+    t.x += s[k][p].x; t.y += s[k][p].y; t.z += s[k][p].z; t.w += s[k][p].w;
+  }
+  __syncthreads();
+  return t;
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void k_bn_act_forward(const uint16_t* __restrict__ x, long long xs, const uint16_t* __restrict__ res,
+                                                        long long rs, uint16_t* __restrict__ out, long long os, int rows, int cols,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
+                                                        float* __restrict__ smean, float* __restrict__ sinv, int relu, int vec) {
+  __shared__ float4 s_r[4][4];
+  const int g = threadIdx.x >> 2, p = threadIdx.x & 3, c = blockIdx.x * TR_COLS + 2 * p;
+  const bool on = c < cols, both = vec && c + 1 < cols, on1 = c + 1 < cols;
+  float2 v[TR_HOLD];
+#pragma unroll
+  for (int i = 0; i < TR_HOLD; ++i) {
+    const int r = g + TR_GROUPS * i;
+    v[i] = make_float2(0.0f, 0.0f);
+    if (on && r < rows) {
+      v[i] = tr_load2<DT>(x + (long long)r * xs + c, both);
+      if (!both && on1) v[i].y = tr_load<DT>(x + (long long)r * xs + c + 1);
+    }
+  }
+  float2 sum = make_float2(0.0f, 0.0f);
+#pragma unroll
+  for (int i = 0; i < TR_HOLD; ++i) { sum.x += v[i].x; sum.y += v[i].y; }
+  for (int r = g + TR_GROUPS * TR_HOLD; on && r < rows; r += TR_GROUPS) {
+    sum.x += tr_load<DT>(x + (long long)r * xs + c);
+    if (on1) sum.y += tr_load<DT>(x + (long long)r * xs + c + 1);
+  }
+  {
+    const float4 t = tr_reduce(make_float4(sum.x, sum.y, 0.0f, 0.0f), s_r);
+    sum = make_float2(t.x, t.y);
+  }
+  const float2 mean = make_float2(sum.x / (float)rows, sum.y / (float)rows);
+  float2 sq = make_float2(0.0f, 0.0f);  // (second moment about the mean: no cancellation)
+#pragma unroll
+  for (int i = 0; i < TR_HOLD; ++i)
+    if (g + TR_GROUPS * i < rows) {
+      const float dx = v[i].x - mean.x, dy = v[i].y - mean.y;
+      sq.x += dx * dx;
+      sq.y += dy * dy;
+    }
+  for (int r = g + TR_GROUPS * TR_HOLD; on && r < rows; r += TR_GROUPS) {
+    const float dx = tr_load<DT>(x + (long long)r * xs + c) - mean.x;
+    sq.x += dx * dx;
+    if (on1) {
+      const float dy = tr_load<DT>(x + (long long)r * xs + c + 1) - mean.y;
+      sq.y += dy * dy;
+    }
+  }
+  {
+    const float4 t = tr_reduce(make_float4(sq.x, sq.y, 0.0f, 0.0f), s_r);
+    sq = make_float2(t.x, t.y);
+  }
+  if (!on) return;
+  const float2 var = make_float2(sq.x / (float)rows, sq.y / (float)rows);
+  const float2 inv = make_float2(rsqrtf(var.x + eps), rsqrtf(var.y + eps));
+  if (g == 0) {
+    const float ub = rows > 1 ? (float)rows / (float)(rows - 1) : 1.0f;
+    smean[c] = mean.x; sinv[c] = inv.x;
+    rmean[c] = (1.0f - momentum) * rmean[c] + momentum * mean.x;
+    rvar[c] = (1.0f - momentum) * rvar[c] + momentum * (var.x * ub);
+    if (on1) {
+      smean[c + 1] = mean.y; sinv[c + 1] = inv.y;
+      rmean[c + 1] = (1.0f - momentum) * rmean[c + 1] + momentum * mean.y;
+      rvar[c + 1] = (1.0f - momentum) * rvar[c + 1] + momentum * (var.y * ub);
+    }
+  }
+  const float2 ga = make_float2(gamma[c], on1 ? gamma[c + 1] : 0.0f), be = make_float2(beta[c], on1 ? beta[c + 1] : 0.0f);
+  auto finish = [&](int r, float2 xv) {
+    float a = (xv.x - mean.x) * inv.x * ga.x + be.x, b = (xv.y - mean.y) * inv.y * ga.y + be.y;
+    if (res != nullptr) {  // (bn's output is a 16-bit tensor before the add, as in PyTorch)
+      float2 rv = tr_load2<DT>(res + (long long)r * rs + c, both);
+      if (!both && on1) rv.y = tr_load<DT>(res + (long long)r * rs + c + 1);
+      a = tr_requant<DT>(a) + rv.x;
+      b = tr_requant<DT>(b) + rv.y;
+    }
+    if (relu) {
+      if (!(a > 0.0f)) a = a != a ? a : 0.0f;
+      if (!(b > 0.0f)) b = b != b ? b : 0.0f;
+    }
+    tr_store2<DT>(out + (long long)r * os + c, a, b, both);
+    if (!both && on1) out[(long long)r * os + c + 1] = tr_round<DT>(b);
+  };
+#pragma unroll
+  for (int i = 0; i < TR_HOLD; ++i)
+    if (g + TR_GROUPS * i < rows) finish(g + TR_GROUPS * i, v[i]);
+  for (int r = g + TR_GROUPS * TR_HOLD; r < rows; r += TR_GROUPS)
+    finish(r, make_float2(tr_load<DT>(x + (long long)r * xs + c), on1 ? tr_load<DT>(x + (long long)r * xs + c + 1) : 0.0f));
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void k_bn_act_backward(const uint16_t* __restrict__ dout, long long ds, const uint16_t* __restrict__ out,
+                                                         long long os, const uint16_t* __restrict__ x, long long xs,
+                                                         uint16_t* __restrict__ dx, long long dxs, uint16_t* __restrict__ dres,
+                                                         long long drs, int rows, int cols, const float* __restrict__ gamma,
+                                                         const float* __restrict__ smean, const float* __restrict__ sinv,
+                                                         float* __restrict__ dgamma, float* __restrict__ dbeta, int relu, int vec) {
+  __shared__ float4 s_r[4][4];
+  const int g = threadIdx.x >> 2, p = threadIdx.x & 3, c = blockIdx.x * TR_COLS + 2 * p;
+  const bool on = c < cols, both = vec && c + 1 < cols, on1 = c + 1 < cols;
+  const float2 mean = make_float2(on ? smean[c] : 0.0f, on1 ? smean[c + 1] : 0.0f);
+  const float2 inv = make_float2(on ? sinv[c] : 0.0f, on1 ? sinv[c + 1] : 0.0f);
+  auto fetch = [&](int r, float2& dz, float2& xh) {  // dz = dout masked by the ReLU, xh = the normalised input
+    dz = tr_load2<DT>(dout + (long long)r * ds + c, both);
+    float2 xv = tr_load2<DT>(x + (long long)r * xs + c, both);
+    if (!both && on1) {
+      dz.y = tr_load<DT>(dout + (long long)r * ds + c + 1);
+      xv.y = tr_load<DT>(x + (long long)r * xs + c + 1);
+    }
+    if (relu) {
+      float2 o = tr_load2<DT>(out + (long long)r * os + c, both);
+      if (!both && on1) o.y = tr_load<DT>(out + (long long)r * os + c + 1);
+      if (!(o.x > 0.0f)) dz.x = 0.0f;
+      if (!(o.y > 0.0f)) dz.y = 0.0f;
+    }
+    xh = make_float2((xv.x - mean.x) * inv.x, (xv.y - mean.y) * inv.y);
+  };
+  float2 dzv[TR_HOLD], xhv[TR_HOLD];
+  float2 s1 = make_float2(0.0f, 0.0f), s2 = make_float2(0.0f, 0.0f);
+#pragma unroll
+  for (int i = 0; i < TR_HOLD; ++i) {
+    dzv[i] = xhv[i] = make_float2(0.0f, 0.0f);
+    if (on && g + TR_GROUPS * i < rows) fetch(g + TR_GROUPS * i, dzv[i], xhv[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < TR_HOLD; ++i) {
+    s1.x += dzv[i].x; s1.y += dzv[i].y;
+    s2.x += dzv[i].x * xhv[i].x; s2.y += dzv[i].y * xhv[i].y;
+  }
+  for (int r = g + TR_GROUPS * TR_HOLD; on && r < rows; r += TR_GROUPS) {
+    float2 dz, xh;
+    fetch(r, dz, xh);
+    s1.x += dz.x; s1.y += dz.y;
+    s2.x += dz.x * xh.x; s2.y += dz.y * xh.y;
+  }
+  {
+    const float4 t = tr_reduce(make_float4(s1.x, s1.y, s2.x, s2.y), s_r);  // both sums in one trip
+    s1 = make_float2(t.x, t.y);
+    s2 = make_float2(t.z, t.w);
+  }
+  if (!on) return;
+  if (g == 0) {
+    dbeta[c] += s1.x; dgamma[c] += s2.x;
+    if (on1) { dbeta[c + 1] += s1.y; dgamma[c + 1] += s2.y; }
+  }
+  const float2 m1 = make_float2(s1.x / (float)rows, s1.y / (float)rows), m2 = make_float2(s2.x / (float)rows, s2.y / (float)rows);
+  const float2 k = make_float2(gamma[c] * inv.x, on1 ? gamma[c + 1] * inv.y : 0.0f);
+  auto finish = [&](int r, float2 dz, float2 xh) {
+    const float a = k.x * (dz.x - m1.x - xh.x * m2.x), b = k.y * (dz.y - m1.y - xh.y * m2.y);
+    tr_store2<DT>(dx + (long long)r * dxs + c, a, b, both);
+    if (!both && on1) dx[(long long)r * dxs + c + 1] = tr_round<DT>(b);
+    if (dres != nullptr) {
+      tr_store2<DT>(dres + (long long)r * drs + c, dz.x, dz.y, both);
+      if (!both && on1) dres[(long long)r * drs + c + 1] = tr_round<DT>(dz.y);
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < TR_HOLD; ++i)
+    if (g + TR_GROUPS * i < rows) finish(g + TR_GROUPS * i, dzv[i], xhv[i]);
+  for (int r = g + TR_GROUPS * TR_HOLD; r < rows; r += TR_GROUPS) {
+    float2 dz, xh;
+    fetch(r, dz, xh);
+    finish(r, dz, xh);
+  }
+}
+
+extern "C" int hz_bn_act_forward(const void* x, int64_t x_stride, const void* res, int64_t res_stride, void* out, int64_t out_stride, int rows,
+                                 int cols, const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
+                                 float eps, float* save_mean, float* save_invstd, int relu, int dtype, void* stream) {
+  HZ_REQUIRE(x && out && gamma && beta && running_mean && running_var && save_mean && save_invstd, "hz_bn_act_forward: null pointer");
+  HZ_REQUIRE(rows >= 1 && cols >= 1 && x_stride >= cols && out_stride >= cols && (!res || res_stride >= cols),
+             "hz_bn_act_forward: rows=%d cols=%d strides %lld / %lld / %lld", rows, cols, (long long)x_stride, (long long)out_stride, (long long)res_stride);
+  HZ_REQUIRE(dtype == HZ_BF16 || dtype == HZ_F16, "hz_bn_act_forward: dtype %d (HZ_BF16 or HZ_F16)", dtype);
+  HZ_REQUIRE(eps > 0.0f && momentum >= 0.0f && momentum <= 1.0f, "hz_bn_act_forward: eps=%g momentum=%g", (double)eps, (double)momentum);
+  const dim3 grid((cols + TR_COLS - 1) / TR_COLS);
+  // (two adjacent columns per 4-B access where every row starts 4-B aligned)
+  const int vec = (x_stride % 2 == 0 && out_stride % 2 == 0 && (!res || res_stride % 2 == 0) && ((uintptr_t)x % 4) == 0 && ((uintptr_t)out % 4) == 0 &&
+                   (!res || ((uintptr_t)res % 4) == 0)) ? 1 : 0;
+  if (dtype == HZ_BF16)
+    hipLaunchKernelGGL(k_bn_act_forward<HZ_BF16>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, (long long)x_stride, (const uint16_t*)res,
+                       (long long)res_stride, (uint16_t*)out, (long long)out_stride, rows, cols, gamma, beta, running_mean, running_var, momentum, eps,
+                       save_mean, save_invstd, relu, vec);
+  else
+    hipLaunchKernelGGL(k_bn_act_forward<HZ_F16>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, (long long)x_stride, (const uint16_t*)res,
+                       (long long)res_stride, (uint16_t*)out, (long long)out_stride, rows, cols, gamma, beta, running_mean, running_var, momentum, eps,
+                       save_mean, save_invstd, relu, vec);
+  HZ_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int hz_bn_act_backward(const void* dout, int64_t dout_stride, const void* out, int64_t out_stride, const void* x, int64_t x_stride,
+                                  void* dx, int64_t dx_stride, void* dres, int64_t dres_stride, int rows, int cols, const float* gamma,
+                                  const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, int relu, int dtype,
+                                  void* stream) {
+  HZ_REQUIRE(dout && x && dx && gamma && save_mean && save_invstd && dgamma && dbeta && (out || !relu), "hz_bn_act_backward: null pointer");
+  HZ_REQUIRE(rows >= 1 && cols >= 1 && dout_stride >= cols && x_stride >= cols && dx_stride >= cols && (!relu || out_stride >= cols) &&
+                 (!dres || dres_stride >= cols),
+             "hz_bn_act_backward: rows=%d cols=%d and a row stride below cols", rows, cols);
+  HZ_REQUIRE(dtype == HZ_BF16 || dtype == HZ_F16, "hz_bn_act_backward: dtype %d (HZ_BF16 or HZ_F16)", dtype);
+  const dim3 grid((cols + TR_COLS - 1) / TR_COLS);
+  auto al = [](const void* q, int64_t st) { return !q || (st % 2 == 0 && ((uintptr_t)q % 4) == 0); };
+  const int vec = (al(dout, dout_stride) && al(relu ? out : nullptr, out_stride) && al(x, x_stride) && al(dx, dx_stride) && al(dres, dres_stride)) ? 1 : 0;
+  if (dtype == HZ_BF16)
+    hipLaunchKernelGGL(k_bn_act_backward<HZ_BF16>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dout, (long long)dout_stride,
+                       (const uint16_t*)out, (long long)out_stride, (const uint16_t*)x, (long long)x_stride, (uint16_t*)dx, (long long)dx_stride,
+                       (uint16_t*)dres, (long long)dres_stride, rows, cols, gamma, save_mean, save_invstd, dgamma, dbeta, relu, vec);
+  else
+    hipLaunchKernelGGL(k_bn_act_backward<HZ_F16>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dout, (long long)dout_stride,
+                       (const uint16_t*)out, (long long)out_stride, (const uint16_t*)x, (long long)x_stride, (uint16_t*)dx, (long long)dx_stride,
+                       (uint16_t*)dres, (long long)dres_stride, rows, cols, gamma, save_mean, save_invstd, dgamma, dbeta, relu, vec);
+  HZ_HIP(hipGetLastError());
+  return 0;
+}

@@ -25,6 +25,8 @@ last_run = {}  # lock-steps / envs of the last test() call (tools/next_rows_benc
 
 def test(config, engine, counter=0, test_episodes=1000, device=None, tie_seed=0, max_moves=None, use_graph=True, check_every=8):
     """Returns (ep_final_rewards list[int], ep_steps list[int])."""
+    import time
+    t_start = time.perf_counter()
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     E = int(test_episodes)
     from ._lib import poll_giveups
@@ -37,6 +39,10 @@ def test(config, engine, counter=0, test_episodes=1000, device=None, tie_seed=0,
     final = np.full(E, -1, np.int64)
     steps = np.zeros(E, np.int64)
     with torch.no_grad():
+        if use_graph:           # (the capture plays its three moves now: `last_run` times it apart from the replays)
+            actor.step()
+            torch.cuda.synchronize(device)
+        t_loop, moves_at_loop = time.perf_counter(), actor.total_moves
         while (final < 0).any() and actor.total_moves // E < limit:
             before = actor.total_moves
             while actor.total_moves - before < check_every * E:  # (the first step() of a graph actor plays three moves)
@@ -52,6 +58,8 @@ def test(config, engine, counter=0, test_episodes=1000, device=None, tie_seed=0,
     if fused and poll_giveups() != giveups_before:  # (include/hz_mlp.h: must not happen)
         raise RuntimeError("the fused inference gave up waits on its arrival counters during this evaluation: its searches "
                            "ran with inputs that may not have been there")
-    last_run.update(lock_steps=actor.total_moves // E, envs=E)
+    torch.cuda.synchronize(device)
+    last_run.update(lock_steps=actor.total_moves // E, envs=E, setup_and_capture_s=t_loop - t_start, replay_s=time.perf_counter() - t_loop,
+                    replayed_lock_steps=(actor.total_moves - moves_at_loop) // E)
     done = final >= 0  # (episodes still running at `max_moves` report score 0 after that many steps)
     return np.where(done, final, 0).tolist(), np.where(done, steps, actor.total_moves // E).tolist()

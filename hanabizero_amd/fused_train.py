@@ -1,0 +1,212 @@
+"""hanabizero_amd.fused_train -- the learner's forward / backward through MuZeroNet / MuZeroNetFull with every
+Linear -> BatchNorm1d -> (+ skip) -> ReLU block as one hipBLASLt GEMM + ONE hand-written launch (include/hz_train.h), in 16 bits.
+
+What it replaces: the module forward PyTorch autograd runs under autocast inside ``update_weights``
+(/root/reference/core/train.py:114-222; blocks of config/hanabi_control/model.py:18-125, 131-149, 241-269).  Same parameters
+(the wrapped module's own tensors: state_dict, optimiser and weight hand-over do not change), same arithmetic per block as
+``F.linear`` + ``F.batch_norm(training=True)`` + add + ReLU under bf16 autocast -- 16-bit GEMM with fp32 accumulate, batch
+statistics in fp32, running statistics updated with momentum 0.1, outputs rounded where autocast materialises 16-bit tensors --
+but per block 2 launches forward and 4 backward instead of ~20: a learner step at batch 256 is launch-bound (~1.7 k kernels of a
+few microseconds; profiles/r04_learner_kernel_stats.md).
+
+How the gradients travel: a block's backward writes the BatchNorm affine gradients and the Linear weight gradient straight INTO
+the parameters' ``.grad`` (accumulating: the recurrent blocks are used num_unroll_steps times per step), so the parameters never
+enter autograd; ``.grad`` must exist and be zeroed per step (``optimizer.zero_grad(set_to_none=False)``, what GraphedUpdate
+does).  The gradient of a Linear bias in front of a training-mode BatchNorm is identically zero (the normalisation removes any
+per-column constant) and is left at zero rather than computed as 16-bit rounding noise.  16-bit copies of the Linear weights are
+refreshed once per step (``refresh()``) instead of cast at every use.
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from ._lib import check, lib
+from .model import NetworkOutput, _Dyn, _Res
+
+_DT = {torch.bfloat16: 1, torch.float16: 2}  # include/hz_tree.h HZ_BF16 / HZ_F16
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _Block:
+    """Linear (+ BatchNorm1d) of the wrapped module; `w16` / `b16`: the Linear's parameters in the compute format."""
+
+    def __init__(self, lin, bn, dtype, uses):
+        self.lin, self.bn, self.uses = lin, bn, uses
+        self.w16 = lin.weight.detach().to(dtype)
+        self.b16 = lin.bias.detach().to(dtype)
+
+
+class _LinBNAct(torch.autograd.Function):
+    """out = act(batch_norm(x @ W^T + b) + res): forward GEMM + hz_bn_act_forward; backward hz_bn_act_backward + two GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x, res, blk, relu, anchor=None):
+        """anchor: any tensor that requires grad (the parameters do not enter autograd here: the first block of a forward, whose
+        input is data, needs one for its output to be part of the graph); its gradient is None."""
+        bn = blk.bn
+        y = torch.addmm(blk.b16, x, blk.w16.t())
+        out = torch.empty_like(y)
+        B, Cn = y.shape
+        stats = torch.empty((2, Cn), dtype=torch.float32, device=y.device)
+        if res is not None:
+            assert res.shape == y.shape and res.stride(1) == 1 and res.dtype == y.dtype
+        check(lib.hz_bn_act_forward(y.data_ptr(), y.stride(0), None if res is None else res.data_ptr(), 0 if res is None else res.stride(0),
+                                    out.data_ptr(), out.stride(0), B, Cn, bn.weight.data_ptr(), bn.bias.data_ptr(),
+                                    bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.momentum), float(bn.eps),
+                                    stats[0].data_ptr(), stats[1].data_ptr(), int(relu), _DT[y.dtype], _stream()), "hz_bn_act_forward")
+        ctx.blk, ctx.relu, ctx.has_res = blk, relu, res is not None
+        ctx.save_for_backward(x, y, out, stats)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, y, out, stats = ctx.saved_tensors
+        blk, bn = ctx.blk, ctx.blk.bn
+        if dout.stride(1) != 1:
+            dout = dout.contiguous()
+        B, Cn = y.shape
+        dy = torch.empty_like(y)
+        dres = torch.empty_like(y) if ctx.has_res else None
+        check(lib.hz_bn_act_backward(dout.data_ptr(), dout.stride(0), out.data_ptr(), out.stride(0), y.data_ptr(), y.stride(0),
+                                     dy.data_ptr(), dy.stride(0), None if dres is None else dres.data_ptr(), 0 if dres is None else dres.stride(0),
+                                     B, Cn, bn.weight.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), bn.weight.grad.data_ptr(),
+                                     bn.bias.grad.data_ptr(), int(ctx.relu), _DT[y.dtype], _stream()), "hz_bn_act_backward")
+        g = blk.lin.weight.grad                                # W.grad += dy^T x: ONE GEMM, 16-bit operands, fp32 accumulate and output
+        torch.addmm(g, dy.t(), x, out_dtype=torch.float32, out=g)
+        dx = torch.mm(dy, blk.w16) if ctx.needs_input_grad[0] else None
+        return dx, dres, None, None, None
+
+
+class _Lin(torch.autograd.Function):
+    """A head's last layer: y = x @ W^T + b (no BatchNorm behind it)."""
+
+    @staticmethod
+    def forward(ctx, x, blk):
+        ctx.blk = blk
+        ctx.save_for_backward(x)
+        return torch.addmm(blk.b16, x, blk.w16.t())
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        blk = ctx.blk
+        g = blk.lin.weight.grad
+        torch.addmm(g, dy.t(), x, out_dtype=torch.float32, out=g)
+        blk.lin.bias.grad.add_(dy.sum(0, dtype=torch.float32))
+        return torch.mm(dy, blk.w16), None
+
+
+class FusedTrainNet:
+    """The training-mode forward of `net` (MuZeroNet / MuZeroNetFull on a GPU) through the fused blocks.  Quacks like the module
+    where the learner touches it: initial_inference / recurrent_inference (training branch of core/model.py:61-84: logits and the
+    hidden state, no scalar transform), parameters / buffers / state_dict / load_state_dict / train; `net` is the module itself
+    (weight hand-over: InferenceEngine.load(model.net))."""
+
+    def __init__(self, net, dtype=torch.bfloat16, unroll_steps=5):
+        assert next(net.parameters()).is_cuda, "the fused blocks are HIP kernels"
+        self.net, self.dtype = net, dtype
+        self.A = net.action_space_n
+        U = int(unroll_steps)
+        self._blocks = []
+        mk = lambda lin, bn, uses: self._mk(lin, bn, uses)
+        self.rep = self._chain(net._representation, 1, mk)
+        d = net._dynamics_state
+        self.dyn = (d.early_skip, mk(d.fc1, d.bn1, U), mk(d.fc2, d.bn2, U), mk(d.fc3, d.bn3, U))
+        self.reward = self._chain(net._dynamics_reward, U, mk)
+        self.actor = self._chain(net._prediction_actor, U + 1, mk)
+        self.value = self._chain(net._prediction_value, U + 1, mk)
+        for p in net.parameters():
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        self._w32 = [b.lin.weight for b in self._blocks] + [b.lin.bias for b in self._blocks]
+        self._w16 = [b.w16 for b in self._blocks] + [b.b16 for b in self._blocks]
+        self._anchor = torch.zeros(1, device=self._w16[0].device, requires_grad=True)
+        self._counters = [b.bn.num_batches_tracked for b in self._blocks if b.bn is not None]
+        self._uses = [b.uses for b in self._blocks if b.bn is not None]
+
+    def _mk(self, lin, bn, uses):
+        b = _Block(lin, bn, self.dtype, uses)
+        self._blocks.append(b)
+        return b
+
+    def _chain(self, seq, uses, mk):
+        """nn.Sequential of [Linear, BatchNorm1d, ReLU]* / _Res / trailing Linear -> a list of steps."""
+        mods, steps, i = list(seq), [], 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, nn.Linear) and i + 2 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm1d):
+                assert isinstance(mods[i + 2], nn.ReLU)
+                steps.append(("lbr", mk(m, mods[i + 1], uses)))
+                i += 3
+            elif isinstance(m, _Res):
+                steps.append(("res", m.early_skip, mk(m.fc1, m.bn1, uses), mk(m.fc2, m.bn2, uses)))
+                i += 1
+            elif isinstance(m, nn.Linear):
+                steps.append(("lin", mk(m, None, uses)))
+                i += 1
+            else:
+                raise TypeError("fused_train: unexpected module %r" % (m,))
+        return steps
+
+    # -- the pieces the learner touches -------------------------------------------------------------------------------------
+    def parameters(self):
+        return self.net.parameters()
+
+    def buffers(self):
+        return self.net.buffers()
+
+    def state_dict(self):
+        return self.net.state_dict()
+
+    def load_state_dict(self, sd):
+        out = self.net.load_state_dict(sd)
+        self.refresh()
+        return out
+
+    def train(self, mode=True):
+        self.net.train(mode)
+        return self
+
+    def refresh(self):
+        """The 16-bit copies of the Linear parameters from the fp32 ones (once per optimiser step; one multi-tensor launch)."""
+        with torch.no_grad():
+            torch._foreach_copy_(self._w16, self._w32)
+
+    def count_batches(self):
+        """num_batches_tracked of every BatchNorm as the module's own forward would have left it after one learner step."""
+        with torch.no_grad():
+            torch._foreach_add_(self._counters, self._uses)
+
+    # -- forward ------------------------------------------------------------------------------------------------------------
+    def _run(self, steps, x):
+        for st in steps:
+            if st[0] == "lbr":
+                x = _LinBNAct.apply(x, None, st[1], True, None if x.requires_grad else self._anchor)
+            elif st[0] == "res":
+                _, early, b1, b2 = st
+                if early:   # ResMLP: skip added behind the first BatchNorm (model.py:18-30)
+                    x = _LinBNAct.apply(_LinBNAct.apply(x, x, b1, True), None, b2, True)
+                else:       # NewResMLP: behind the second (model.py:43-57)
+                    x = _LinBNAct.apply(_LinBNAct.apply(x, None, b1, True), x, b2, True)
+            else:
+                x = _Lin.apply(x, st[1])
+        return x
+
+    def initial_inference(self, obs):  # core/model.py:61-71, training branch
+        state = self._run(self.rep, obs.to(self.dtype))
+        return NetworkOutput(self._run(self.value, state), [0.0] * obs.shape[0], self._run(self.actor, state), state)
+
+    def recurrent_inference(self, hidden_state, action):  # core/model.py:74-84, training branch
+        B = hidden_state.shape[0]
+        one_hot = torch.zeros(B, self.A, dtype=self.dtype, device=hidden_state.device)
+        one_hot.scatter_(1, action, 1.0)
+        early, b1, b2, b3 = self.dyn
+        sa = torch.cat((hidden_state, one_hot), 1)
+        y = _LinBNAct.apply(sa, hidden_state if early else None, b1, True)
+        y = _LinBNAct.apply(y, None, b2, True)
+        state = _LinBNAct.apply(y, None if early else hidden_state, b3, True)
+        return NetworkOutput(self._run(self.value, state), self._run(self.reward, state), self._run(self.actor, state), state)

@@ -244,10 +244,14 @@ def update_weights(model, batch, optimizer, config, amp=torch.bfloat16):
     total_loss = weighted_loss
     gradient_scale = 1.0 / config.num_unroll_steps
     total_loss.register_hook(lambda grad: grad * gradient_scale)  # train.py:222-229
-    optimizer.zero_grad()
+    fused = hasattr(model, "refresh")  # (hanabizero_amd.fused_train.FusedTrainNet: its blocks accumulate into existing .grad tensors)
+    optimizer.zero_grad(set_to_none=not fused)
     total_loss.backward()
     torch.nn.utils.clip_grad_norm_(model.parameters(), config.max_grad_norm)
     optimizer.step()
+    if fused:
+        model.refresh()
+        model.count_batches()
     r = config.priority_reward_ratio
     new_priority = (1 - r) * (parts["value_priority"] + config.prioritized_replay_eps) + r * parts["reward_priority"]
     f = lambda t: float(t.detach())
@@ -290,6 +294,9 @@ class GraphedUpdate:
         total_loss.backward()
         torch.nn.utils.clip_grad_norm_(self.model.parameters(), cfg.max_grad_norm, foreach=True)
         self.optimizer.step()
+        if hasattr(self.model, "refresh"):  # (fused_train.FusedTrainNet: the 16-bit weight copies follow the step, inside the graph)
+            self.model.refresh()
+            self.model.count_batches()
         r = cfg.priority_reward_ratio
         self.priority.copy_((1 - r) * (parts["value_priority"] + cfg.prioritized_replay_eps) + r * parts["reward_priority"])
         self.out.copy_(torch.stack([total_loss.detach(), weighted_loss.detach(), parts["loss"].detach().mean(),
@@ -316,6 +323,8 @@ class GraphedUpdate:
             for st in self.optimizer.state.values():
                 if st.get("momentum_buffer") is not None:
                     st["momentum_buffer"].zero_()  # (a zero buffer gives the first real step what a missing one gives it)
+            if hasattr(self.model, "refresh"):
+                self.model.refresh()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, capture_error_mode="thread_local"):
             self._body()
@@ -401,7 +410,8 @@ class LearnerPipeline:
         self.gen = torch.Generator(device=dev)
         self.gen.manual_seed(int(seed))
         import copy
-        self._recent_net = copy.deepcopy(model)  # train.py:396-398: the target model runs one interval behind
+        self.net = getattr(model, "net", model)  # (the nn.Module itself where `model` is fused_train.FusedTrainNet)
+        self._recent_net = copy.deepcopy(self.net)  # train.py:396-398: the target model runs one interval behind
         cur = torch.cuda.current_stream(dev)
         self.prep.wait_stream(cur)
         self.learn.wait_stream(cur)
@@ -428,7 +438,7 @@ class LearnerPipeline:
                 prev = self.slots[(k - 1) % 2]
                 self.prep.wait_event(prev.done)                # (the learner's weights as of step k - 1 are complete)
                 self.target.load(self._recent_net)
-                self._recent_net.load_state_dict(self.model.state_dict())
+                self._recent_net.load_state_dict(self.net.state_dict())
                 self._weights_taken = torch.cuda.Event()
                 self._weights_taken.record(self.prep)
                 self.learn.wait_event(self._weights_taken)     # (the next update must not overwrite what is being copied)

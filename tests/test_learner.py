@@ -442,3 +442,109 @@ def test_config5_loop_hanabi_full_5p_with_reanalyze_on_one_gpu():
         actor.step()
     torch.cuda.synchronize()
     assert int(actor.illegal_steps) == 0 and int(actor.out_count[0].item()) > before
+
+
+# ---- the fused Linear + BatchNorm + ReLU blocks of the learner (include/hz_train.h, hanabizero_amd/fused_train.py) ----------
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("rows,cols,relu,with_res", [(256, 512, True, False), (256, 1024, True, True), (64, 200, False, True), (7, 33, True, False)])
+def test_bn_act_kernels_against_fp32_reference(dtype, rows, cols, relu, with_res):
+    """hz_bn_act_forward / hz_bn_act_backward against plain PyTorch fp32 of the same op on the same 16-bit inputs:
+    batch_norm(training) -> (+ residual, through the 16-bit rounding autocast puts there) -> ReLU; outputs to one unit of the
+    element format, statistics and affine gradients to fp32 summation order."""
+    import ctypes as C
+    from hanabizero_amd._lib import check, lib
+    g = torch.Generator(device="cuda").manual_seed(rows * cols)
+    x = (torch.randn(rows, cols, device="cuda", generator=g) * 1.7 + 0.3).to(dtype)
+    res = torch.randn(rows, cols, device="cuda", generator=g).to(dtype) if with_res else None
+    gamma = torch.rand(cols, device="cuda", generator=g) + 0.5
+    beta = torch.randn(cols, device="cuda", generator=g) * 0.2
+    rm, rv = torch.randn(cols, device="cuda", generator=g) * 0.1, torch.rand(cols, device="cuda", generator=g) + 0.5
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    dout = torch.randn(rows, cols, device="cuda", generator=g).to(dtype)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    dt = {torch.bfloat16: 1, torch.float16: 2}[dtype]
+    out, stats = torch.empty_like(x), torch.empty(2, cols, device="cuda")
+    check(lib.hz_bn_act_forward(x.data_ptr(), cols, None if res is None else res.data_ptr(), cols, out.data_ptr(), cols, rows, cols, gamma.data_ptr(),
+                                beta.data_ptr(), rm.data_ptr(), rv.data_ptr(), 0.1, 1e-5, stats[0].data_ptr(), stats[1].data_ptr(), int(relu), dt, st), "fwd")
+    # fp32 reference
+    xr = x.float().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    bn = torch.nn.functional.batch_norm(xr, rm_ref, rv_ref, gr, br, training=True, momentum=0.1, eps=1e-5)
+    rr = res.float().requires_grad_(True) if with_res else None
+    pre = bn.to(dtype).float() + rr if with_res else bn      # (autocast materialises bn's output in 16 bits before the add)
+    if with_res:
+        pre = bn + (bn.to(dtype).float() - bn).detach() + rr   # same value, gradient of the identity (straight through the rounding)
+    want = torch.relu(pre) if relu else pre
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    assert torch.allclose(out.float(), want.to(dtype).float(), rtol=2 * ulp, atol=2 * ulp)
+    assert torch.allclose(rm, rm_ref, rtol=1e-5, atol=1e-6) and torch.allclose(rv, rv_ref, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(stats[0], x.float().mean(0), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(stats[1], torch.rsqrt(x.float().var(0, unbiased=False) + 1e-5), rtol=1e-5)
+    # backward: the ReLU mask comes from the kernel's own 16-bit output
+    dx, dres = torch.empty_like(x), (torch.empty_like(x) if with_res else None)
+    dgamma, dbeta = torch.full((cols,), 0.5, device="cuda"), torch.full((cols,), -0.25, device="cuda")  # (accumulated into)
+    check(lib.hz_bn_act_backward(dout.data_ptr(), cols, out.data_ptr(), cols, x.data_ptr(), cols, dx.data_ptr(), cols,
+                                 None if dres is None else dres.data_ptr(), cols, rows, cols, gamma.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(),
+                                 dgamma.data_ptr(), dbeta.data_ptr(), int(relu), dt, st), "bwd")
+    mask = (out.float() > 0).float() if relu else torch.ones_like(want)
+    (pre * (dout.float() * mask).detach()).sum().backward()
+    scale = float(xr.grad.abs().max())
+    assert torch.allclose(dx.float(), xr.grad, rtol=4 * ulp, atol=4 * ulp * scale)
+    assert torch.allclose(dgamma - 0.5, gr.grad, rtol=1e-4, atol=1e-4 * float(gr.grad.abs().max()))
+    assert torch.allclose(dbeta + 0.25, br.grad, rtol=1e-4, atol=1e-4 * float(br.grad.abs().max()))
+    if with_res:
+        assert torch.equal(dres.float(), (dout.float() * mask).to(dtype).float())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("game,stack", [("Hanabi-Small", 2), ("Hanabi-Full-5p", 4)])
+def test_fused_learner_step_matches_the_autocast_step(game, stack):
+    """update_weights through fused_train.FusedTrainNet (GEMM + one launch per block) against update_weights through the module's
+    own forward under bf16 autocast -- the path the reference-recorded fixtures pin (tests/test_reference_callers.py) -- from the
+    same weights on the same batch: losses, priorities, every parameter's gradient direction, the stepped weights, the
+    BatchNorm running statistics and counters."""
+    import copy
+    from hanabizero_amd.fused_train import FusedTrainNet
+    from hanabizero_amd.learner import make_optimizer, update_weights
+    cfg = _cfg(game, stack)
+    for seed in (3, 4):  # (one step each from fresh, identical weights: after a step the two 16-bit computations have drifted apart
+        torch.manual_seed(seed)  # by their own rounding, and the deep layers' gradients are sensitive to that)
+        net = cfg.get_uniform_network()
+        for p in net.parameters():
+            if float(p.detach().abs().sum()) == 0.0:
+                torch.nn.init.normal_(p, std=0.05)
+        net = net.cuda()
+        net2, net3 = copy.deepcopy(net), copy.deepcopy(net)
+        batch = _batch(cfg, 64, seed)
+        opt1, opt2 = make_optimizer(net, cfg), make_optimizer(net2, cfg)
+        fused = FusedTrainNet(net2, unroll_steps=cfg.num_unroll_steps)
+        update_weights(net3, batch, make_optimizer(net3, cfg), cfg, amp=None)   # the same step in fp32: what both 16-bit paths approximate
+        g0 = [p.grad.clone() for p in net3.parameters()]
+        l1, p1 = update_weights(net, batch, opt1, cfg, amp=torch.bfloat16)
+        g1 = [p.grad.clone() for p in net.parameters()]
+        l2, p2 = update_weights(fused, batch, opt2, cfg, amp=torch.bfloat16)
+        g2 = [p.grad.clone() for p in net2.parameters()]
+        assert np.allclose(l1, l2, rtol=2e-2, atol=1e-3), (seed, l1, l2)
+        assert np.allclose(p1, p2, rtol=5e-2, atol=5e-2)
+        names = [n for n, _ in net.named_parameters()]
+        cosine = lambda u, v: float((u * v).sum() / (u.norm() * v.norm() + 1e-30))
+        for n, z, a, b in zip(names, g0, g1, g2):
+            if float(b.abs().sum()) == 0.0 and float(z.norm()) < 1e-4 * max(1.0, float(a.norm())) + 1e-5:
+                continue  # a Linear bias in front of a BatchNorm: zero in fp32 too (rounding noise under autocast, exactly zero in the fused block)
+            if float(z.norm()) < 1e-6:
+                continue
+            # every parameter's gradient: as close to the fp32 gradient as the autocast step's is (the deepest layers' gradients pass
+            # through every rounding of the unrolled net: 0.90 - 0.97 against fp32 on either 16-bit path), and close to the autocast one
+            c_auto, c_fused = cosine(z, a), cosine(z, b)
+            assert c_fused > c_auto - 0.03 and c_fused > 0.85, (seed, n, c_auto, c_fused)
+            assert cosine(a, b) > 0.9, (seed, n, cosine(a, b))
+            assert 0.9 < float(b.norm() / a.norm()) < 1.1, (seed, n)
+        for (n, a), b in zip(net.state_dict().items(), net2.state_dict().values()):
+            if n.endswith("num_batches_tracked"):
+                assert int(a) == int(b), n
+            else:
+                assert torch.allclose(a, b, rtol=2e-2, atol=2e-3), (n, float((a - b).abs().max()))
+        # the fused model's 16-bit weight copies follow the step
+        for blk in fused._blocks:
+            assert torch.equal(blk.w16, blk.lin.weight.detach().to(torch.bfloat16))

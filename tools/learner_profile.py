@@ -21,11 +21,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--game", default="Hanabi-Full-5p")
     ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--eager", action="store_true")
+    ap.add_argument("--fused", action="store_true", help="the module forward through the fused Linear + BatchNorm + ReLU blocks (hanabizero_amd/fused_train.py)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     cfg = make_config(args.game, simulations=50, stack=4, p_mcts_num=256, batch_size=256)
     net = cfg.get_uniform_network().to(dev)
+    if args.fused:
+        from hanabizero_amd.fused_train import FusedTrainNet
+        net = FusedTrainNet(net, unroll_steps=cfg.num_unroll_steps)
     opt = make_optimizer(net, cfg, capturable=True)
     g = GraphedUpdate(net, opt, cfg, cfg.batch_size)
     B, U, A, stack = cfg.batch_size, cfg.num_unroll_steps, cfg.action_space_size, cfg.stacked_observations
@@ -47,7 +50,7 @@ def main():
         g._graph.replay()
     torch.cuda.synchronize()
     replay = (time.perf_counter() - t0) / args.steps
-    print(json.dumps({"game": args.game, "ms_per_step_with_batch_copy_and_readback": 1e3 * with_copy, "ms_per_graph_replay": 1e3 * replay}))
+    print(json.dumps({"game": args.game, "blocks": "fused" if args.fused else "autograd under autocast", "ms_per_step_with_batch_copy_and_readback": 1e3 * with_copy, "ms_per_graph_replay": 1e3 * replay}))
 
 
 if __name__ == "__main__":

@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--share-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--learner-acts", action="store_true", help="N > 1: rank 0 plays too (default: it only learns)")
+    ap.add_argument("--eager-blocks", action="store_true", help="the learner's module forward through PyTorch autograd under autocast instead of the fused Linear + BatchNorm + ReLU blocks (include/hz_train.h)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         import bench
@@ -109,6 +110,9 @@ def main():
         target = bench.build_engine(cfg, dtype, device)
         learner = cfg.get_uniform_network().to(device)
         learner.load_state_dict((engine or target)._net.state_dict())
+        if not args.eager_blocks:
+            from hanabizero_amd.fused_train import FusedTrainNet
+            learner = FusedTrainNet(learner, unroll_steps=cfg.num_unroll_steps)
 
         def on_checkpoint(step, done_event):
             handover["pending"], handover["event"] = True, done_event
@@ -131,7 +135,7 @@ def main():
             ws = actor._work_stream()
             with torch.cuda.stream(ws):
                 ws.wait_event(handover["event"])
-                engine.load(pipe.model)
+                engine.load(pipe.net)
                 taken = torch.cuda.Event()
                 taken.record(ws)
             pipe.learn.wait_event(taken)  # (the next update must not overwrite what is being folded)
@@ -139,7 +143,7 @@ def main():
             state = None
             if learns:
                 pipe.learn.synchronize()
-                state = {k: v.detach() for k, v in pipe.model.state_dict().items()}
+                state = {k: v.detach() for k, v in pipe.net.state_dict().items()}
             else:
                 state = {k: v.detach() for k, v in net_dev.state_dict().items()}
             if coll_dev.type == "cpu":
@@ -263,7 +267,7 @@ def main():
                "weight_handover_ms": handover_ms, "weight_handover_first_ms": handover_each[0], "weight_handovers_in_run": handover["count"] - 3,
                "host_wait_for_the_gpu_ms_per_learner_step": (1e3 * pipe.host_wait_s / max(1, pipe.steps)),
                "checkpoint_interval": cfg.checkpoint_interval, "target_model_interval": cfg.target_model_interval,
-               "loss_last": losses[1] if losses else None}
+               "loss_last": losses[1] if losses else None, "learner_blocks": "autograd (autocast)" if args.eager_blocks else "fused (include/hz_train.h)"}
         print(json.dumps(out), flush=True)
     if world > 1:
         barrier()

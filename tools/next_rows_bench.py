@@ -100,13 +100,18 @@ def main():
                                        # the batch keeps all 1000 envs moving until the longest episode has ended (as the reference's loop
                                        # keeps them in its model / MCTS batch, core/test.py:99-100): the lock-steps' own rate, incl. capture
                                        "lock_steps": evaluate.last_run.get("lock_steps"),
-                                       "batch_moves_per_s": evaluate.last_run.get("lock_steps", 0) * 1000 / dt}
+                                       "batch_moves_per_s": evaluate.last_run.get("lock_steps", 0) * 1000 / dt,
+                                       # ... and of the replayed lock-steps alone (random-init games last 8 moves: set-up and capture are most of `s`)
+                                       "setup_and_capture_s": evaluate.last_run.get("setup_and_capture_s"),
+                                       "replayed_batch_moves_per_s": evaluate.last_run.get("replayed_lock_steps", 0) * 1000 / max(1e-9, evaluate.last_run.get("replay_s", 0))}
     t0 = time.perf_counter()
     scores4, steps4 = run_test(cfg, engine, test_episodes=4096)
     dt = time.perf_counter() - t0
     out["evaluation_4096_episodes"] = {"s": dt, "moves": int(np.sum(steps4)), "moves_per_s": float(np.sum(steps4)) / dt,
                                        "mean_score": float(np.mean(scores4)), "lock_steps": evaluate.last_run.get("lock_steps"),
-                                       "batch_moves_per_s": evaluate.last_run.get("lock_steps", 0) * 4096 / dt}
+                                       "batch_moves_per_s": evaluate.last_run.get("lock_steps", 0) * 4096 / dt,
+                                       "setup_and_capture_s": evaluate.last_run.get("setup_and_capture_s"),
+                                       "replayed_batch_moves_per_s": evaluate.last_run.get("replayed_lock_steps", 0) * 4096 / max(1e-9, evaluate.last_run.get("replay_s", 0))}
     print(json.dumps(out, indent=1))
 
 
