@@ -180,6 +180,23 @@ def _t(a, device, dtype=torch.float32):
     return t.to(device=device, dtype=dtype)
 
 
+def _support_to_scalar(logits, support):
+    """inverse_value / inverse_reward_transform (core/config.py:210-232) of head logits [B, 2 s + 1] for the PRIORITIES (no
+    gradient): on the GPU the HIP kernel the search uses (include/hz_tree.h hz_support_to_scalar: one launch, any of the three
+    element formats) instead of ~15 elementwise launches per inference."""
+    logits = logits.detach()
+    if not logits.is_cuda or logits.dim() != 2 or logits.stride(1) != 1:
+        from .model import inverse_scalar_transform
+        return inverse_scalar_transform(logits.float(), support.min, support.max).reshape(-1)
+    import ctypes as C
+    from ._lib import check, lib
+    out = torch.empty(logits.shape[0], dtype=torch.float32, device=logits.device)
+    dt = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[logits.dtype]
+    check(lib.hz_support_to_scalar(logits.data_ptr(), logits.stride(0), support.size, support.min, dt, out.data_ptr(), logits.shape[0],
+                                   C.c_void_p(torch.cuda.current_stream().cuda_stream)), "hz_support_to_scalar")
+    return out
+
+
 def compute_losses(model, config, obs_batch, action_batch, target_reward, target_value, target_policy, weights,
                    amp=torch.bfloat16):
     """The forward part of update_weights (train.py:114-222).  Tensors on the model's device:
@@ -198,7 +215,7 @@ def compute_losses(model, config, obs_batch, action_batch, target_reward, target
 
     with cast():
         value, _, policy_logits, hidden_state = model.initial_inference(obs_batch.reshape(B, -1))
-    scaled_value = config.inverse_value_transform(value.float())
+    scaled_value = _support_to_scalar(value, vs)
     value_priority = (scaled_value.reshape(B) - target_value[:, 0]).abs().detach()
     value_loss = scalar_loss(value.float(), target_value_phi[:, 0])
     policy_loss = -(torch.log_softmax(policy_logits.float(), dim=1) * target_policy[:, 0]).sum(1)
@@ -212,7 +229,7 @@ def compute_losses(model, config, obs_batch, action_batch, target_reward, target
             reward_loss = reward_loss + scalar_loss(reward.float(), target_reward_phi[:, k])
             if hidden_state.requires_grad:
                 hidden_state.register_hook(lambda grad: grad * 0.5)  # train.py:169
-            scaled_reward = config.inverse_reward_transform(reward.detach().float())
+            scaled_reward = _support_to_scalar(reward, rs)
             reward_priority.append((scaled_reward.reshape(B) - target_reward[:, k]).abs())
     loss = config.policy_loss_coeff * policy_loss + config.value_loss_coeff * value_loss + config.reward_loss_coeff * reward_loss
     weighted_loss = (weights * loss).mean()

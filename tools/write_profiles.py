@@ -131,7 +131,7 @@ this stream, with the product's MFMAs and layer boundaries, reaches 54-55 B per 
 phases run at 47 (16 rows) / 44 (32 rows) -- tools/mlp_loop_bench.py -- and the tree phases (bound by instruction issue) stream nothing.  (2) The shader clock:
 under these kernels the chip runs at the clock in row 2, not at 2.4 GHz (the synthetic stream holds 2.39 GHz at 16 rows and 2.2 GHz at 32; random
 rather than constant weights alone cost it 11 %% of its rate at 32 rows): L1 and L2 are clocked with the shaders, so every GB/s figure of this
-kernel scales with it.  The MFMA pipes are busy 14 %% / 24 %% of the time: with 16 / 32 rows per weight fragment the matrix cores cannot be the bound.
+kernel scales with it.  The MFMA pipes are busy %.1f %% / %.1f %% of the time: with 16 / 32 rows per weight fragment the matrix cores cannot be the bound.
 """ % (tag, commit, note, A["cyc"] / 1e6, r("cyc", 0), B["cyc"] / 1e6, r("cyc", 1), clk[0], clk[1],
        A["req"], A["gb"], r("req", 0), B["req"], B["gb"], r("req", 1),
        A["req"] * 128 / 256 / A["cyc"], B["req"] * 128 / 256 / B["cyc"],
@@ -141,7 +141,7 @@ kernel scales with it.  The MFMA pipes are busy 14 %% / 24 %% of the time: with 
        A["hit"] * 100, r("hit", 0), B["hit"] * 100, r("hit", 1), A["nmfma"], r("nmfma", 0), B["nmfma"], r("nmfma", 1),
        A["mfma"] * 100, r("mfma", 0), B["mfma"] * 100, r("mfma", 1), A["wait"] * 100, r("wait", 0), B["wait"] * 100, r("wait", 1),
        A["lds"] * 100, r("lds", 0), B["lds"] * 100, r("lds", 1), tr["full4096"]["k_search"] / 1e9, r("hbm", 0),
-       tr["full8192"]["k_search"] / 1e9, r("hbm", 1))
+       tr["full8192"]["k_search"] / 1e9, r("hbm", 1), A["mfma"] * 100, B["mfma"] * 100)
     open(os.path.join(ROOT, "profiles", "%s_k_search_pmc.md" % tag), "w").write(md)
     print(md[:2600])
 
@@ -157,7 +157,10 @@ def main():
         subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"), f[0], wr[0], w], stdout=subprocess.DEVNULL)
     for w in ("full4096", "full8192"):
         stats(tag, w, commit, note)
-    pmc(tag, commit, note)
+    if os.path.exists(os.path.join(ROOT, "gpurun_out", "%s_pmc_summary_4096.txt" % tag)):
+        pmc(tag, commit, note)
+    else:
+        print("no counter summaries of tools/pmc_search.sh for %s under gpurun_out/: profiles/%s_k_search_pmc.md not written" % (tag, tag))
 
 
 if __name__ == "__main__":
