@@ -95,13 +95,17 @@ class DeviceReplay:
         """buf: uint8 tensor (device, or host: copied once) in the format of SelfPlayActor.drain_packed / dist.gather_packed --
         n games, `moves` moves in total.  Equals ReplayBuffer.ingest_packed (turn-reward reshape of DataWorker.put,
         selfplay_worker.py:32-37; new positions enter at the current maximum priority, replay_buffer.py:116-118).  No host
-        loop over games, no synchronisation."""
+        loop over games; a device buffer is read on the CALLING stream without synchronisation (a receive buffer that the next gather
+        reuses must not be rewritten before this stream has passed: tools/loop_bench.py orders the two with an event)."""
         n, moves = int(n), int(moves)
         if n == 0:
             return 0
         if not isinstance(buf, torch.Tensor):
             buf = torch.from_numpy(np.ascontiguousarray(buf))
-        buf = buf.to(self.device, non_blocking=True)
+        if buf.is_cuda:
+            buf.record_stream(torch.cuda.current_stream(self.device))  # (the caller may drop its reference before this stream has read it)
+        else:
+            buf = buf.to(self.device)  # (a host buffer -- e.g. dist.gather_packed's reused landing memory -- is copied before this returns)
         if self.head + moves > self.P or self.fhead + moves + n > self.F:
             self.remove_to_fit(room=moves)
             self._compact()

@@ -66,6 +66,9 @@ class _LinBNAct(torch.autograd.Function):
     def backward(ctx, dout):
         x, y, out, stats = ctx.saved_tensors
         blk, bn = ctx.blk, ctx.blk.bn
+        if bn.weight.grad is None or blk.lin.weight.grad is None:
+            raise RuntimeError("fused_train: the blocks accumulate into existing .grad tensors -- zero them with "
+                               "optimizer.zero_grad(set_to_none=False), do not drop them")
         if dout.stride(1) != 1:
             dout = dout.contiguous()
         B, Cn = y.shape

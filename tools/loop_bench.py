@@ -165,6 +165,8 @@ def main():
                 actor.step()
             packed = actor.drain_packed()   # (blocks for this rank's lock-steps; the learner's streams keep running)
         t1 = time.perf_counter()
+        if learns and one_round.ingested is not None:  # (the receive buffers are reused: the last round's ingest has to have read them)
+            torch.cuda.current_stream(device).wait_event(one_round.ingested)
         got = gather_packed(packed, A, W, dst=0, to_host=False)
         t2 = time.perf_counter()
         round_moves = torch.tensor([args.flush_every * args.envs if acts else 0], dtype=torch.int64, device=coll_dev)
@@ -178,6 +180,8 @@ def main():
                 for buf, n, mv in got:
                     replay.ingest_packed(buf, n, mv)
                     totals["games"] += n
+                one_round.ingested = torch.cuda.Event()
+                one_round.ingested.record(pipe.prep)
             t3 = time.perf_counter()
             if train:
                 one_round.owed += moves * args.ratio
@@ -202,6 +206,7 @@ def main():
         totals["moves"] += moves
         return steps
     one_round.owed = 0.0
+    one_round.ingested = None
 
     for _ in range(args.warm_rounds):
         one_round(train=False)
