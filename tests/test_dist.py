@@ -148,6 +148,53 @@ def test_gather_packed_world4_gloo():
     assert res == [(r, True) for r in range(4)]
 
 
+def _worker_subgroup(rank, world, port, q):
+    """r04 (advisor): `dst` / `src` are ranks OF THE GROUP; the point-to-point calls underneath want global ranks.  A subgroup
+    {1, 3} of four ranks gathers to its member 1 (= global rank 3) in the device form (to_host=False: torch buffers, as the
+    HBM-resident replay ingests them) and broadcasts weights from it."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hanabizero_amd.dist import broadcast_weights, gather_packed
+    from hanabizero_amd.selfplay import pack_records, unpack_packed, unpack_record
+    sub = dist.new_group([1, 3])
+    ok = True
+    if rank in (1, 3):
+        A, W = 11, 7
+        for rnd in range(2):
+            mine = _fake_rec(2 + rank + rnd, 40 + 10 * rnd + rank, T=5, A=A, W=W)
+            buf, n_, moves_ = pack_records(mine, A, W)
+            got = gather_packed((torch.from_numpy(buf), n_, moves_), A, W, dst=1, group=sub, to_host=False)
+            if rank == 3:
+                ok &= len(got) == 2 and all(isinstance(b, torch.Tensor) for b, _, _ in got)
+                for (b, n2, m2), r in zip(got, (1, 3)):   # (group-rank order: global ranks 1, 3)
+                    w = _fake_rec(2 + r + rnd, 40 + 10 * rnd + r, T=5, A=A, W=W)
+                    view = unpack_packed(b.numpy(), n2, m2, A, W)
+                    ok &= n2 == 2 + r + rnd
+                    for i in range(n2):
+                        a, c = unpack_record(view, i), unpack_record(w, i)
+                        ok &= all(np.array_equal(np.asarray(a[k]), np.asarray(c[k])) for k in a)
+            else:
+                ok &= got is None
+        out = broadcast_weights({"w": torch.full((4,), float(rank))}, src=1, group=sub)
+        ok &= bool((out["w"] == 3.0).all())
+    dist.barrier()
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_gather_packed_subgroup_ranks_and_device_form_gloo():
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_subgroup, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert res == [(r, True) for r in range(4)]
+
+
 @pytest.mark.gpu
 def test_collectives_over_rccl_one_rank():
     """The same three exchange steps through the "nccl" (= RCCL) backend with device tensors: one rank on the one GPU of
@@ -178,6 +225,15 @@ def test_collectives_over_rccl_one_rank():
             for k in a:
                 assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), (i, k)
         assert hd.gather_packed(None, A, W, dst=0) == []
+        # r04: the games stay on the device for a replay that lives there (tools/loop_bench.py: gather -> DeviceReplay.ingest_packed)
+        dev_buf = torch.from_numpy(buf).to(device)
+        out = hd.gather_packed((dev_buf, n_, moves_), A, W, dst=0, to_host=False)
+        assert len(out) == 1 and out[0][0].is_cuda and out[0][1:] == (n_, moves_) and torch.equal(out[0][0][:dev_buf.numel()], dev_buf)
+        assert hd.gather_packed(None, A, W, dst=0, to_host=False) == []
+        # ... and subgroup ranks are translated (group rank 0 of a one-member subgroup is global rank 0 here: the call shape is what is exercised)
+        sub = dist.new_group([0])
+        out = hd.gather_packed((dev_buf, n_, moves_), A, W, dst=0, group=sub, to_host=False)
+        assert len(out) == 1 and out[0][1:] == (n_, moves_)
         sd = {"w": torch.arange(6.0).reshape(2, 3), "b": torch.ones(3, dtype=torch.bfloat16)}
         bw = hd.broadcast_weights(sd, src=0)
         assert bw["w"].is_cuda and (bw["w"].cpu() == sd["w"]).all() and bw["b"].dtype == torch.bfloat16
