@@ -282,3 +282,145 @@ extern "C" int hz_bn_act_backward(const void* dout, int64_t dout_stride, const v
   HZ_HIP(hipGetLastError());
   return 0;
 }
+
+
+// ------------------------------------------------------------------------------------------------ the heads' losses of one inference
+// One wavefront per batch row: lane l owns logits l, l + 64, ... of each head.  Everything in fp32 (the reference casts the
+// logits to float before log_softmax: train.py:145-168 via .float()); the gradients leave in the logits' element format.
+template <int DT>
+__device__ __forceinline__ float hl_load(const void* base, long long i) {
+  if (DT == HZ_F32) return reinterpret_cast<const float*>(base)[i];
+  return tr_load<(DT == HZ_F32 ? HZ_BF16 : DT)>(reinterpret_cast<const uint16_t*>(base) + i);
+}
+template <int DT>
+__device__ __forceinline__ void hl_store(void* base, long long i, float v) {
+  if (DT == HZ_F32) reinterpret_cast<float*>(base)[i] = v;
+  else reinterpret_cast<uint16_t*>(base)[i] = tr_round<(DT == HZ_F32 ? HZ_BF16 : DT)>(v);
+}
+__device__ __forceinline__ float hl_wave_sum(float v) {
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m);
+  return v;
+}
+__device__ __forceinline__ float hl_wave_max(float v) {
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) v = fmaxf(v, __shfl_xor(v, m));
+  return v;
+}
+
+// log-softmax statistics of one row of n logits: returns (max, log of the sum of exp(x - max)); e[] keeps the lane's exponentials
+template <int DT, int MAXPER>
+__device__ __forceinline__ void hl_row_stats(const void* row, int n, int lane, float (&x)[MAXPER], float& mx, float& lse) {
+  mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < MAXPER; ++i) {
+    const int j = lane + 64 * i;
+    x[i] = j < n ? hl_load<DT>(row, j) : -INFINITY;
+    mx = fmaxf(mx, x[i]);
+  }
+  mx = hl_wave_max(mx);
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < MAXPER; ++i)
+    if (lane + 64 * i < n) s += expf(x[i] - mx);
+  lse = logf(hl_wave_sum(s));
+}
+
+// a categorical head against the two-hot of a scalar target: (loss, predicted scalar); writes the gradient row scaled by `fac`
+template <int DT>
+__device__ __forceinline__ void hl_support_head(const void* logits, void* grad, int V, int smin, float target, float fac, int lane,
+                                                float& loss, float& pred) {
+  float x[4], mx, lse;
+  hl_row_stats<DT, 4>(logits, V, lane, x, mx, lse);
+  // phi(h(target)): core/config.py:192-202, 240-253 (delta = 1)
+  float h = (target < 0.0f ? -1.0f : 1.0f) * (sqrtf(fabsf(target) + 1.0f) - 1.0f) + 0.001f * target;
+  h = fminf(fmaxf(h, (float)smin), (float)(smin + V - 1));
+  const float lo_f = floorf(h), hi_f = ceilf(h);
+  const float p_hi = h - lo_f;
+  const int lo = (int)lo_f - smin, hi = (int)hi_f - smin;
+  float l = 0.0f, ev = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int j = lane + 64 * i;
+    if (j < V) {
+      const float logp = x[i] - mx - lse;
+      const float p = expf(logp);
+      float t = 0.0f;
+      if (j == hi) t = p_hi;
+      if (j == lo) t = 1.0f - p_hi;   // (lo == hi: the second scatter of the reference overwrites the first)
+      l -= logp * t;
+      ev += p * (float)(smin + j);
+      if (grad != nullptr) hl_store<DT>(grad, j, fac * (p - t));
+    }
+  }
+  loss = hl_wave_sum(l);
+  const float v = hl_wave_sum(ev);    // inverse_scalar_transform: core/config.py:210-232
+  const float a = fabsf(v);
+  const float r = (sqrtf(1.0f + 4.0f * 0.001f * (a + 1.0f + 0.001f)) - 1.0f) / (2.0f * 0.001f);
+  float out = (v < 0.0f ? -1.0f : 1.0f) * (r * r - 1.0f);
+  pred = out != out ? 0.0f : out;
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void k_head_losses(const void* __restrict__ vlog, long long vs, const void* __restrict__ rlog, long long rs,
+                                                     const void* __restrict__ plog, long long ps, int rows, int V, int smin, int A,
+                                                     const float* __restrict__ tv, long long tvs, const float* __restrict__ trw, long long trs,
+                                                     const float* __restrict__ tp, long long tps, const float* __restrict__ weights,
+                                                     float vc, float rc, float pc, void* dv, void* dr, void* dp,
+                                                     float* __restrict__ losses, float* __restrict__ preds) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  constexpr long long ES = DT == HZ_F32 ? 4 : 2;
+  const float wfac = weights[row] / (float)rows;
+  auto at = [&](const void* b, long long stride) { return reinterpret_cast<const char*>(b) + (long long)row * stride * ES; };
+  auto atw = [&](void* b, long long stride) { return b ? reinterpret_cast<char*>(b) + (long long)row * stride * ES : nullptr; };
+  float vl, vpred, rl = 0.0f, rpred = 0.0f;
+  hl_support_head<DT>(at(vlog, vs), atw(dv, V), V, smin, tv[(long long)row * tvs], wfac * vc, lane, vl, vpred);
+  if (rlog != nullptr) hl_support_head<DT>(at(rlog, rs), atw(dr, V), V, smin, trw[(long long)row * trs], wfac * rc, lane, rl, rpred);
+  // policy: -(log_softmax . target); gradient softmax * sum(target) - target
+  float x[1], mx, lse;
+  hl_row_stats<DT, 1>(at(plog, ps), A, lane, x, mx, lse);
+  const float t = lane < A ? tp[(long long)row * tps + lane] : 0.0f;
+  const float tsum = hl_wave_sum(t);
+  float pl = 0.0f;
+  if (lane < A) {
+    const float logp = x[0] - mx - lse;
+    pl = -logp * t;
+    if (dp != nullptr) hl_store<DT>(atw(dp, A), lane, wfac * pc * (expf(logp) * tsum - t));
+  }
+  pl = hl_wave_sum(pl);
+  if (lane == 0) {
+    float* o = losses + 4ll * row;
+    o[0] = pl; o[1] = vl; o[2] = rl; o[3] = wfac * (pc * pl + vc * vl + rc * rl);
+    preds[2ll * row] = vpred;
+    preds[2ll * row + 1] = rpred;
+  }
+}
+
+extern "C" int hz_muzero_head_losses(const void* value_logits, int64_t value_stride, const void* reward_logits, int64_t reward_stride,
+                                     const void* policy_logits, int64_t policy_stride, int rows, int support_size, int support_min, int num_actions,
+                                     int dtype, const float* target_value, int64_t target_value_stride, const float* target_reward,
+                                     int64_t target_reward_stride, const float* target_policy, int64_t target_policy_stride, const float* weights,
+                                     float value_coeff, float reward_coeff, float policy_coeff, void* d_value, void* d_reward, void* d_policy,
+                                     float* losses, float* preds, void* stream) {
+  HZ_REQUIRE(value_logits && policy_logits && target_value && target_policy && weights && losses && preds, "hz_muzero_head_losses: null pointer");
+  HZ_REQUIRE(!reward_logits || target_reward, "hz_muzero_head_losses: reward logits without reward targets");
+  HZ_REQUIRE(rows >= 1 && support_size >= 1 && support_size <= 256 && num_actions >= 1 && num_actions <= 64,
+             "hz_muzero_head_losses: rows=%d support_size=%d (<= 256) num_actions=%d (<= 64)", rows, support_size, num_actions);
+  HZ_REQUIRE(value_stride >= support_size && (!reward_logits || reward_stride >= support_size) && policy_stride >= num_actions,
+             "hz_muzero_head_losses: a logits row stride below its width");
+  HZ_REQUIRE(dtype == HZ_F32 || dtype == HZ_BF16 || dtype == HZ_F16, "hz_muzero_head_losses: dtype %d", dtype);
+  const dim3 grid((rows + 3) / 4);
+#define HZ_HL(DT)                                                                                                                      \
+  hipLaunchKernelGGL(k_head_losses<DT>, grid, dim3(256), 0, (hipStream_t)stream, value_logits, (long long)value_stride, reward_logits,  \
+                     (long long)reward_stride, policy_logits, (long long)policy_stride, rows, support_size, support_min, num_actions,  \
+                     target_value, (long long)target_value_stride, target_reward, (long long)target_reward_stride, target_policy,      \
+                     (long long)target_policy_stride, weights, value_coeff, reward_coeff, policy_coeff, d_value, d_reward, d_policy,   \
+                     losses, preds)
+  if (dtype == HZ_F32) HZ_HL(HZ_F32);
+  else if (dtype == HZ_BF16) HZ_HL(HZ_BF16);
+  else HZ_HL(HZ_F16);
+#undef HZ_HL
+  HZ_HIP(hipGetLastError());
+  return 0;
+}

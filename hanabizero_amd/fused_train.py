@@ -103,6 +103,43 @@ class _Lin(torch.autograd.Function):
         return torch.mm(dy, blk.w16), None
 
 
+class _HeadLosses(torch.autograd.Function):
+    """The losses of one inference (value / reward cross-entropies against the two-hot targets, policy cross-entropy against the
+    visit distribution, the weighted total per row) and their gradients with respect to the three heads' logits in ONE launch
+    (include/hz_train.h hz_muzero_head_losses) instead of ~20 forward and ~20 backward elementwise / softmax / reduce launches.
+    Returns (row_total [B] -- differentiable --, losses [B, 4] = policy / value / reward / total, preds [B, 2] = the heads' scalars)."""
+
+    @staticmethod
+    def forward(ctx, value, reward, policy, tv, tr, tp, weights, support, coeffs):
+        B, V = value.shape
+        A = policy.shape[1]
+        d = value.device
+        dt = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[value.dtype]
+        assert policy.dtype == value.dtype and (reward is None or reward.dtype == value.dtype)
+        assert value.stride(1) == 1 and policy.stride(1) == 1 and tp.stride(1) == 1 and weights.is_contiguous()
+        dv, dp = torch.empty((B, V), dtype=value.dtype, device=d), torch.empty((B, A), dtype=value.dtype, device=d)
+        dr = torch.empty((B, V), dtype=value.dtype, device=d) if reward is not None else None
+        losses = torch.empty((B, 4), dtype=torch.float32, device=d)
+        preds = torch.empty((B, 2), dtype=torch.float32, device=d)
+        vc, rc, pc = coeffs
+        check(lib.hz_muzero_head_losses(value.data_ptr(), value.stride(0), None if reward is None else reward.data_ptr(),
+                                        0 if reward is None else reward.stride(0), policy.data_ptr(), policy.stride(0), B, V, support.min, A, dt,
+                                        tv.data_ptr(), tv.stride(0), None if tr is None else tr.data_ptr(), 0 if tr is None else tr.stride(0),
+                                        tp.data_ptr(), tp.stride(0), weights.data_ptr(), float(vc), float(rc), float(pc), dv.data_ptr(),
+                                        None if dr is None else dr.data_ptr(), dp.data_ptr(), losses.data_ptr(), preds.data_ptr(), _stream()),
+              "hz_muzero_head_losses")
+        ctx.has_reward = reward is not None
+        ctx.save_for_backward(dv, dr if dr is not None else dv.new_empty(0), dp)
+        ctx.mark_non_differentiable(losses, preds)
+        return losses[:, 3], losses, preds
+
+    @staticmethod
+    def backward(ctx, g, _gl, _gp):
+        dv, dr, dp = ctx.saved_tensors
+        g = g.to(dv.dtype).unsqueeze(1)
+        return dv * g, (dr * g if ctx.has_reward else None), dp * g, None, None, None, None, None, None
+
+
 class FusedTrainNet:
     """The training-mode forward of `net` (MuZeroNet / MuZeroNetFull on a GPU) through the fused blocks.  Quacks like the module
     where the learner touches it: initial_inference / recurrent_inference (training branch of core/model.py:61-84: logits and the
@@ -178,6 +215,34 @@ class FusedTrainNet:
         """The 16-bit copies of the Linear parameters from the fp32 ones (once per optimiser step; one multi-tensor launch)."""
         with torch.no_grad():
             torch._foreach_copy_(self._w16, self._w32)
+
+    fused_heads = True  # learner.compute_losses hands the whole unrolled forward + losses to compute_losses() below
+
+    def compute_losses(self, config, obs_batch, action_batch, target_reward, target_value, target_policy, weights):
+        """learner.compute_losses (core/train.py:114-222) with every inference's losses, priorities' ingredients and logit
+        gradients in one launch (_HeadLosses).  Same returns."""
+        U = config.num_unroll_steps
+        B = obs_batch.shape[0]
+        vs, rs = config.value_support, config.reward_support
+        assert (vs.min, vs.size) == (rs.min, rs.size)
+        coeffs = (config.value_loss_coeff, config.reward_loss_coeff, config.policy_loss_coeff)
+        value, _, policy_logits, hidden_state = self.initial_inference(obs_batch.reshape(B, -1))
+        tot, L, P = _HeadLosses.apply(value, None, policy_logits, target_value[:, 0], None, target_policy[:, 0], weights, vs, coeffs)
+        value_priority = (P[:, 0] - target_value[:, 0]).abs()
+        totals, Ls, reward_priority = [tot], [L], []
+        for k in range(U):
+            value, reward, policy_logits, hidden_state = self.recurrent_inference(hidden_state, action_batch[:, k:k + 1])
+            tot, L, P = _HeadLosses.apply(value, reward, policy_logits, target_value[:, k + 1], target_reward[:, k], target_policy[:, k + 1],
+                                          weights, vs, coeffs)
+            hidden_state.register_hook(lambda grad: grad * 0.5)  # train.py:169
+            totals.append(tot)
+            Ls.append(L)
+            reward_priority.append((P[:, 1] - target_reward[:, k]).abs())
+        weighted_loss = torch.stack(totals).sum()
+        Ls = torch.stack(Ls).sum(0)
+        vc, rc, pc = coeffs
+        return weighted_loss, dict(loss=pc * Ls[:, 0] + vc * Ls[:, 1] + rc * Ls[:, 2], policy_loss=Ls[:, 0], value_loss=Ls[:, 1],
+                                   reward_loss=Ls[:, 2], value_priority=value_priority, reward_priority=torch.stack(reward_priority).mean(0))
 
     def count_batches(self):
         """num_batches_tracked of every BatchNorm as the module's own forward would have left it after one learner step."""

@@ -203,6 +203,8 @@ def compute_losses(model, config, obs_batch, action_batch, target_reward, target
     obs_batch [B, stack * D] (the first stacked window of the batch), action_batch [B, U] long, target_reward [B, U],
     target_value / target_policy [B, U + 1] / [B, U + 1, A], weights [B].
     Returns (weighted_loss, dict of per-sample losses and priorities' ingredients)."""
+    if getattr(model, "fused_heads", False) and obs_batch.is_cuda and amp is not None:
+        return model.compute_losses(config, obs_batch, action_batch, target_reward, target_value, target_policy, weights)
     U = config.num_unroll_steps
     B = obs_batch.shape[0]
     dev = obs_batch.device

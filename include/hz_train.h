@@ -39,6 +39,26 @@ int hz_bn_act_backward(const void* dout, int64_t dout_stride, const void* out, i
                        void* dx, int64_t dx_stride, void* dres, int64_t dres_stride, int rows, int cols, const float* gamma,
                        const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, int relu, int dtype, void* stream);
 
+/* The losses of ONE inference of the unrolled learner step (initial or recurrent; core/train.py:145-168, 196-216 with
+ * config/hanabi_control/__init__.py:119-123 and core/config.py:192-253) in one launch, gradients included:
+ *   value / reward   cross-entropy of the categorical head (logits [rows][support_size], 16-bit or fp32) against the two-hot
+ *                    phi(h(target)) of the scalar target: h(x) = sign(x) (sqrt(|x| + 1) - 1) + 0.001 x, clamped to the support,
+ *                    mass x - floor(x) on ceil(x) and the rest on floor(x) (an integer puts everything on itself);
+ *   policy           cross-entropy of the policy logits [rows][num_actions] against the visit distribution (rows past the end of a
+ *                    game are all zero: no loss, no gradient);
+ *   predictions      the heads' scalars softmax . support -> h^-1 (what the priorities compare with the targets).
+ * Outputs per row: losses[row] = {policy, value, reward, weight[row] / rows * (pc policy + vc value + rc reward)} (written, not
+ * accumulated), preds[row] = {value scalar, reward scalar}; gradients of the LAST of these (the weighted total) with respect to the
+ * logits, in the logits' element format: d_value, d_reward, d_policy (softmax * sum(target) - target, scaled by the row's factor).
+ * reward_logits == NULL: the initial inference (no reward head: reward loss 0).  Strides in elements.  One wavefront per row. */
+int hz_muzero_head_losses(const void* value_logits, int64_t value_stride, const void* reward_logits, int64_t reward_stride,
+                          const void* policy_logits, int64_t policy_stride, int rows, int support_size, int support_min, int num_actions,
+                          int dtype /* HZ_F32 | HZ_BF16 | HZ_F16 */, const float* target_value, int64_t target_value_stride,
+                          const float* target_reward, int64_t target_reward_stride, const float* target_policy,
+                          int64_t target_policy_stride, const float* weights, float value_coeff, float reward_coeff, float policy_coeff,
+                          void* d_value, void* d_reward, void* d_policy, float* losses /* [rows][4] */, float* preds /* [rows][2] */,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -548,3 +548,52 @@ def test_fused_learner_step_matches_the_autocast_step(game, stack):
         # the fused model's 16-bit weight copies follow the step
         for blk in fused._blocks:
             assert torch.equal(blk.w16, blk.lin.weight.detach().to(torch.bfloat16))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("V,smin,A,with_reward", [(201, -100, 48, True), (51, -25, 11, True), (201, -100, 20, False)])
+def test_head_losses_kernel_against_fp32_reference(dtype, V, smin, A, with_reward):
+    """hz_muzero_head_losses against the plain PyTorch fp32 restatement of one inference's losses (scalar_transform -> phi two-hot ->
+    -(log_softmax . target), the policy cross-entropy, the weighted total) and autograd's gradients with respect to the logits; the
+    heads' scalar predictions against inverse_scalar_transform."""
+    from hanabizero_amd.fused_train import _HeadLosses
+    from hanabizero_amd.learner import phi, scalar_transform
+    from hanabizero_amd.model import inverse_scalar_transform
+    import types
+    B = 133
+    g = torch.Generator(device="cuda").manual_seed(V + A)
+    mk = lambda *s: (torch.randn(*s, device="cuda", generator=g) * 2).to(dtype)
+    value, reward, policy = mk(B, V), (mk(B, V) if with_reward else None), mk(B, A)
+    tv = torch.rand(B, 3, device="cuda", generator=g) * 60 - 20     # (strided rows: column 1 is the target)
+    tv[0, 1], tv[1, 1], tv[2, 1] = 3.0, 0.0, -1e6                    # an integer after the transform? (0 is), clamped far below the support
+    tr = (torch.randint(-3, 4, (B, 2), device="cuda", generator=g)).float()
+    tp = torch.rand(B, 2, A, device="cuda", generator=g)
+    tp = tp / tp.sum(-1, keepdim=True)
+    tp[5:9, 1] = 0.0                                                  # positions past the end of their game: no policy target
+    weights = torch.rand(B, device="cuda", generator=g) + 0.5
+    support = types.SimpleNamespace(min=smin, max=smin + V - 1, size=V)
+    coeffs = (0.25, 1.0, 1.0)
+    v_in, p_in = value.clone().requires_grad_(True), policy.clone().requires_grad_(True)
+    r_in = reward.clone().requires_grad_(True) if with_reward else None
+    tot, L, P = _HeadLosses.apply(v_in, r_in, p_in, tv[:, 1], tr[:, 0] if with_reward else None, tp[:, 1], weights, support, coeffs)
+    tot.sum().backward()
+    # fp32 reference
+    vr, pr = value.float().requires_grad_(True), policy.float().requires_grad_(True)
+    rr = reward.float().requires_grad_(True) if with_reward else None
+    ce = lambda logits, target: -(torch.log_softmax(logits, 1) * target).sum(1)
+    vphi = phi(scalar_transform(tv[:, 1:2].clone()), smin, smin + V - 1, V)[:, 0]
+    vl = ce(vr, vphi)
+    pl = ce(pr, tp[:, 1])
+    rl = ce(rr, phi(scalar_transform(tr[:, 0:1].clone()), smin, smin + V - 1, V)[:, 0]) if with_reward else torch.zeros(B, device="cuda")
+    want = weights / B * (coeffs[2] * pl + coeffs[0] * vl + coeffs[1] * rl)
+    want.sum().backward()
+    tol = dict(rtol=2e-5, atol=2e-5) if dtype == torch.float32 else dict(rtol=1e-4, atol=1e-4)
+    assert torch.allclose(L[:, 0], pl, **tol) and torch.allclose(L[:, 1], vl, **tol) and torch.allclose(L[:, 2], rl, **tol)
+    assert torch.allclose(tot, want, **tol) and torch.equal(tot, L[:, 3])
+    ulp = {torch.float32: 1e-6, torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}[dtype]
+    for got, ref in ((v_in.grad, vr.grad), (p_in.grad, pr.grad)) + (((r_in.grad, rr.grad),) if with_reward else ()):
+        assert got.dtype == dtype and torch.allclose(got.float(), ref, rtol=4 * ulp, atol=4 * ulp * float(ref.abs().max()))
+    assert torch.allclose(P[:, 0], inverse_scalar_transform(value.float(), smin, smin + V - 1).reshape(-1), rtol=1e-4, atol=1e-4)
+    if with_reward:
+        assert torch.allclose(P[:, 1], inverse_scalar_transform(reward.float(), smin, smin + V - 1).reshape(-1), rtol=1e-4, atol=1e-4)
