@@ -824,11 +824,28 @@ def main():
             also[name] = entry
             r.release()
             del r
+        # BASELINE configs[4] (Hanabi-Full 5p: self-play + reanalyze + learner batch 256) as its own process on this GPU, after
+        # everything above has let go of it: tools/loop_bench.py's JSON line, trimmed (failures are reported, not raised)
+        if args.workload == "full4096" and args.net == "random":
+            try:
+                torch.cuda.empty_cache()
+                p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "loop_bench.py"), "--rounds", "3"], stdout=subprocess.PIPE,
+                                   stderr=subprocess.PIPE, text=True, timeout=300)
+                line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+                if p.returncode == 0 and line:
+                    d = json.loads(line[-1])
+                    also["config5_loop"] = {k: d[k] for k in ("workload", "learner_steps_per_s", "selfplay_moves_per_s", "replay_ratio_target", "replay_ratio_achieved",
+                                                              "learner_steps", "wall_s", "weight_handover_ms", "host_ms_per_learner_step_enqueue",
+                                                              "host_wait_for_the_gpu_ms_per_learner_step", "replay_positions", "learner_blocks", "reference")}
+                else:
+                    also["config5_loop"] = {"error": (p.stderr or p.stdout)[-400:]}
+            except Exception as e:  # noqa: BLE001
+                also["config5_loop"] = {"error": repr(e)[:400]}
         out["also"] = also
         # the other 16-bit format's figure for the SAME workload, at the top level beside `value` (BASELINE's configs name bf16, the
         # reference's own search runs in fp16: both are measured in every default run)
         for name, entry in also.items():
-            if entry["workload"] == args.workload and entry["net"] == args.net and entry["dtype"] != args.dtype:
+            if entry.get("workload") == args.workload and entry.get("net") == args.net and entry.get("dtype") not in (None, args.dtype):
                 out["value_" + entry["dtype"]] = entry["value"]
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:  # (rank 0 at N = 1 only)
