@@ -36,17 +36,6 @@ class RowsJob(C.Structure):  # include/hz_rows.h hz_rows_job_t
                 ("max_rows", C.c_int32), ("src", C.c_void_p * 8), ("dst", C.c_void_p * 8), ("row_bytes", C.c_int64 * 8)]
 
 
-class GemmBn(C.Structure):  # include/hz_train.h hz_gemm_bn_t
-    _fields_ = [("gamma", C.c_void_p), ("beta", C.c_void_p), ("running_mean", C.c_void_p), ("running_var", C.c_void_p),
-                ("save_mean", C.c_void_p), ("save_invstd", C.c_void_p), ("momentum", C.c_float), ("eps", C.c_float),
-                ("res", C.c_void_p), ("res_stride", C.c_int64), ("y", C.c_void_p), ("y_stride", C.c_int64),
-                ("out_t", C.c_void_p), ("out_t_stride", C.c_int64), ("relu", C.c_int32)]
-
-
-class CastJob(C.Structure):  # include/hz_train.h hz_cast_job_t
-    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("dst_t", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32), ("dst_stride", C.c_int64)]
-
-
 class ActorBufs(C.Structure):  # include/hz_selfplay.h hz_actor_bufs_t
     _fields_ = [(n, C.c_int32) for n in ("num_envs", "num_actions", "packed_words", "max_moves", "outbox_games",
                                          "env_id_base")] + \
@@ -124,9 +113,7 @@ def _load():
         "hz_replay_windows": [V, I, V, V, I, I, I, V, I64, I64, I, V],
         # include/hz_train.h
         "hz_bn_act_forward": [V, I64, V, I64, V, I64, I, I, V, V, V, V, F, F, V, V, I, I, V],
-        "hz_bn_act_backward": [V, I64, V, I64, V, I64, V, I64, V, I64, V, I64, I, I, V, V, V, V, V, I, I, V],
-        "hz_gemm_nt": [V, I64, V, I64, V, I, I, I, V, I64, I, C.POINTER(GemmBn), I, V],
-        "hz_cast_transpose_many": [V, I, I, I, V],
+        "hz_bn_act_backward": [V, I64, V, I64, V, I64, V, I64, V, I64, I, I, V, V, V, V, V, I, I, V],
         "hz_muzero_head_losses": [V, I64, V, I64, V, I64, I, I, I, I, I, V, I64, V, I64, V, I64, V, F, F, F, V, V, V, V, V, V],
         # include/hz_netglue.h
         "hz_add_relu": [V, I64, V, I64, I, I, I, V],

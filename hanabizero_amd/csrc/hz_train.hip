@@ -1,6 +1,7 @@
 // hz_train.hip -- BatchNorm1d (training) + residual + ReLU behind the learner's GEMMs, forward and backward (include/hz_train.h).
 // Latency-bound work: a learner batch is 256 rows, a layer 256..1024 columns.  One workgroup per 32 columns; column sums meet in LDS.
-#include "hz_mlp_dev.h"  // ElBf16 / ElF16: the element formats and their MFMA
+#include "hz_common.h"
+#include "hz_tree.h"
 #include "hz_train.h"
 
 template <int DT>
@@ -162,8 +163,7 @@ template <int DT>
 __global__ __launch_bounds__(256) void k_bn_act_backward(const uint16_t* __restrict__ dout, long long ds, const uint16_t* __restrict__ out,
                                                          long long os, const uint16_t* __restrict__ x, long long xs,
                                                          uint16_t* __restrict__ dx, long long dxs, uint16_t* __restrict__ dres,
-                                                         long long drs, uint16_t* __restrict__ dxt, long long dxts, int rows, int cols,
-                                                         const float* __restrict__ gamma,
+                                                         long long drs, int rows, int cols, const float* __restrict__ gamma,
                                                          const float* __restrict__ smean, const float* __restrict__ sinv,
                                                          float* __restrict__ dgamma, float* __restrict__ dbeta, int relu, int vec) {
   __shared__ float4 s_r[4][4];
@@ -224,10 +224,6 @@ __global__ __launch_bounds__(256) void k_bn_act_backward(const uint16_t* __restr
       tr_store2<DT>(dres + (long long)r * drs + c, dz.x, dz.y, both);
       if (!both && on1) dres[(long long)r * drs + c + 1] = tr_round<DT>(dz.y);
     }
-    if (dxt != nullptr) {
-      dxt[(long long)c * dxts + r] = tr_round<DT>(a);
-      if (on1) dxt[(long long)(c + 1) * dxts + r] = tr_round<DT>(b);
-    }
   };
 #pragma unroll
   for (int i = 0; i < TR_HOLD; ++i)
@@ -264,12 +260,12 @@ extern "C" int hz_bn_act_forward(const void* x, int64_t x_stride, const void* re
 }
 
 extern "C" int hz_bn_act_backward(const void* dout, int64_t dout_stride, const void* out, int64_t out_stride, const void* x, int64_t x_stride,
-                                  void* dx, int64_t dx_stride, void* dres, int64_t dres_stride, void* dx_t, int64_t dx_t_stride, int rows, int cols,
-                                  const float* gamma, const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, int relu,
-                                  int dtype, void* stream) {
+                                  void* dx, int64_t dx_stride, void* dres, int64_t dres_stride, int rows, int cols, const float* gamma,
+                                  const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, int relu, int dtype,
+                                  void* stream) {
   HZ_REQUIRE(dout && x && dx && gamma && save_mean && save_invstd && dgamma && dbeta && (out || !relu), "hz_bn_act_backward: null pointer");
   HZ_REQUIRE(rows >= 1 && cols >= 1 && dout_stride >= cols && x_stride >= cols && dx_stride >= cols && (!relu || out_stride >= cols) &&
-                 (!dres || dres_stride >= cols) && (!dx_t || dx_t_stride >= rows),
+                 (!dres || dres_stride >= cols),
              "hz_bn_act_backward: rows=%d cols=%d and a row stride below cols", rows, cols);
   HZ_REQUIRE(dtype == HZ_BF16 || dtype == HZ_F16, "hz_bn_act_backward: dtype %d (HZ_BF16 or HZ_F16)", dtype);
   const dim3 grid((cols + TR_COLS - 1) / TR_COLS);
@@ -278,370 +274,15 @@ extern "C" int hz_bn_act_backward(const void* dout, int64_t dout_stride, const v
   if (dtype == HZ_BF16)
     hipLaunchKernelGGL(k_bn_act_backward<HZ_BF16>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dout, (long long)dout_stride,
                        (const uint16_t*)out, (long long)out_stride, (const uint16_t*)x, (long long)x_stride, (uint16_t*)dx, (long long)dx_stride,
-                       (uint16_t*)dres, (long long)dres_stride, (uint16_t*)dx_t, (long long)dx_t_stride, rows, cols, gamma, save_mean, save_invstd, dgamma, dbeta, relu, vec);
+                       (uint16_t*)dres, (long long)dres_stride, rows, cols, gamma, save_mean, save_invstd, dgamma, dbeta, relu, vec);
   else
     hipLaunchKernelGGL(k_bn_act_backward<HZ_F16>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dout, (long long)dout_stride,
                        (const uint16_t*)out, (long long)out_stride, (const uint16_t*)x, (long long)x_stride, (uint16_t*)dx, (long long)dx_stride,
-                       (uint16_t*)dres, (long long)dres_stride, (uint16_t*)dx_t, (long long)dx_t_stride, rows, cols, gamma, save_mean, save_invstd, dgamma, dbeta, relu, vec);
+                       (uint16_t*)dres, (long long)dres_stride, rows, cols, gamma, save_mean, save_invstd, dgamma, dbeta, relu, vec);
   HZ_HIP(hipGetLastError());
   return 0;
 }
 
-
-// ------------------------------------------------------------------------------------------------ the learner's GEMMs (NT form)
-// A workgroup owns 32 output columns x (32 RG) rows; its RG x KS wavefronts are RG row groups x KS slices of the reduction, each
-// computing a 32 x 32 tile (2 x 2 tiles of v_mfma_f32_16x16x32) over its slice.  Fragments come straight from memory -- both
-// operands are contiguous along the reduction: 16 B per lane -- through a ring of ST k-steps in registers; a slice is at most 2 ST
-// steps, so a wavefront has (nearly) all its requests in flight at once and the launch costs about one memory round trip instead
-// of one per k-step (a first version with 4 waves walking the whole K: 15 us at K = 512 where the library needs 5 hot, 12 cold).
-// The weight rows' fragments are the MFMA's first operand, so a lane ends up with FOUR CONSECUTIVE OUTPUT COLUMNS of one row per
-// tile: out[32 rg + 16 rt + (l & 15)][16 ct + 4 (l >> 4) + i].  Partial sums of the slices meet in LDS; slice 0's waves run the epilogue.
-template <class EL>
-__device__ __forceinline__ typename EL::v8 gm_load(const uint16_t* p) {
-  return *reinterpret_cast<const typename EL::v8*>(p);
-}
-template <class EL>
-__device__ __forceinline__ float gm_requant(float v) {
-  return EL::lo(EL::pack(v, 0.0f));
-}
-
-template <class EL, int EPI, int RG, int KS>
-__global__ __launch_bounds__(64 * RG * KS) void k_gemm_nt(const uint16_t* __restrict__ x, long long xs, const uint16_t* __restrict__ w,
-                                                          long long ws, const uint16_t* __restrict__ bias, int rows, int cols, int K,
-                                                          void* __restrict__ outv, long long os, hz_gemm_bn_t bn) {
-  typedef typename EL::v8 v8;
-  __shared__ float s_part[(KS - 1) * RG][16][64];
-  __shared__ float s_red[2][RG][32];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int rg = wave % RG, ks = wave / RG;
-  const int c0 = blockIdx.x * 32, rb = blockIdx.y * (32 * RG) + 32 * rg;
-  const int r16 = lane & 15, q = lane >> 4;
-  // this wave's slice of the reduction: whole k-steps, the first slices one step longer when they do not divide
-  const int steps = K >> 5, per = (steps + KS - 1) / KS;
-  const int kb = min(ks * per, steps) * 32, ke = min((ks + 1) * per, steps) * 32;
-  const uint16_t* wp[2];
-  const uint16_t* xp[2];
-#pragma unroll
-  for (int ct = 0; ct < 2; ++ct) wp[ct] = w + (long long)min(c0 + 16 * ct + r16, cols - 1) * ws + 8 * q;
-#pragma unroll
-  for (int rt = 0; rt < 2; ++rt) xp[rt] = x + (long long)min(rb + 16 * rt + r16, rows - 1) * xs + 8 * q;
-  f32x4 acc[2][2];
-#pragma unroll
-  for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt) acc[ct][rt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-  if (kb < ke) {
-    constexpr int ST = 4;
-    v8 wr[ST][2], xr[ST][2];
-    const int klast = ke - 32;
-#pragma unroll
-    for (int s = 0; s < ST - 1; ++s) {
-      const int kk = min(kb + 32 * s, klast);
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct) wr[s][ct] = gm_load<EL>(wp[ct] + kk);
-#pragma unroll
-      for (int rt = 0; rt < 2; ++rt) xr[s][rt] = gm_load<EL>(xp[rt] + kk);
-    }
-    for (int k0 = kb; k0 < ke; k0 += 32 * ST) {
-#pragma unroll
-      for (int s = 0; s < ST; ++s) {
-        const int kk = k0 + 32 * s;
-        const int kn = min(kk + 32 * (ST - 1), klast);   // (steps past the end request the last step's fragments again: L1 hits)
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) wr[(s + ST - 1) % ST][ct] = gm_load<EL>(wp[ct] + kn);
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt) xr[(s + ST - 1) % ST][rt] = gm_load<EL>(xp[rt] + kn);
-        if (kk < ke) {
-#pragma unroll
-          for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt) acc[ct][rt] = EL::mfma(wr[s][ct], xr[s][rt], acc[ct][rt]);
-        }
-      }
-    }
-  }
-  // the slices' partial sums -> slice 0
-  if (KS > 1) {
-    if (ks > 0) {
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) s_part[(ks - 1) * RG + rg][8 * ct + 4 * rt + i][lane] = acc[ct][rt][i];
-    }
-    __syncthreads();
-    if (ks == 0) {
-#pragma unroll
-      for (int p = 0; p < KS - 1; ++p)
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-          for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[ct][rt][i] += s_part[p * RG + rg][8 * ct + 4 * rt + i][lane];
-    }
-  }
-  const bool lead = ks == 0;   // the waves that hold the sums and run the epilogue (the others only keep the barriers company)
-  // ---- epilogues: lane owns columns col(ct) .. col(ct) + 3 of rows row(rt)
-  auto colof = [&](int ct) { return c0 + 16 * ct + 4 * q; };
-  auto rowof = [&](int rt) { return rb + 16 * rt + r16; };
-  float bv[2][4];
-#pragma unroll
-  for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = colof(ct) + i;
-      bv[ct][i] = (bias != nullptr && c < cols) ? EL::one(bias[c]) : 0.0f;
-    }
-  if constexpr (EPI == HZ_GEMM_STORE) {
-    if (!lead) return;
-    uint16_t* out = reinterpret_cast<uint16_t*>(outv);
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-      for (int rt = 0; rt < 2; ++rt) {
-        const int r = rowof(rt), c = colof(ct);
-        if (r >= rows || c >= cols) continue;
-        uint16_t* p = out + (long long)r * os + c;
-        const f32x4 a = acc[ct][rt];
-        if (c + 3 < cols && (os & 3) == 0) {
-          uint2 pk;
-          pk.x = EL::pack(a[0] + bv[ct][0], a[1] + bv[ct][1]);
-          pk.y = EL::pack(a[2] + bv[ct][2], a[3] + bv[ct][3]);
-          *reinterpret_cast<uint2*>(p) = pk;
-        } else {
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (c + i < cols) p[i] = (uint16_t)(EL::pack(a[i] + bv[ct][i], 0.0f) & 0xffffu);
-        }
-      }
-  } else if constexpr (EPI == HZ_GEMM_ACC32) {
-    if (!lead) return;
-    float* out = reinterpret_cast<float*>(outv);
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-      for (int rt = 0; rt < 2; ++rt) {
-        const int r = rowof(rt), c = colof(ct);
-        if (r >= rows || c >= cols) continue;
-        float* p = out + (long long)r * os + c;
-        const f32x4 a = acc[ct][rt];
-        if (c + 3 < cols && (os & 3) == 0) {
-          float4 g = *reinterpret_cast<float4*>(p);
-          g.x += a[0]; g.y += a[1]; g.z += a[2]; g.w += a[3];
-          *reinterpret_cast<float4*>(p) = g;
-        } else {
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (c + i < cols) p[i] += a[i];
-        }
-      }
-  } else {
-    // training-mode BatchNorm1d + residual + ReLU on the accumulators (the arithmetic of k_bn_act_forward): the workgroup holds every
-    // row of its 32 columns.  y = x W^T + b is rounded to the element format first -- the tensor autocast's F.linear hands over.
-    uint16_t* out = reinterpret_cast<uint16_t*>(outv);
-    uint16_t* yo = reinterpret_cast<uint16_t*>(bn.y);
-    const uint16_t* res = reinterpret_cast<const uint16_t*>(bn.res);
-    uint16_t* ot = reinterpret_cast<uint16_t*>(bn.out_t);
-    float sum[2][4];
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) sum[ct][i] = 0.0f;
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-      for (int rt = 0; rt < 2; ++rt) {
-        const bool rv = lead && rowof(rt) < rows;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float y = rv ? gm_requant<EL>(acc[ct][rt][i] + bv[ct][i]) : 0.0f;
-          acc[ct][rt][i] = y;
-          sum[ct][i] += y;
-        }
-      }
-    auto reduce = [&](float (&v)[2][4], int slot) {  // over the 16 lanes of a row group, then over the RG row-group waves
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          v[ct][i] = hz_row16_sum(v[ct][i]);
-          if (lead && r16 == 0) s_red[slot][rg][16 * ct + 4 * q + i] = v[ct][i];
-        }
-      __syncthreads();
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int cl = 16 * ct + 4 * q + i;
-          float t = 0.0f;
-#pragma unroll
-          for (int g = 0; g < RG; ++g) t += s_red[slot][g][cl];
-          v[ct][i] = t;
-        }
-    };
-    reduce(sum, 0);
-    float mean[2][4], sq[2][4];
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        mean[ct][i] = sum[ct][i] / (float)rows;
-        sq[ct][i] = 0.0f;
-      }
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-      for (int rt = 0; rt < 2; ++rt)
-        if (lead && rowof(rt) < rows) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float d = acc[ct][rt][i] - mean[ct][i];
-            sq[ct][i] += d * d;
-          }
-        }
-    reduce(sq, 1);
-    if (!lead) return;
-    float inv[2][4], ga[2][4], be[2][4];
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int c = colof(ct) + i;
-        const float var = sq[ct][i] / (float)rows;
-        inv[ct][i] = rsqrtf(var + bn.eps);
-        ga[ct][i] = c < cols ? bn.gamma[c] : 0.0f;
-        be[ct][i] = c < cols ? bn.beta[c] : 0.0f;
-        if (rg == 0 && r16 == 0 && c < cols) {
-          const float ub = rows > 1 ? (float)rows / (float)(rows - 1) : 1.0f;
-          bn.save_mean[c] = mean[ct][i];
-          bn.save_invstd[c] = inv[ct][i];
-          bn.running_mean[c] = (1.0f - bn.momentum) * bn.running_mean[c] + bn.momentum * mean[ct][i];
-          bn.running_var[c] = (1.0f - bn.momentum) * bn.running_var[c] + bn.momentum * (var * ub);
-        }
-      }
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-      for (int rt = 0; rt < 2; ++rt) {
-        const int r = rowof(rt), c = colof(ct);
-        if (r >= rows || c >= cols) continue;
-        float v[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = (acc[ct][rt][i] - mean[ct][i]) * inv[ct][i] * ga[ct][i] + be[ct][i];
-        const bool full = c + 3 < cols;
-        if (res != nullptr) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (c + i < cols) v[i] = gm_requant<EL>(v[i]) + EL::one(res[(long long)r * bn.res_stride + c + i]);
-        }
-        if (bn.relu) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (!(v[i] > 0.0f)) v[i] = v[i] != v[i] ? v[i] : 0.0f;
-        }
-        if (full && (os & 3) == 0 && (bn.y_stride & 3) == 0) {
-          uint2 pk, py;
-          pk.x = EL::pack(v[0], v[1]); pk.y = EL::pack(v[2], v[3]);
-          py.x = EL::pack(acc[ct][rt][0], acc[ct][rt][1]); py.y = EL::pack(acc[ct][rt][2], acc[ct][rt][3]);
-          *reinterpret_cast<uint2*>(out + (long long)r * os + c) = pk;
-          *reinterpret_cast<uint2*>(yo + (long long)r * bn.y_stride + c) = py;
-        } else {
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (c + i < cols) {
-              out[(long long)r * os + c + i] = (uint16_t)(EL::pack(v[i], 0.0f) & 0xffffu);
-              yo[(long long)r * bn.y_stride + c + i] = (uint16_t)(EL::pack(acc[ct][rt][i], 0.0f) & 0xffffu);
-            }
-        }
-        if (ot != nullptr) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (c + i < cols) ot[(long long)(c + i) * bn.out_t_stride + r] = (uint16_t)(EL::pack(v[i], 0.0f) & 0xffffu);
-        }
-      }
-  }
-}
-
-extern "C" int hz_gemm_nt(const void* x, int64_t x_stride, const void* w, int64_t w_stride, const void* bias, int rows, int cols, int k,
-                          void* out, int64_t out_stride, int epilogue, const hz_gemm_bn_t* bn, int dtype, void* stream) {
-  HZ_REQUIRE(x && w && out, "hz_gemm_nt: null pointer");
-  HZ_REQUIRE(rows >= 1 && cols >= 1 && k >= 32 && k % 32 == 0, "hz_gemm_nt: rows=%d cols=%d k=%d (k: a positive multiple of 32)", rows, cols, k);
-  HZ_REQUIRE(x_stride >= k && w_stride >= k && x_stride % 8 == 0 && w_stride % 8 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0,
-             "hz_gemm_nt: operand rows must be 16-B aligned and at least k long (strides %lld, %lld)", (long long)x_stride, (long long)w_stride);
-  HZ_REQUIRE(out_stride >= cols, "hz_gemm_nt: out_stride %lld < cols %d", (long long)out_stride, cols);
-  HZ_REQUIRE(dtype == HZ_BF16 || dtype == HZ_F16, "hz_gemm_nt: dtype %d (HZ_BF16 or HZ_F16)", dtype);
-  HZ_REQUIRE(epilogue == HZ_GEMM_STORE || epilogue == HZ_GEMM_BN || epilogue == HZ_GEMM_ACC32, "hz_gemm_nt: epilogue %d", epilogue);
-  hz_gemm_bn_t b;
-  memset(&b, 0, sizeof(b));
-  if (epilogue == HZ_GEMM_BN) {
-    HZ_REQUIRE(bn != nullptr && bn->gamma && bn->beta && bn->running_mean && bn->running_var && bn->save_mean && bn->save_invstd && bn->y,
-               "hz_gemm_nt: the BatchNorm epilogue needs its parameter block");
-    HZ_REQUIRE(rows <= 256, "hz_gemm_nt: the BatchNorm epilogue keeps every row of a column in one workgroup: rows %d > 256", rows);
-    HZ_REQUIRE(bn->y_stride >= cols && (!bn->res || bn->res_stride >= cols) && (!bn->out_t || bn->out_t_stride >= rows) && bn->eps > 0.0f,
-               "hz_gemm_nt: BatchNorm epilogue strides / eps");
-    b = *bn;
-  }
-  hipStream_t s = (hipStream_t)stream;
-  // BatchNorm epilogue: 8 row groups (256 rows) x 2 slices of k; the others: 4 row groups (128 rows per workgroup) x 4 slices
-#define HZ_GEMM_LAUNCH(EL, EPI, RG, KS)                                                                                               \
-  hipLaunchKernelGGL((k_gemm_nt<EL, EPI, RG, KS>), dim3((cols + 31) / 32, (rows + 32 * RG - 1) / (32 * RG)), dim3(64 * RG * KS), 0, s,  \
-                     (const uint16_t*)x, (long long)x_stride, (const uint16_t*)w, (long long)w_stride, (const uint16_t*)bias, rows, cols, k, \
-                     out, (long long)out_stride, b)
-  if (dtype == HZ_BF16) {
-    if (epilogue == HZ_GEMM_STORE) HZ_GEMM_LAUNCH(ElBf16, HZ_GEMM_STORE, 4, 4);
-    else if (epilogue == HZ_GEMM_BN) HZ_GEMM_LAUNCH(ElBf16, HZ_GEMM_BN, 8, 2);
-    else HZ_GEMM_LAUNCH(ElBf16, HZ_GEMM_ACC32, 4, 4);
-  } else {
-    if (epilogue == HZ_GEMM_STORE) HZ_GEMM_LAUNCH(ElF16, HZ_GEMM_STORE, 4, 4);
-    else if (epilogue == HZ_GEMM_BN) HZ_GEMM_LAUNCH(ElF16, HZ_GEMM_BN, 8, 2);
-    else HZ_GEMM_LAUNCH(ElF16, HZ_GEMM_ACC32, 4, 4);
-  }
-#undef HZ_GEMM_LAUNCH
-  HZ_HIP(hipGetLastError());
-  return 0;
-}
-
-// 16-bit copies (and transposes) of many fp32 matrices in one launch: workgroup (tile, job) moves one 32 x 32 tile through LDS
-template <int DT>
-__global__ __launch_bounds__(256) void k_cast_transpose_many(const hz_cast_job_t* __restrict__ table) {
-  __shared__ float tile[32][33];
-  const hz_cast_job_t J = table[blockIdx.y];
-  const int tx = (J.cols + 31) / 32, ty = (J.rows + 31) / 32;
-  if ((int)blockIdx.x >= tx * ty) return;
-  const int r0 = ((int)blockIdx.x / tx) * 32, c0 = ((int)blockIdx.x % tx) * 32;
-  const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
-  uint16_t* dst = reinterpret_cast<uint16_t*>(J.dst);
-  uint16_t* dst_t = reinterpret_cast<uint16_t*>(J.dst_t);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = r0 + ly + 8 * i, c = c0 + lx;
-    float v = 0.0f;
-    if (r < J.rows && c < J.cols) {
-      v = J.src[(long long)r * J.cols + c];
-      if (dst != nullptr) dst[(long long)r * (J.dst_stride ? J.dst_stride : (long long)J.cols) + c] = tr_round<DT>(v);
-    }
-    tile[ly + 8 * i][lx] = v;
-  }
-  __syncthreads();
-  if (dst_t == nullptr) return;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = c0 + ly + 8 * i, r = r0 + lx;  // dst_t[c][r] = src[r][c]
-    if (r < J.rows && c < J.cols) dst_t[(long long)c * J.rows + r] = tr_round<DT>(tile[lx][ly + 8 * i]);
-  }
-}
-
-extern "C" int hz_cast_transpose_many(const hz_cast_job_t* table, int n, int max_tiles_per_job, int dtype, void* stream) {
-  HZ_REQUIRE(table != nullptr && n >= 1 && max_tiles_per_job >= 1, "hz_cast_transpose_many: table=%p n=%d max_tiles=%d", (const void*)table, n, max_tiles_per_job);
-  HZ_REQUIRE(dtype == HZ_BF16 || dtype == HZ_F16, "hz_cast_transpose_many: dtype %d (HZ_BF16 or HZ_F16)", dtype);
-  const dim3 grid(max_tiles_per_job, n);
-  if (dtype == HZ_BF16) hipLaunchKernelGGL(k_cast_transpose_many<HZ_BF16>, grid, dim3(256), 0, (hipStream_t)stream, table);
-  else hipLaunchKernelGGL(k_cast_transpose_many<HZ_F16>, grid, dim3(256), 0, (hipStream_t)stream, table);
-  HZ_HIP(hipGetLastError());
-  return 0;
-}
 
 // ------------------------------------------------------------------------------------------------ the heads' losses of one inference
 // One wavefront per batch row: lane l owns logits l, l + 64, ... of each head.  Everything in fp32 (the reference casts the

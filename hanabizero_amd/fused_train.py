@@ -1,121 +1,70 @@
 """hanabizero_amd.fused_train -- the learner's forward / backward through MuZeroNet / MuZeroNetFull with every
-Linear -> BatchNorm1d -> (+ skip) -> ReLU block, and every inference's losses, as hand-written launches (include/hz_train.h), in 16 bits.
+Linear -> BatchNorm1d -> (+ skip) -> ReLU block as one hipBLASLt GEMM + ONE hand-written launch (include/hz_train.h), in 16 bits.
 
 What it replaces: the module forward PyTorch autograd runs under autocast inside ``update_weights``
 (/root/reference/core/train.py:114-222; blocks of config/hanabi_control/model.py:18-125, 131-149, 241-269).  Same parameters
 (the wrapped module's own tensors: state_dict, optimiser and weight hand-over do not change), same arithmetic per block as
 ``F.linear`` + ``F.batch_norm(training=True)`` + add + ReLU under bf16 autocast -- 16-bit GEMM with fp32 accumulate, batch
-statistics in fp32, running statistics updated with momentum 0.1, outputs rounded where autocast materialises 16-bit tensors.
-A learner step at batch 256 is launch- and latency-bound (PyTorch: ~1.7 k kernels of a few microseconds; the library runs every
-GEMM of 256 rows on two compute units, 12 us each with operands nothing has touched since the last step:
-profiles/r04_learner_kernel_stats.md), so a block is
-
-    forward    ONE launch: hz_gemm_nt with the BatchNorm epilogue (a workgroup owns all rows of 32 output columns: the batch
-               statistics are local to it), writing y = x W^T + b, the output, and the output transposed
-    backward   hz_bn_act_backward (ReLU mask, the two BatchNorm reductions, dY and dY^T, affine gradients added into .grad)
-               hz_gemm_nt  W.grad += dY^T X   (operands dY^T and X^T, contiguous along the batch; fp32 accumulate INTO .grad)
-               hz_gemm_nt  dX = dY W          (operand W^T, kept beside W in 16 bits)
-
-instead of ~20 launches, and an inference's three losses + their logit gradients one more (_HeadLosses).  The reduction length of
-every GEMM is padded to a multiple of 32 with zeros (the first layer's 5540 input bits -> 5568, the dynamics net's 512 + 48 -> 576).
-Batches of more than 256 rows take the same blocks as a hipBLASLt GEMM + hz_bn_act_forward (the statistics no longer fit one
-workgroup).
+statistics in fp32, running statistics updated with momentum 0.1, outputs rounded where autocast materialises 16-bit tensors --
+but per block 2 launches forward and 4 backward instead of ~20: a learner step at batch 256 is launch-bound (~1.7 k kernels of a
+few microseconds; profiles/r04_learner_kernel_stats.md).
 
 How the gradients travel: a block's backward writes the BatchNorm affine gradients and the Linear weight gradient straight INTO
 the parameters' ``.grad`` (accumulating: the recurrent blocks are used num_unroll_steps times per step), so the parameters never
 enter autograd; ``.grad`` must exist and be zeroed per step (``optimizer.zero_grad(set_to_none=False)``, what GraphedUpdate
 does).  The gradient of a Linear bias in front of a training-mode BatchNorm is identically zero (the normalisation removes any
-per-column constant) and is left at zero rather than computed as 16-bit rounding noise.  16-bit copies of the Linear weights
-and their transposes are refreshed once per step by ONE launch (``refresh()``: hz_cast_transpose_many) instead of cast at every
-use.
+per-column constant) and is left at zero rather than computed as 16-bit rounding noise.  16-bit copies of the Linear weights are
+refreshed once per step (``refresh()``) instead of cast at every use.
 """
 import ctypes as C
 
 import torch
 import torch.nn as nn
 
-from ._lib import CastJob, GemmBn, check, lib
-from .model import NetworkOutput, _Res
+from ._lib import check, lib
+from .model import NetworkOutput, _Dyn, _Res
 
 _DT = {torch.bfloat16: 1, torch.float16: 2}  # include/hz_tree.h HZ_BF16 / HZ_F16
-_STORE, _BN, _ACC32 = 0, 1, 2                # include/hz_train.h HZ_GEMM_*
-MAX_FUSED_ROWS = 256
 
 
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def _pad32(k):
-    return (k + 31) // 32 * 32
-
-
-def _gemm(x, w, bias, rows, cols, k, out, epilogue, bn=None):
-    check(lib.hz_gemm_nt(x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), None if bias is None else bias.data_ptr(), rows, cols, k,
-                         out.data_ptr(), out.stride(0), epilogue, None if bn is None else C.byref(bn), _DT[x.dtype], _stream()), "hz_gemm_nt")
-
-
 class _Block:
-    """Linear (+ BatchNorm1d) of the wrapped module.  `w16` [C, Kp] / `w16t` [Kp, C] / `b16` [C]: the Linear's parameters in the
-    compute format, the reduction dimension K zero-padded to Kp = a multiple of 32."""
+    """Linear (+ BatchNorm1d) of the wrapped module; `w16` / `b16`: the Linear's parameters in the compute format."""
 
     def __init__(self, lin, bn, dtype, uses):
         self.lin, self.bn, self.uses = lin, bn, uses
-        Cn, K = lin.weight.shape
-        self.C, self.K, self.Kp = Cn, K, _pad32(K)
-        dev = lin.weight.device
-        self.w16 = torch.zeros(Cn, self.Kp, dtype=dtype, device=dev)
-        self.w16t = torch.zeros(self.Kp, Cn, dtype=dtype, device=dev)
+        self.w16 = lin.weight.detach().to(dtype)
         self.b16 = lin.bias.detach().to(dtype)
 
 
-def _padded(x, Kp):
-    """x [B, K] -> [B, Kp] with zero columns behind K (no copy when K == Kp)."""
-    if x.shape[1] == Kp and x.stride(1) == 1 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0:
-        return x
-    xp = torch.zeros(x.shape[0], Kp, dtype=x.dtype, device=x.device)
-    xp[:, :x.shape[1]] = x
-    return xp
-
-
 class _LinBNAct(torch.autograd.Function):
-    """(out, out^T) = act(batch_norm(x @ W^T + b) + res).  x: [B, Kp] (zero-padded), xt: its transpose [Kp, B] or None."""
+    """out = act(batch_norm(x @ W^T + b) + res): forward GEMM + hz_bn_act_forward; backward hz_bn_act_backward + two GEMMs."""
 
     @staticmethod
-    def forward(ctx, x, xt, res, blk, relu, anchor=None):
+    def forward(ctx, x, res, blk, relu, anchor=None):
         """anchor: any tensor that requires grad (the parameters do not enter autograd here: the first block of a forward, whose
         input is data, needs one for its output to be part of the graph); its gradient is None."""
         bn = blk.bn
-        B, Cn = x.shape[0], blk.C
-        stats = torch.empty((2, Cn), dtype=torch.float32, device=x.device)
-        y = torch.empty((B, Cn), dtype=x.dtype, device=x.device)
+        y = torch.addmm(blk.b16, x, blk.w16.t())
         out = torch.empty_like(y)
+        B, Cn = y.shape
+        stats = torch.empty((2, Cn), dtype=torch.float32, device=y.device)
         if res is not None:
             assert res.shape == y.shape and res.stride(1) == 1 and res.dtype == y.dtype
-        fast = B <= MAX_FUSED_ROWS
-        if fast:
-            out_t = torch.empty((Cn, B), dtype=x.dtype, device=x.device)
-            args = GemmBn(gamma=bn.weight.data_ptr(), beta=bn.bias.data_ptr(), running_mean=bn.running_mean.data_ptr(),
-                          running_var=bn.running_var.data_ptr(), save_mean=stats[0].data_ptr(), save_invstd=stats[1].data_ptr(),
-                          momentum=float(bn.momentum), eps=float(bn.eps), res=None if res is None else res.data_ptr(),
-                          res_stride=0 if res is None else res.stride(0), y=y.data_ptr(), y_stride=y.stride(0), out_t=out_t.data_ptr(),
-                          out_t_stride=out_t.stride(0), relu=int(relu))
-            _gemm(x, blk.w16, blk.b16, B, Cn, blk.Kp, out, _BN, args)
-        else:
-            out_t = out.new_empty(0)
-            torch.addmm(blk.b16, x, blk.w16.t(), out=y)
-            check(lib.hz_bn_act_forward(y.data_ptr(), y.stride(0), None if res is None else res.data_ptr(), 0 if res is None else res.stride(0),
-                                        out.data_ptr(), out.stride(0), B, Cn, bn.weight.data_ptr(), bn.bias.data_ptr(),
-                                        bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.momentum), float(bn.eps),
-                                        stats[0].data_ptr(), stats[1].data_ptr(), int(relu), _DT[y.dtype], _stream()), "hz_bn_act_forward")
-        ctx.blk, ctx.relu, ctx.has_res, ctx.fast = blk, relu, res is not None, fast
-        ctx.save_for_backward(x, xt if xt is not None else x.new_empty(0), y, out, stats)
-        ctx.mark_non_differentiable(out_t)
-        return out, out_t
+        check(lib.hz_bn_act_forward(y.data_ptr(), y.stride(0), None if res is None else res.data_ptr(), 0 if res is None else res.stride(0),
+                                    out.data_ptr(), out.stride(0), B, Cn, bn.weight.data_ptr(), bn.bias.data_ptr(),
+                                    bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.momentum), float(bn.eps),
+                                    stats[0].data_ptr(), stats[1].data_ptr(), int(relu), _DT[y.dtype], _stream()), "hz_bn_act_forward")
+        ctx.blk, ctx.relu, ctx.has_res = blk, relu, res is not None
+        ctx.save_for_backward(x, y, out, stats)
+        return out
 
     @staticmethod
-    def backward(ctx, dout, _dout_t):
-        x, xt, y, out, stats = ctx.saved_tensors
+    def backward(ctx, dout):
+        x, y, out, stats = ctx.saved_tensors
         blk, bn = ctx.blk, ctx.blk.bn
         if bn.weight.grad is None or blk.lin.weight.grad is None:
             raise RuntimeError("fused_train: the blocks accumulate into existing .grad tensors -- zero them with "
@@ -123,34 +72,20 @@ class _LinBNAct(torch.autograd.Function):
         if dout.stride(1) != 1:
             dout = dout.contiguous()
         B, Cn = y.shape
-        fast = ctx.fast and B % 32 == 0
         dy = torch.empty_like(y)
-        dy_t = torch.empty((Cn, B), dtype=y.dtype, device=y.device) if fast else None
         dres = torch.empty_like(y) if ctx.has_res else None
         check(lib.hz_bn_act_backward(dout.data_ptr(), dout.stride(0), out.data_ptr(), out.stride(0), y.data_ptr(), y.stride(0),
                                      dy.data_ptr(), dy.stride(0), None if dres is None else dres.data_ptr(), 0 if dres is None else dres.stride(0),
-                                     None if dy_t is None else dy_t.data_ptr(), 0 if dy_t is None else dy_t.stride(0),
                                      B, Cn, bn.weight.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), bn.weight.grad.data_ptr(),
                                      bn.bias.grad.data_ptr(), int(ctx.relu), _DT[y.dtype], _stream()), "hz_bn_act_backward")
-        g = blk.lin.weight.grad                                # W.grad += dY^T X: fp32 accumulate and output, no 16-bit rounding
-        if fast:
-            if xt.numel() == 0:
-                xt = x.t().contiguous()                        # (an input no fused block produced: the data, the dynamics net's concat)
-            _gemm(dy_t, xt, None, Cn, blk.K, B, g, _ACC32)
-        else:
-            torch.addmm(g, dy.t(), x[:, :blk.K], out_dtype=torch.float32, out=g)
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty((B, blk.Kp), dtype=y.dtype, device=y.device)
-            if ctx.fast:
-                _gemm(dy, blk.w16t, None, B, blk.Kp, Cn, dx, _STORE)
-            else:
-                torch.mm(dy, blk.w16, out=dx)
-        return dx, None, dres, None, None, None
+        g = blk.lin.weight.grad                                # W.grad += dy^T x: ONE GEMM, 16-bit operands, fp32 accumulate and output
+        torch.addmm(g, dy.t(), x, out_dtype=torch.float32, out=g)
+        dx = torch.mm(dy, blk.w16) if ctx.needs_input_grad[0] else None
+        return dx, dres, None, None, None
 
 
 class _Lin(torch.autograd.Function):
-    """A head's last layer: y = x @ W^T + b (no BatchNorm behind it; 201 / 48 / 20 columns: hipBLASLt)."""
+    """A head's last layer: y = x @ W^T + b (no BatchNorm behind it)."""
 
     @staticmethod
     def forward(ctx, x, blk):
@@ -163,7 +98,7 @@ class _Lin(torch.autograd.Function):
         (x,) = ctx.saved_tensors
         blk = ctx.blk
         g = blk.lin.weight.grad
-        torch.addmm(g, dy.t(), x[:, :blk.K], out_dtype=torch.float32, out=g)
+        torch.addmm(g, dy.t(), x, out_dtype=torch.float32, out=g)
         blk.lin.bias.grad.add_(dy.sum(0, dtype=torch.float32))
         return torch.mm(dy, blk.w16), None
 
@@ -214,7 +149,7 @@ class FusedTrainNet:
     def __init__(self, net, dtype=torch.bfloat16, unroll_steps=5):
         assert next(net.parameters()).is_cuda, "the fused blocks are HIP kernels"
         self.net, self.dtype = net, dtype
-        self.A, self.H = net.action_space_n, net.feature_size
+        self.A = net.action_space_n
         U = int(unroll_steps)
         self._blocks = []
         mk = lambda lin, bn, uses: self._mk(lin, bn, uses)
@@ -227,17 +162,11 @@ class FusedTrainNet:
         for p in net.parameters():
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
-        dev = self._blocks[0].w16.device
-        self._b32 = [b.lin.bias for b in self._blocks]
-        self._b16 = [b.b16 for b in self._blocks]
-        jobs = (CastJob * len(self._blocks))(*[CastJob(src=b.lin.weight.data_ptr(), dst=b.w16.data_ptr(), dst_t=b.w16t.data_ptr(), rows=b.C,
-                                                       cols=b.K, dst_stride=b.Kp) for b in self._blocks])
-        self._cast_table = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(dev)
-        self._cast_tiles = max(((b.C + 31) // 32) * ((b.K + 31) // 32) for b in self._blocks)
-        self._anchor = torch.zeros(1, device=dev, requires_grad=True)
+        self._w32 = [b.lin.weight for b in self._blocks] + [b.lin.bias for b in self._blocks]
+        self._w16 = [b.w16 for b in self._blocks] + [b.b16 for b in self._blocks]
+        self._anchor = torch.zeros(1, device=self._w16[0].device, requires_grad=True)
         self._counters = [b.bn.num_batches_tracked for b in self._blocks if b.bn is not None]
         self._uses = [b.uses for b in self._blocks if b.bn is not None]
-        self.refresh()
 
     def _mk(self, lin, bn, uses):
         b = _Block(lin, bn, self.dtype, uses)
@@ -283,12 +212,9 @@ class FusedTrainNet:
         return self
 
     def refresh(self):
-        """The 16-bit copies of the Linear weights (and their transposes) from the fp32 parameters: ONE launch for all of them
-        (hz_cast_transpose_many), one multi-tensor copy for the biases; once per optimiser step."""
+        """The 16-bit copies of the Linear parameters from the fp32 ones (once per optimiser step; one multi-tensor launch)."""
         with torch.no_grad():
-            check(lib.hz_cast_transpose_many(self._cast_table.data_ptr(), len(self._blocks), self._cast_tiles, _DT[self.dtype], _stream()),
-                  "hz_cast_transpose_many")
-            torch._foreach_copy_(self._b16, self._b32)
+            torch._foreach_copy_(self._w16, self._w32)
 
     fused_heads = True  # learner.compute_losses hands the whole unrolled forward + losses to compute_losses() below
 
@@ -324,37 +250,31 @@ class FusedTrainNet:
             torch._foreach_add_(self._counters, self._uses)
 
     # -- forward ------------------------------------------------------------------------------------------------------------
-    def _block(self, x, xt, res, blk, relu=True):
-        anchor = None if x.requires_grad else self._anchor
-        return _LinBNAct.apply(_padded(x, blk.Kp), xt if xt is not None and xt.numel() and xt.shape[0] == blk.Kp else None, res, blk, relu, anchor)
-
-    def _run(self, steps, x, xt=None):
+    def _run(self, steps, x):
         for st in steps:
             if st[0] == "lbr":
-                x, xt = self._block(x, xt, None, st[1])
+                x = _LinBNAct.apply(x, None, st[1], True, None if x.requires_grad else self._anchor)
             elif st[0] == "res":
                 _, early, b1, b2 = st
                 if early:   # ResMLP: skip added behind the first BatchNorm (model.py:18-30)
-                    t, tt = self._block(x, xt, x, b1)
-                    x, xt = self._block(t, tt, None, b2)
+                    x = _LinBNAct.apply(_LinBNAct.apply(x, x, b1, True), None, b2, True)
                 else:       # NewResMLP: behind the second (model.py:43-57)
-                    t, tt = self._block(x, xt, None, b1)
-                    x, xt = self._block(t, tt, x, b2)
+                    x = _LinBNAct.apply(_LinBNAct.apply(x, None, b1, True), x, b2, True)
             else:
-                x, xt = _Lin.apply(x, st[1]), None
-        return x, xt
+                x = _Lin.apply(x, st[1])
+        return x
 
     def initial_inference(self, obs):  # core/model.py:61-71, training branch
-        state, st = self._run(self.rep, obs.to(self.dtype))
-        return NetworkOutput(self._run(self.value, state, st)[0], [0.0] * obs.shape[0], self._run(self.actor, state, st)[0], state)
+        state = self._run(self.rep, obs.to(self.dtype))
+        return NetworkOutput(self._run(self.value, state), [0.0] * obs.shape[0], self._run(self.actor, state), state)
 
     def recurrent_inference(self, hidden_state, action):  # core/model.py:74-84, training branch
-        B, H = hidden_state.shape[0], self.H
+        B = hidden_state.shape[0]
+        one_hot = torch.zeros(B, self.A, dtype=self.dtype, device=hidden_state.device)
+        one_hot.scatter_(1, action, 1.0)
         early, b1, b2, b3 = self.dyn
-        sa = torch.zeros(B, b1.Kp, dtype=self.dtype, device=hidden_state.device)   # [state | one-hot action | zero padding]
-        sa[:, :H] = hidden_state
-        sa.scatter_(1, action + H, 1.0)
-        y, yt = self._block(sa, None, hidden_state if early else None, b1)
-        y, yt = self._block(y, yt, None, b2)
-        state, st = self._block(y, yt, None if early else hidden_state, b3)
-        return NetworkOutput(self._run(self.value, state, st)[0], self._run(self.reward, state, st)[0], self._run(self.actor, state, st)[0], state)
+        sa = torch.cat((hidden_state, one_hot), 1)
+        y = _LinBNAct.apply(sa, hidden_state if early else None, b1, True)
+        y = _LinBNAct.apply(y, None, b2, True)
+        state = _LinBNAct.apply(y, None if early else hidden_state, b3, True)
+        return NetworkOutput(self._run(self.value, state), self._run(self.reward, state), self._run(self.actor, state), state)

@@ -34,57 +34,10 @@ int hz_bn_act_forward(const void* x, int64_t x_stride, const void* res, int64_t 
 /* Backward of the same: dz = relu ? dout * (out > 0) : dout;
  *   dx[r][c] = gamma[c] * invstd[c] * (dz - mean_r(dz) - xhat * mean_r(dz * xhat)),   xhat = (x - mean) * invstd
  *   dgamma[c] += sum_r dz * xhat,  dbeta[c] += sum_r dz      (ACCUMULATED into fp32 buffers: the parameters' .grad)
- *   dres = dz (16-bit) if dres is not NULL: the gradient of the residual input;
- *   dx_t [cols][rows] = dx transposed if dx_t is not NULL (the weight-gradient GEMM's operand, contiguous along the batch). */
+ *   dres = dz (16-bit) if dres is not NULL: the gradient of the residual input. */
 int hz_bn_act_backward(const void* dout, int64_t dout_stride, const void* out, int64_t out_stride, const void* x, int64_t x_stride,
-                       void* dx, int64_t dx_stride, void* dres, int64_t dres_stride, void* dx_t, int64_t dx_t_stride, int rows, int cols,
-                       const float* gamma, const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, int relu, int dtype,
-                       void* stream);
-
-/* The learner's GEMMs at batch size: C[m][n] = sum_k X[m][k] * W[n][k] ("NT": both operands contiguous along the reduction), 16-bit
- * operands, fp32 accumulate on the matrix cores (v_mfma_f32_16x16x32), a few hundred rows.  The library runs these shapes as one or
- * two 256 x 256 macro-tiles: two compute units fetch the operands of a layer that nothing has touched since the last step (12 us
- * with cold operands, TunableOp's best included).  Here a workgroup owns 32 output columns and its 16 wavefronts split the rows
- * AND the reduction (partial sums meet in LDS), so that every fragment a wavefront needs is requested up front: one memory
- * latency per launch, 16 .. 64 compute units fetching.
- *   epilogue HZ_GEMM_BN     (rows <= 256: eight row groups x two halves of k) training-mode BatchNorm1d + residual + ReLU of
- *                           hz_bn_act_forward on the accumulators -- its statistics are local to the workgroup -- so a block's
- *                           forward is ONE launch.  Writes y = x W^T + b (16-bit: what the backward normalises again), out, and
- *                           optionally out^T [cols][rows] (the next block's weight-gradient operand, contiguous along the batch).
- *   epilogue HZ_GEMM_STORE  C (+ bias) rounded to 16 bits: the input gradient dX = dY W with W^T as the [n][k] operand.
- *   epilogue HZ_GEMM_ACC32  C added into an fp32 matrix: the weight gradient dW += dY^T X with dY^T and X^T as operands -- the
- *                           parameter's .grad accumulates in fp32 without a 16-bit rounding of the product.
- * x [rows][k] (row stride x_stride), w [cols][k] (w_stride); k % 32 == 0, strides % 8 == 0, pointers 16-B aligned. */
-enum { HZ_GEMM_STORE = 0, HZ_GEMM_BN = 1, HZ_GEMM_ACC32 = 2 };
-typedef struct {
-  const float* gamma;      /* HZ_GEMM_BN: BatchNorm affine, running statistics (updated), saved statistics (written) [cols] */
-  const float* beta;
-  float* running_mean;
-  float* running_var;
-  float* save_mean;
-  float* save_invstd;
-  float momentum, eps;
-  const void* res;         /* optional residual [rows][cols] 16-bit added behind the normalisation */
-  int64_t res_stride;
-  void* y;                 /* [rows][cols] 16-bit: the linear output */
-  int64_t y_stride;
-  void* out_t;             /* optional [cols][rows] 16-bit: out transposed */
-  int64_t out_t_stride;
-  int relu;
-} hz_gemm_bn_t;
-int hz_gemm_nt(const void* x, int64_t x_stride, const void* w, int64_t w_stride, const void* bias /* [cols] 16-bit or NULL */, int rows,
-               int cols, int k, void* out, int64_t out_stride, int epilogue, const hz_gemm_bn_t* bn, int dtype, void* stream);
-
-/* 16-bit copies of many fp32 matrices in one launch: dst[i] = src[i] rounded (row stride dst_stride), and dst_t[i] = its transpose
- * (where dst_t[i] != NULL).  table: n entries on the DEVICE (the learner's Linear weights and their transposes once per step). */
-typedef struct {
-  const float* src;
-  void* dst;
-  void* dst_t;
-  int32_t rows, cols;
-  int64_t dst_stride;   /* row stride of dst in elements (>= cols; 0 = cols): a copy padded along its rows keeps its padding */
-} hz_cast_job_t;
-int hz_cast_transpose_many(const hz_cast_job_t* table, int n, int max_tiles_per_job, int dtype, void* stream);
+                       void* dx, int64_t dx_stride, void* dres, int64_t dres_stride, int rows, int cols, const float* gamma,
+                       const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, int relu, int dtype, void* stream);
 
 /* The losses of ONE inference of the unrolled learner step (initial or recurrent; core/train.py:145-168, 196-216 with
  * config/hanabi_control/__init__.py:119-123 and core/config.py:192-253) in one launch, gradients included:

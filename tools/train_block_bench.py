@@ -56,15 +56,12 @@ def main():
                     x = torch.relu(bn(lin(x)))
             x.float().sum().backward()
         blocks = [_Block(lin, bn, torch.bfloat16, 1) for lin, bn in zip(lins, bns)]
-        for b in blocks:
-            b.w16.copy_(b.lin.weight.detach())
-            b.w16t.copy_(b.lin.weight.detach().t())
         x16 = x0.to(torch.bfloat16)
 
         def fused():
-            x, xt = x16, None
+            x = x16
             for k, b in enumerate(blocks):
-                x, xt = _LinBNAct.apply(x, xt, None, b, True, anchor if k == 0 else None)
+                x = _LinBNAct.apply(x, None, b, True, anchor if k == 0 else None)
             x.float().sum().backward()
         te, tf = graph_time(eager), graph_time(fused)
         # the two kernels alone
@@ -81,46 +78,9 @@ def main():
 
         def kb():
             for _ in range(20):
-                check(lib.hz_bn_act_backward(y.data_ptr(), Cn, o.data_ptr(), Cn, y.data_ptr(), Cn, dx.data_ptr(), Cn, None, 0, None, 0, B, Cn, bn.weight.data_ptr(),
+                check(lib.hz_bn_act_backward(y.data_ptr(), Cn, o.data_ptr(), Cn, y.data_ptr(), Cn, dx.data_ptr(), Cn, None, 0, B, Cn, bn.weight.data_ptr(),
                                              st8[0].data_ptr(), st8[1].data_ptr(), bn.weight.grad.data_ptr(), bn.bias.grad.data_ptr(), 1, 1, s()), "b")
-        # the GEMMs alone, hot and cold: hipBLASLt through torch against hz_gemm_nt (16-bit store; fp32 accumulate with the short reduction of a
-        # weight gradient).  "cold": 24 different weight matrices in turn (what a step does: a layer's weights were last touched a step ago)
-        a16 = torch.randn(B, Cn, device="cuda").bfloat16()
-        ws = [torch.randn(Cn, Cn, device="cuda").bfloat16() for _ in range(24)]
-        o16, g32 = torch.empty(B, Cn, device="cuda", dtype=torch.bfloat16), torch.zeros(Cn, Cn, device="cuda")
-        at = a16.t().contiguous()
-        st_ = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
-
-        def hz(xx, ww, rows, cols, k, oo, epi):
-            check(lib.hz_gemm_nt(xx.data_ptr(), xx.stride(0), ww.data_ptr(), ww.stride(0), None, rows, cols, k, oo.data_ptr(), oo.stride(0), epi, None, 1, st_()), "g")
-
-        def t_mm():
-            for i in range(24):
-                torch.mm(a16, ws[0].t(), out=o16)
-
-        def h_mm():
-            for i in range(24):
-                hz(a16, ws[0], B, Cn, Cn, o16, 0)
-
-        def t_mm_cold():
-            for i in range(24):
-                torch.mm(a16, ws[i].t(), out=o16)
-
-        def h_mm_cold():
-            for i in range(24):
-                hz(a16, ws[i], B, Cn, Cn, o16, 0)
-
-        def t_dw():
-            for _ in range(24):
-                torch.addmm(g32, at, a16, out_dtype=torch.float32, out=g32)
-
-        def h_dw():
-            for _ in range(24):
-                hz(at, at, Cn, Cn, B, g32, 2)
-        gem = {"torch_mm_hot_us": 1e6 * graph_time(t_mm) / 24, "hz_gemm_nt_store_hot_us": 1e6 * graph_time(h_mm) / 24,
-               "torch_mm_24_weights_us": 1e6 * graph_time(t_mm_cold) / 24, "hz_gemm_nt_store_24_weights_us": 1e6 * graph_time(h_mm_cold) / 24,
-               "torch_addmm_fp32_dw_us": 1e6 * graph_time(t_dw) / 24, "hz_gemm_nt_acc32_dw_us": 1e6 * graph_time(h_dw) / 24}
-        out["%dx%d" % (B, Cn)] = {**gem, "autograd_autocast_us_per_block_fwd_bwd": 1e6 * te / L, "fused_us_per_block_fwd_bwd": 1e6 * tf / L,
+        out["%dx%d" % (B, Cn)] = {"autograd_autocast_us_per_block_fwd_bwd": 1e6 * te / L, "fused_us_per_block_fwd_bwd": 1e6 * tf / L,
                                   "hz_bn_act_forward_us": 1e6 * graph_time(kf) / 20, "hz_bn_act_backward_us": 1e6 * graph_time(kb) / 20}
     print(json.dumps(out, indent=1))
 
