@@ -101,7 +101,7 @@ def test_game_history_and_put_equal_reference():
 
 
 # ------------------------------------------------------------------------------------------------ learner step
-def _learner_case(game, device, amp=None):
+def _learner_case(game, device, amp=None, fused=False):
     from hanabizero_amd.config import make_config
     from hanabizero_amd.learner import make_optimizer, update_weights
     fx = _fx("learner_step_%s.npz" % game)
@@ -114,13 +114,16 @@ def _learner_case(game, device, amp=None):
     net.load_state_dict({k: torch.from_numpy(v) for k, v in fill_state_dict(net.state_dict()).items()})
     net = net.to(device)
     assert [n for n, _ in net.named_parameters()] == [str(n) for n in fx["param_names"]]
+    if fused:  # (the learner's hand-written blocks and losses around the same parameters: hanabizero_amd/fused_train.py)
+        from hanabizero_amd.fused_train import FusedTrainNet
+        net = FusedTrainNet(net, unroll_steps=cfg.num_unroll_steps)
     opt = make_optimizer(net, cfg)
     batch = ((fx["obs"].astype(np.float32), fx["action"], fx["mask"], fx["indices"], fx["weights"], np.zeros(len(fx["weights"]))),
              (fx["target_reward"], fx["target_value"], fx["target_policy"]))
     out = []
     for it in range(2):
         loss_data, prio = update_weights(net, batch, opt, cfg, amp=amp)
-        grads = np.array([float(p.grad.double().norm()) for _, p in net.named_parameters()])
+        grads = np.array([float(p.grad.double().norm()) for p in net.parameters()])
         out.append((np.array(loss_data, np.float64), np.asarray(prio, np.float64), grads))
     return fx, net, out
 
@@ -170,6 +173,20 @@ def test_update_weights_on_gpu_equals_reference_step(game):
     fx, net, out = _learner_case(game, "cuda", amp=torch.bfloat16)
     for it, (loss, prio, grads) in enumerate(out):
         assert np.allclose(loss[[0, 1, 2, 4, 5, 6]], fx["loss_data_%d" % it][[0, 1, 2, 4, 5, 6]], rtol=3e-2, atol=3e-2), (it, loss)
+    # ... and through the hand-written blocks and losses (fused_train.FusedTrainNet: what the configs[4] loop trains with): the
+    # same bf16 bar against the reference's recorded fp32 step, priorities and first-step gradient norms included
+    fx, net, out = _learner_case(game, "cuda", amp=torch.bfloat16, fused=True)
+    for it, (loss, prio, grads) in enumerate(out):
+        tol = 3e-2 if it == 0 else 0.15   # (second step: weights that differ by one 16-bit step of rounding, 4 - 8 samples per BatchNorm)
+        assert np.allclose(loss[[0, 1, 2, 4, 5, 6]], fx["loss_data_%d" % it][[0, 1, 2, 4, 5, 6]], rtol=tol, atol=tol), (it, loss, fx["loss_data_%d" % it])
+        if it == 0:  # (the second step of a batch of 4-8 samples through train-mode BatchNorm in 16 bits: losses hold, per-sample values scatter)
+            ref = fx["priority_%d" % it]   # |predicted scalar - target| of 4 - 8 samples normalised together: 16-bit noise of a few % of the largest
+            assert np.allclose(prio, ref, rtol=0.15, atol=0.05 * float(ref.max())), (it, prio, ref)
+            names = [str(n) for n in fx["param_names"]]
+            big = np.array([fx["grad_norm_0"][k] > 1e-3 for k in range(len(names))])   # (Linear biases in front of a BatchNorm: zero in exact arithmetic)
+            ratio = grads[big] / fx["grad_norm_0"][big]
+            worst = sorted(zip(np.abs(np.log(ratio)), np.array(names)[big], ratio), reverse=True)[:6]
+            assert np.allclose(grads[big], fx["grad_norm_0"][big], rtol=0.35), worst   # (16-bit, 4 - 8 samples per BatchNorm: magnitudes, not digits)
 
 
 # ------------------------------------------------------------------------------------------------ batch inputs / targets
