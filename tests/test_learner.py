@@ -447,7 +447,8 @@ def test_config5_loop_hanabi_full_5p_with_reanalyze_on_one_gpu():
 # ---- the fused Linear + BatchNorm + ReLU blocks of the learner (include/hz_train.h, hanabizero_amd/fused_train.py) ----------
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("rows,cols,relu,with_res", [(256, 512, True, False), (256, 1024, True, True), (64, 200, False, True), (7, 33, True, False)])
+@pytest.mark.parametrize("rows,cols,relu,with_res", [(256, 512, True, False), (256, 1024, True, True), (64, 200, False, True), (7, 33, True, False),
+                                                     (600, 96, True, True)])  # (more rows than a thread holds in registers: the re-reading passes)
 def test_bn_act_kernels_against_fp32_reference(dtype, rows, cols, relu, with_res):
     """hz_bn_act_forward / hz_bn_act_backward against plain PyTorch fp32 of the same op on the same 16-bit inputs:
     batch_norm(training) -> (+ residual, through the 16-bit rounding autocast puts there) -> ReLU; outputs to one unit of the
