@@ -322,11 +322,32 @@ class GraphedUpdate:
                                     parts["policy_loss"].detach().mean(), parts["reward_loss"].detach().mean(),
                                     parts["value_loss"].detach().mean(), total_loss.detach() * 0]))
 
+    def _snapshot(self):
+        """What a step changes (weights, BatchNorm statistics, momentum), so that steps taken for warm-up or timing can be undone."""
+        mom = [None if st.get("momentum_buffer") is None else st["momentum_buffer"].detach().clone() for st in self.optimizer.state.values()]
+        return [p.detach().clone() for p in self.model.parameters()], [b.detach().clone() for b in self.model.buffers()], mom
+
+    def _restore(self, snap):
+        saved, saved_buf, mom = snap
+        with torch.no_grad():
+            for p, q in zip(self.model.parameters(), saved):
+                p.copy_(q)
+            for b, q in zip(self.model.buffers(), saved_buf):
+                b.copy_(q)
+            states = list(self.optimizer.state.values())
+            for i, st in enumerate(states):
+                if st.get("momentum_buffer") is not None:
+                    if i < len(mom) and mom[i] is not None:
+                        st["momentum_buffer"].copy_(mom[i])
+                    else:
+                        st["momentum_buffer"].zero_()  # (a zero buffer gives the first real step what a missing one gives it)
+            if hasattr(self.model, "refresh"):
+                self.model.refresh()
+
     def _capture(self):
         self.model.train()
         # warm-up on a side stream (allocations, autotuning, momentum buffers) with the state put back afterwards
-        saved = [p.detach().clone() for p in self.model.parameters()]
-        saved_buf = [b.detach().clone() for b in self.model.buffers()]
+        snap = self._snapshot()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -334,16 +355,7 @@ class GraphedUpdate:
                 self._body()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        with torch.no_grad():
-            for p, q in zip(self.model.parameters(), saved):
-                p.copy_(q)
-            for b, q in zip(self.model.buffers(), saved_buf):
-                b.copy_(q)
-            for st in self.optimizer.state.values():
-                if st.get("momentum_buffer") is not None:
-                    st["momentum_buffer"].zero_()  # (a zero buffer gives the first real step what a missing one gives it)
-            if hasattr(self.model, "refresh"):
-                self.model.refresh()
+        self._restore(snap)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, capture_error_mode="thread_local"):
             self._body()
@@ -436,6 +448,47 @@ class LearnerPipeline:
         self.learn.wait_stream(cur)
         with torch.cuda.stream(self.learn):
             self.graphed._capture()             # (now, not inside the first step: a capture synchronises the device)
+        self.prep_interference_ms = None
+        if getattr(model, "_head_streams", None):
+            self._pick_prepare_stream(dev)
+
+    def _pick_prepare_stream(self, dev, candidates=4, launches=1500):
+        """A captured step with parallel branches (fused_train.FusedTrainNet's heads) replays on streams of the graph's own, and
+        the GPU has fewer hardware queues (4) than the process has streams: a prepare stream that shares a queue with one of those
+        branches runs its batch AFTER the step instead of beside it (measured: 156 learner steps/s against 255).  Which of
+        PyTorch's pool streams collide is a matter of creation order, so measure: a captured train of small launches (about as
+        long as two steps, no host in it) on each candidate beside two replays of the step; the candidate on which the pair
+        finishes first becomes the prepare stream."""
+        g = self.graphed
+        snap = g._snapshot()
+        x = torch.zeros(1024, device=dev)
+        cands = [self.prep] + [torch.cuda.Stream(device=dev) for _ in range(candidates - 1)]
+        train = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize(dev)
+        with torch.cuda.graph(train, capture_error_mode="thread_local"):
+            for _ in range(launches):
+                x.add_(1.0)
+        t = []
+        for c in cands:
+            torch.cuda.synchronize(dev)
+            a, b, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            cur = torch.cuda.current_stream(dev)
+            a.record(cur)
+            c.wait_event(a)
+            self.learn.wait_event(a)
+            with torch.cuda.stream(c):
+                train.replay()
+                b.record(c)
+            with torch.cuda.stream(self.learn):
+                g.run()
+                g.run()
+                e.record(self.learn)
+            torch.cuda.synchronize(dev)
+            t.append(max(a.elapsed_time(b), a.elapsed_time(e)))
+        g._restore(snap)
+        torch.cuda.synchronize(dev)
+        self.prep = cands[min(range(len(t)), key=t.__getitem__)]
+        self.prep_interference_ms = t
 
     def _value_fn(self, windows):
         return self.target.initial(windows, padded=self.Dp != self.replay.D)[0]

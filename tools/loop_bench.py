@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--share-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--learner-acts", action="store_true", help="N > 1: rank 0 plays too (default: it only learns)")
+    ap.add_argument("--actor-stream", default="null", choices=["null", "normal", "low"], help="the stream the lock-steps run on")
     ap.add_argument("--eager-blocks", action="store_true", help="the learner's module forward through PyTorch autograd under autocast instead of the fused Linear + BatchNorm + ReLU blocks (include/hz_train.h)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -100,7 +101,8 @@ def main():
     engine = actor = None
     if acts:
         engine = bench.build_engine(cfg, dtype, device)
-        actor = SelfPlayActor(cfg, engine, args.envs, rank=actor_index, seed=0, device=device)
+        actor_stream = None if args.actor_stream == "null" else torch.cuda.Stream(device=device, priority=0 if args.actor_stream == "normal" else 1)
+        actor = SelfPlayActor(cfg, engine, args.envs, rank=actor_index, seed=0, device=device, stream=actor_stream)
         net_dev = cfg.get_uniform_network().to(device)  # the module the broadcast weights land in (in place, on the device)
         net_dev.eval()
     pipe = replay = None
@@ -272,7 +274,8 @@ def main():
                "weight_handover_ms": handover_ms, "weight_handover_first_ms": handover_each[0], "weight_handovers_in_run": handover["count"] - 3,
                "host_wait_for_the_gpu_ms_per_learner_step": (1e3 * pipe.host_wait_s / max(1, pipe.steps)),
                "checkpoint_interval": cfg.checkpoint_interval, "target_model_interval": cfg.target_model_interval,
-               "loss_last": losses[1] if losses else None, "learner_blocks": "autograd (autocast)" if args.eager_blocks else "fused (include/hz_train.h)"}
+               "loss_last": losses[1] if losses else None, "learner_blocks": "autograd (autocast)" if args.eager_blocks else "fused (include/hz_train.h)",
+               "prepare_stream_candidates_ms": pipe.prep_interference_ms}
         print(json.dumps(out), flush=True)
     if world > 1:
         barrier()
