@@ -146,19 +146,18 @@ class FusedTrainNet:
     hidden state, no scalar transform), parameters / buffers / state_dict / load_state_dict / train; `net` is the module itself
     (weight hand-over: InferenceEngine.load(model.net))."""
 
-    def __init__(self, net, dtype=torch.bfloat16, unroll_steps=5, parallel_heads=2):
-        """parallel_heads (0..3): the value / reward / policy heads of an inference are three independent chains of small
+    def __init__(self, net, dtype=torch.bfloat16, unroll_steps=5, parallel_heads=None):
+        """parallel_heads (0..3; None: 2 where the heads have three layers or more, else 0): the value / reward / policy heads of an inference are three independent chains of small
         launches; that many of them (in this order) run on streams of their own, forked from and joined into the caller's
         (autograd runs a chain's backward on its forward's stream).  Inside the learner's captured step they become parallel
         branches of the hipGraph, which the GPU does overlap for kernels this small: 4.35 ms per replayed step with 0, 3.91 with
         1, 3.52 with 2, 3.65 with 3 (Hanabi-Full 5p, batch 256).  Two is the default for a second reason: a step three branches
         wide keeps three of the GPU's four hardware queues busy, and the learner's prepare stream needs one to itself
-        (learner.LearnerPipeline._pick_prepare_stream)."""
+        (learner.LearnerPipeline._pick_prepare_stream).  Two-layer heads (Hanabi-Small) do not repay the fork and the join: 2.26 ms
+        per step as one chain, 2.52 with two branches."""
         assert next(net.parameters()).is_cuda, "the fused blocks are HIP kernels"
         self.net, self.dtype = net, dtype
         dev0 = next(net.parameters()).device
-        n_side = max(0, min(3, int(parallel_heads)))
-        self._head_streams = [torch.cuda.Stream(device=dev0) for _ in range(n_side)] + [None] * (3 - n_side) if n_side else None
         self.A = net.action_space_n
         U = int(unroll_steps)
         self._blocks = []
@@ -169,6 +168,9 @@ class FusedTrainNet:
         self.reward = self._chain(net._dynamics_reward, U, mk)
         self.actor = self._chain(net._prediction_actor, U + 1, mk)
         self.value = self._chain(net._prediction_value, U + 1, mk)
+        layers = sum(2 if st[0] == "res" else 1 for st in self.value)
+        n_side = (2 if layers >= 3 else 0) if parallel_heads is None else max(0, min(3, int(parallel_heads)))
+        self._head_streams = [torch.cuda.Stream(device=dev0) for _ in range(n_side)] + [None] * (3 - n_side) if n_side else None
         for p in net.parameters():
             if p.grad is None:
                 p.grad = torch.zeros_like(p)

@@ -402,6 +402,9 @@ class _Slot:
         self.re_windows = torch.zeros((R * (U + 1), win_shape[1]), dtype=win_dtype, device=d) if R else None
         self.ready, self.done = torch.cuda.Event(), torch.cuda.Event()
         self.used = False
+        import threading
+        self.enqueued = threading.Event()   # the learner half of the step that last used this slot has been enqueued (`done` recorded)
+        self.enqueued.set()
 
 
 class LearnerPipeline:
@@ -416,10 +419,15 @@ class LearnerPipeline:
     so batch k + 1 is searched and assembled while step k trains (the reference's queue of prepared batches, depth 2).
     Cadences as train.py:392-398: `on_checkpoint(step)` every checkpoint_interval steps (the caller hands the weights to the
     actors), the target model takes the learner's weights of one target_model_interval ago every target_model_interval steps.
-    Nothing synchronises the host; `losses()` reads the last step's loss tuple (one small read-back) when somebody wants it."""
+    Nothing synchronises the host; `losses()` reads the last step's loss tuple (one small read-back) when somebody wants it.
+
+    host_thread: the learner half is enqueued by a second host thread.  Launching the captured step costs the host 2.1 ms
+    (~550 graph nodes, spent inside hipGraphLaunch without the GIL), the prepare half 2.4 ms of Python-side launches; one thread
+    doing both was slower than the 3.5 ms the step takes on the GPU.  What runs on which stream, and in which order, is the same
+    either way; `flush()` before touching `learn` or a slot's `done` event from outside."""
 
     def __init__(self, config, replay, model, target_engine, batch_size=None, reanalyze_share=0.5, amp=torch.bfloat16, beta=0.4,
-                 on_checkpoint=None, seed=0):
+                 on_checkpoint=None, seed=0, host_thread=True):
         from .device_replay import policy_re_device
         self._policy_re = policy_re_device
         self.cfg, self.replay, self.model, self.target = config, replay, model, target_engine
@@ -451,6 +459,53 @@ class LearnerPipeline:
         self.prep_interference_ms = None
         if getattr(model, "_head_streams", None):
             self._pick_prepare_stream(dev)
+        self._dev, self._error, self._queue, self._thread = dev, None, None, None
+        if host_thread:
+            import queue
+            import threading
+            self._queue = queue.Queue()
+            self._thread = threading.Thread(target=self._learn_loop, name="hz-learner-half", daemon=True)
+            self._thread.start()
+
+    def _learn_loop(self):
+        torch.cuda.set_device(self._dev)
+        while True:
+            item = self._queue.get()
+            if item is None:
+                return
+            slot, k = item
+            try:
+                if self._error is None:
+                    self._learn_half(slot, k)
+            except BaseException as e:      # (surfaces in the enqueueing thread: step / flush / losses)
+                self._error = e
+            finally:
+                slot.enqueued.set()
+
+    def _learn_half(self, slot, k):
+        with torch.cuda.stream(self.learn):
+            self.learn.wait_event(slot.ready)
+            g = self.graphed
+            for name in ("obs", "action", "target_reward", "target_value", "target_policy", "weights"):
+                getattr(g, name).copy_(getattr(slot, name), non_blocking=True)
+            adjust_lr(self.cfg, self.optimizer, k)
+            g.run()
+            slot.priority.copy_(g.priority, non_blocking=True)
+            slot.done.record(self.learn)
+
+    def flush(self):
+        """Returns once every step handed in so far has been enqueued on the streams (not: has run)."""
+        for slot in self.slots:
+            slot.enqueued.wait()
+        if self._error is not None:
+            e, self._error = self._error, None
+            raise RuntimeError("the learner half of a step failed") from e
+
+    def close(self):
+        if self._thread is not None:
+            self._queue.put(None)
+            self._thread.join()
+            self._thread = None
 
     def _pick_prepare_stream(self, dev, candidates=4, launches=1500):
         """A captured step with parallel branches (fused_train.FusedTrainNet's heads) replays on streams of the graph's own, and
@@ -497,8 +552,11 @@ class LearnerPipeline:
         """Enqueue learner step number self.steps (both halves).  Returns nothing; never blocks the host."""
         cfg, rp, k = self.cfg, self.replay, self.steps
         slot = self.slots[k % 2]
+        if self._error is not None:
+            self.flush()
         if slot.used:
             import time
+            slot.enqueued.wait()                # (step k - 2's learner half has been enqueued: `done` is that step's)
             t0 = time.perf_counter()
             slot.done.synchronize()             # (back-pressure: the host enqueues at most two steps ahead of the one training)
             self.host_wait_s += time.perf_counter() - t0
@@ -508,6 +566,7 @@ class LearnerPipeline:
                 rp.update_priorities(slot.ids, slot.priority)
             if k % cfg.target_model_interval == 0 and k > 0:   # train.py:396-398
                 prev = self.slots[(k - 1) % 2]
+                prev.enqueued.wait()
                 self.prep.wait_event(prev.done)                # (the learner's weights as of step k - 1 are complete)
                 self.target.load(self._recent_net)
                 self._recent_net.load_state_dict(self.net.state_dict())
@@ -528,22 +587,20 @@ class LearnerPipeline:
                                       padded=self.Dp != rp.D, roots=self._re_roots)
                 slot.target_policy[:self.R] = pol.view(self.R, cfg.num_unroll_steps + 1, -1)   # [reanalyzed | stored], :412-419
             slot.ready.record(self.prep)
-        with torch.cuda.stream(self.learn):
-            self.learn.wait_event(slot.ready)
-            g = self.graphed
-            for name in ("obs", "action", "target_reward", "target_value", "target_policy", "weights"):
-                getattr(g, name).copy_(getattr(slot, name), non_blocking=True)
-            adjust_lr(cfg, self.optimizer, k)
-            g.run()
-            slot.priority.copy_(g.priority, non_blocking=True)
-            slot.done.record(self.learn)
+        if self._thread is not None:
+            slot.enqueued.clear()
+            self._queue.put((slot, k))
+        else:
+            self._learn_half(slot, k)
         slot.used = True
         self.steps = k + 1
         if self.on_checkpoint is not None and self.steps % cfg.checkpoint_interval == 0:   # train.py:392-393
+            slot.enqueued.wait()
             self.on_checkpoint(self.steps, slot.done)
 
     def losses(self):
         """(total, weighted, mean loss, 0, mean policy, mean reward, mean value, 0.0) of the last finished step (synchronises)."""
+        self.flush()
         self.learn.synchronize()
         o = self.graphed.out.cpu().numpy()
         return (float(o[0]), float(o[1]), float(o[2]), 0, float(o[3]), float(o[4]), float(o[5]), 0.0)

@@ -212,8 +212,8 @@ def test_policy_re_on_the_device_equals_the_host_context_path():
 
 
 def test_learner_pipeline_equals_its_single_stream_schedule():
-    """learner.LearnerPipeline (two streams, batch k + 1 prepared while step k trains, priorities written back two steps later,
-    target model refreshed one interval behind) leaves the same weights, priorities and target model as the SAME sequence of
+    """learner.LearnerPipeline (two streams fed by two host threads, batch k + 1 prepared while step k trains, priorities written
+    back two steps later, target model refreshed one interval behind) leaves the same weights, priorities and target model as the SAME sequence of
     operations enqueued on one stream -- where ordering is trivially right: any missing event between the streams shows here."""
     import copy
     from hanabizero_amd.learner import LearnerPipeline
@@ -227,14 +227,17 @@ def test_learner_pipeline_equals_its_single_stream_schedule():
         model = copy.deepcopy(eng._net).cuda()
         target = InferenceEngine(copy.deepcopy(eng._net), cfg.value_support.max, dtype=torch.float16, device="cuda")
         calls = []
-        pipe = LearnerPipeline(cfg, dr, model, target, reanalyze_share=0.5, on_checkpoint=lambda step, ev: calls.append(step), seed=3)
+        pipe = LearnerPipeline(cfg, dr, model, target, reanalyze_share=0.5, on_checkpoint=lambda step, ev: calls.append(step), seed=3,
+                               host_thread=pipelined)
         if not pipelined:
             pipe.prep = pipe.learn = torch.cuda.current_stream()
         for _ in range(11):
             pipe.step()
+        pipe.flush()
         torch.cuda.synchronize()
         assert pipe.steps == 11 and calls == [5, 10]
         losses = pipe.losses()
+        pipe.close()
         assert all(np.isfinite(x) for x in losses)
         results.append(([p.detach().clone() for p in model.parameters()], dr.priority[:dr.head].clone(),
                         [t.clone() for t in target._dev.values()], losses))

@@ -21,6 +21,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--game", default="Hanabi-Full-5p")
     ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--parallel-heads", type=int, default=None, help="--fused: head chains on streams of their own (FusedTrainNet)")
     ap.add_argument("--fused", action="store_true", help="the module forward through the fused Linear + BatchNorm + ReLU blocks (hanabizero_amd/fused_train.py)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -28,7 +29,7 @@ def main():
     net = cfg.get_uniform_network().to(dev)
     if args.fused:
         from hanabizero_amd.fused_train import FusedTrainNet
-        net = FusedTrainNet(net, unroll_steps=cfg.num_unroll_steps)
+        net = FusedTrainNet(net, unroll_steps=cfg.num_unroll_steps, parallel_heads=args.parallel_heads)
     opt = make_optimizer(net, cfg, capturable=True)
     g = GraphedUpdate(net, opt, cfg, cfg.batch_size)
     B, U, A, stack = cfg.batch_size, cfg.num_unroll_steps, cfg.action_space_size, cfg.stacked_observations

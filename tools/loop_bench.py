@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--share-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--learner-acts", action="store_true", help="N > 1: rank 0 plays too (default: it only learns)")
     ap.add_argument("--actor-stream", default="null", choices=["null", "normal", "low"], help="the stream the lock-steps run on")
+    ap.add_argument("--parallel-heads", type=int, default=None, help="head chains of the learner's inferences on streams of their own (FusedTrainNet)")
+    ap.add_argument("--one-host-thread", action="store_true", help="the learner half of a step enqueued by the thread that prepares the batches (default: by a second one)")
     ap.add_argument("--eager-blocks", action="store_true", help="the learner's module forward through PyTorch autograd under autocast instead of the fused Linear + BatchNorm + ReLU blocks (include/hz_train.h)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -114,12 +116,12 @@ def main():
         learner.load_state_dict((engine or target)._net.state_dict())
         if not args.eager_blocks:
             from hanabizero_amd.fused_train import FusedTrainNet
-            learner = FusedTrainNet(learner, unroll_steps=cfg.num_unroll_steps)
+            learner = FusedTrainNet(learner, unroll_steps=cfg.num_unroll_steps, parallel_heads=args.parallel_heads)
 
         def on_checkpoint(step, done_event):
             handover["pending"], handover["event"] = True, done_event
         pipe = LearnerPipeline(cfg, replay, learner, target, batch_size=cfg.batch_size, reanalyze_share=args.reanalyze_share,
-                               on_checkpoint=on_checkpoint)
+                               on_checkpoint=on_checkpoint, host_thread=not args.one_host_thread)
     A = cfg.action_space_size
     W = (cfg.obs_dim + 31) // 32
 
@@ -140,10 +142,12 @@ def main():
                 engine.load(pipe.net)
                 taken = torch.cuda.Event()
                 taken.record(ws)
+            pipe.flush()
             pipe.learn.wait_event(taken)  # (the next update must not overwrite what is being folded)
         else:
             state = None
             if learns:
+                pipe.flush()
                 pipe.learn.synchronize()
                 state = {k: v.detach() for k, v in pipe.net.state_dict().items()}
             else:
@@ -216,6 +220,7 @@ def main():
         assert replay.get_total_len() > cfg.batch_size, "the warm rounds finished too few games (%d positions)" % replay.get_total_len()
         for _ in range(3):   # (first shapes of the reanalyze search, hipBLASLt workspaces)
             pipe.step()
+        pipe.flush()
         pipe.learn.synchronize()
     torch.cuda.synchronize(device)
     barrier()
@@ -227,6 +232,7 @@ def main():
     for r in range(args.rounds):
         one_round(train=args.ratio > 0)
     if learns:
+        pipe.flush()
         pipe.learn.synchronize()
         pipe.prep.synchronize()
     torch.cuda.synchronize(device)
@@ -275,8 +281,10 @@ def main():
                "host_wait_for_the_gpu_ms_per_learner_step": (1e3 * pipe.host_wait_s / max(1, pipe.steps)),
                "checkpoint_interval": cfg.checkpoint_interval, "target_model_interval": cfg.target_model_interval,
                "loss_last": losses[1] if losses else None, "learner_blocks": "autograd (autocast)" if args.eager_blocks else "fused (include/hz_train.h)",
-               "prepare_stream_candidates_ms": pipe.prep_interference_ms}
+               "prepare_stream_candidates_ms": pipe.prep_interference_ms,
+               "host_threads_on_the_learner_rank": 1 if args.one_host_thread else 2}
         print(json.dumps(out), flush=True)
+        pipe.close()
     if world > 1:
         barrier()
         dist.destroy_process_group()
