@@ -401,8 +401,10 @@ class Run:
         self.workload, self.dtype_name, self.net = workload, dtype_name, net
         self.flush_every = args.flush_every or (15 if self.game == "Hanabi-Small" else 40)
         self.cfg = make_config(self.game, simulations=self.S, stack=self.stack, p_mcts_num=self.N)
-        self.dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[dtype_name]
-        self.engine = build_engine(self.cfg, self.dtype, device, fused=False if args.no_fused_mlp else None, net=net)
+        # ("fp16x2": the fp32 engine whose recurrent inference is the MFMA kernel's fp16-pair build -- include/hz_mlp.h, HZ_F16X2)
+        self.dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32, "fp16x2": torch.float32}[dtype_name]
+        self.fused = "fp16x2" if dtype_name == "fp16x2" else (False if args.no_fused_mlp else None)
+        self.engine = build_engine(self.cfg, self.dtype, device, fused=self.fused, net=net)
         K, N = args.actors_per_gpu, self.N
         assert N % K == 0
         # outbox ring: 8 x envs games -- the asynchronous drain hands a flush interval's games out one interval later, and
@@ -527,19 +529,19 @@ class Run:
         torch.cuda.empty_cache()
 
 
-def net_error(game, dtype, search=True):
+def net_error(game, dtype, search=True, fused=None):
     from tests.netgold import golden_net_error
     g = "Hanabi-Full" if game.startswith("Hanabi-Full") else game  # (the 5p net is the Full net at other widths)
-    e = golden_net_error(g, dtype)
+    e = golden_net_error(g, dtype, fused=fused)
     w = e["wide"]
     out = {"against": "tests/golden/nets_%s.npz (reference MuZeroNet%s fp32 outputs)" % (g, "" if g == "Hanabi-Small" else "Full"),
-           "path": "fused MFMA kernels" if e["fused"] else "GEMM chain", "measure": "max / mean of |got - ref| / max(1, |ref|)",
+           "path": ("fp32 GEMMs (root) + fused MFMA kernel, fp16 pairs (recurrent)" if fused == "fp16x2" else "fused MFMA kernels") if e["fused"] else "GEMM chain", "measure": "max / mean of |got - ref| / max(1, |ref|)",
            "worst": e["worst"], **{k: v for k, v in e.items() if isinstance(v, dict) and "max" in v},
            # the reference's own search precision as the yardstick (tests/golden/nets_*_autocast.npz)
            "reference_under_fp16_autocast_vs_its_fp32_worst": e["reference_autocast_vs_fp32"]["worst"],
            "vs_reference_under_fp16_autocast_worst": e["vs_reference_autocast"]["worst"],
            "rms_ratio_to_reference_autocast_256_rows": {k: v["rms"] / w["reference_autocast_vs_fp32"][k]["rms"] for k, v in w["got_vs_fp32"].items()}}
-    if search and e["fused"]:
+    if search and e["fused"] and fused != "fp16x2":
         from tests.netgold import search_divergence
         out["search_vs_fp32_engine"] = search_divergence(g, dtype, roots=512)
     return out
@@ -598,7 +600,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="full4096", choices=sorted(WORKLOADS))
-    ap.add_argument("--dtype", default="fp16", choices=["bf16", "fp16", "fp32"],
+    ap.add_argument("--dtype", default="fp16", choices=["bf16", "fp16", "fp32", "fp16x2"],
                     help="format of the nets (weights, activations, hidden-state pool; fp32 accumulate): fp16 = the reference's own search "
                          "precision (autocast, core/mcts.py:38-40; the default), bf16 = what BASELINE.json configs[2] names (measured under `also`)")
     ap.add_argument("--predicted-lines", default="auto", choices=["auto", "on", "off"],
@@ -699,7 +701,7 @@ def main():
     if args.check_env_ids and rank == 0:
         out["config"]["env_id_min_max_distinct"] = [min(run.env_ids), max(run.env_ids), len(run.env_ids)] if run.env_ids else None
     if rank == 0 and not args.no_roofline:
-        out["net_error"] = net_error(game, run.dtype)
+        out["net_error"] = net_error(game, run.dtype, fused=run.fused if run.fused == "fp16x2" else None)
 
     if rank == 0 and not args.no_roofline:
         actor, engine, cfg, dtype = run.actors[0], run.engine, run.cfg, run.dtype
@@ -803,7 +805,9 @@ def main():
             other_dt = "bf16" if args.dtype != "bf16" else "fp16"
             plan = [("full8192", "full8192", args.dtype, "random"), ("full8192_bf16", "full8192", "bf16", "random"),  # configs[2] names bf16
                     (other_dt, args.workload, other_dt, "random"), ("deep_paths", args.workload, args.dtype, "sharp"),
-                    ("deep_paths_full8192", "full8192", args.dtype, "sharp")]
+                    ("deep_paths_full8192", "full8192", args.dtype, "sharp"),
+                    # the engines inside the contract's 1e-3 of the reference's fp32 nets: hand-written recurrent kernel / library GEMMs
+                    ("fp16x2", args.workload, "fp16x2", "random"), ("fp32", args.workload, "fp32", "random")]
             plan = [p for k, p in enumerate(plan) if p[1:] not in [q[1:] for q in plan[:k]]]
         for name, wl, dt, net in plan:
             r = Run(args, wl, dt, device, 0, 1, net=net)
@@ -819,7 +823,7 @@ def main():
                 if net != "random":
                     entry["mean_path_edges"], entry["deepest_path_edges"] = mean_path_edges(r.actors[0])
                 if dt != args.dtype:
-                    ne = net_error(r.game, r.dtype)
+                    ne = net_error(r.game, r.dtype, fused=r.fused if r.fused == "fp16x2" else None)
                     entry["net_error_worst"], entry["search_vs_fp32_engine"] = ne["worst"], ne.get("search_vs_fp32_engine")
             also[name] = entry
             r.release()

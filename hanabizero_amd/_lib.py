@@ -27,7 +27,7 @@ class MlpHeader(C.Structure):  # include/hz_mlp.h hz_mlp_header_t
                 ("support_size", C.c_int32), ("support_min", C.c_int32), ("num_actions", C.c_int32),
                 ("action_table_stride", C.c_int32), ("in_width", C.c_int32), ("dtype", C.c_int32),
                 ("num_waves", C.c_int32), ("tiles_per_wave", C.c_int32),
-                ("logit_split", C.c_int32), ("off_reward2", C.c_int32), ("off_value2", C.c_int32), ("reserved1", C.c_int32),
+                ("logit_split", C.c_int32), ("off_reward2", C.c_int32), ("off_value2", C.c_int32), ("lo_plane", C.c_int32),
                 ("kstep_stride", C.c_int64), ("wave_stream_off", C.c_int64 * 16)]
 
 

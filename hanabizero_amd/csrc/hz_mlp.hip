@@ -87,7 +87,12 @@ extern "C" int hz_mlp_recurrent_res(const hz_mlp_header_t* H, const hz_mlp_job_t
              "hz_mlp_recurrent_res: the residual rows go with ungathered input rows, 16-B aligned, stride a multiple of 8 elements");
   HZ_REQUIRE(rows_per_wg == 16 || rows_per_wg == 32, "hz_mlp_recurrent: rows_per_wg must be 16 or 32");
   HZ_REQUIRE(H->n_jobs > 0 && H->n_jobs <= 32, "hz_mlp_recurrent: bad job count %d", H->n_jobs);
-  HZ_REQUIRE(H->dtype == HZ_BF16 || H->dtype == HZ_F16, "hz_mlp_recurrent: header dtype must be HZ_BF16 or HZ_F16 (got %d)", H->dtype);
+  HZ_REQUIRE(H->dtype == HZ_BF16 || H->dtype == HZ_F16 || H->dtype == HZ_F16X2,
+             "hz_mlp_recurrent: header dtype must be HZ_BF16, HZ_F16 or HZ_F16X2 (got %d)", H->dtype);
+  HZ_REQUIRE(H->dtype != HZ_F16X2 || (H->num_waves != 16 && state_res == nullptr && H->lo_plane > 0 && H->lo_plane % 8 == 0 &&
+                                      2 * H->lo_plane <= H->row_stride),
+             "hz_mlp_recurrent: the fp16-pair build runs the 4- and 8-wave shapes on ungathered or gathered fp32 rows; its lo plane "
+             "lies lo_plane (a multiple of 8, at most row_stride / 2) columns behind the hi plane");
   HZ_REQUIRE(H->support_size > 0 && H->support_size <= 256 && H->off_reward % 8 == 0 && H->off_value % 8 == 0,
              "hz_mlp_recurrent: support_size must be <= 256 and the logit columns 16-B aligned");
   HZ_REQUIRE(H->row_stride % 8 == 0 && H->hidden % 8 == 0 && row_stride % 8 == 0 && plane_stride % 8 == 0 &&
@@ -134,6 +139,7 @@ extern "C" int hz_mlp_recurrent_res(const hz_mlp_header_t* H, const hz_mlp_job_t
 #define HZ_LAUNCH(RT, NW, NT)                           \
   do {                                                  \
     if (H->dtype == HZ_F16) HZ_LAUNCH_EL(ElF16, RT, NW, NT); \
+    else if (H->dtype == HZ_F16X2) HZ_LAUNCH_EL(ElF16x2, RT, NW, NT); \
     else HZ_LAUNCH_EL(ElBf16, RT, NW, NT);              \
   } while (0)
   if (H->num_waves == 4) {

@@ -18,6 +18,7 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 struct ElBf16 {
   typedef bf16x8 v8;
   static constexpr int code = HZ_BF16;
+  static constexpr bool split = false;
   // the two elements of a packed pair -> fp32
   static __device__ __forceinline__ float lo(uint32_t w) { return __uint_as_float(w << 16); }
   static __device__ __forceinline__ float hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
@@ -36,6 +37,7 @@ struct ElBf16 {
 struct ElF16 {
   typedef f16x8 v8;
   static constexpr int code = HZ_F16;
+  static constexpr bool split = false;
   static __device__ __forceinline__ float one(uint16_t h) { return (float)*reinterpret_cast<const _Float16*>(&h); }
   static __device__ __forceinline__ float lo(uint32_t w) { return one((uint16_t)(w & 0xffffu)); }
   static __device__ __forceinline__ float hi(uint32_t w) { return one((uint16_t)(w >> 16)); }
@@ -46,6 +48,20 @@ struct ElF16 {
   }
   static __device__ __forceinline__ f32x4 mfma(v8 a, v8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+};
+
+// Every fp32 number as a PAIR of fp16 -- hi = fp16(x), lo = fp16(x - hi): 22 bits of mantissa together -- for weights and
+// activations alike, the product of two numbers as hi*hi + hi*lo + lo*hi (three MFMAs into the same fp32 accumulator; the
+// dropped lo*lo term is 2^-22 of the product).  The image keeps the lo halves in a second plane `lo_plane` columns behind
+// the hi halves, a wave's weight stream carries a tile's lo fragment behind its hi fragment, state rows come from and go
+// to memory as fp32.  This is the build whose outputs stay within 1e-3 of the reference's fp32 nets (include/hz_mlp.h).
+struct ElF16x2 : ElF16 {
+  static constexpr int code = HZ_F16X2;
+  static constexpr bool split = true;
+  static __device__ __forceinline__ void halves(float a, float b, uint32_t& hi2, uint32_t& lo2) {  // two numbers -> packed hi pair, lo pair
+    hi2 = pack(a, b);
+    lo2 = pack(a - lo(hi2), b - hi(hi2));
   }
 };
 
@@ -250,6 +266,10 @@ __device__ __forceinline__ void mlp_body(
   constexpr int NTHR = 64 * NW;
   constexpr bool PRESTAGED = STAGE != STAGE_GATHER;
   constexpr int MT = 16 * RT;
+  constexpr bool SPLIT = EL::split;   // ElF16x2: hi / lo planes, three MFMAs per fragment pair, fp32 state rows
+  constexpr int WP = SPLIT ? 2 : 1;   // fragments per tile and k-step (weights) / per row tile and k-step (activations)
+  static_assert(!SPLIT || (STAGE == STAGE_GATHER && NT != 2), "the fp16-pair build: stand-alone kernel, compiler-scheduled k-loop");
+  const int LP = H.lo_plane;          // SPLIT: columns between an element's hi half and its lo half
   // (opaque to the optimiser: inside a caller's loop -- the simulations of the persistent search kernel -- everything
   // derived from the thread index would otherwise be hoisted out of that loop, kept alive across the other phases and,
   // at 128 registers per lane, spilled to scratch: a memory round trip per use instead of a few ALU instructions)
@@ -296,8 +316,8 @@ __device__ __forceinline__ void mlp_body(
   constexpr int PF = RT == 1 ? RING - 1 : RING - 2;
   // NT == 2 (the 16 x 2 shape of the persistent search kernel): the k-loop is hand-scheduled assembly (below) and its
   // loads are invisible to the compiler; the other shapes keep the compiler-scheduled loop.
-  constexpr bool ASMK = NT == 2 && RING == 4;
-  v8 wf[ASMK ? 1 : RING][NT];                    // !ASMK: the ring as C++ values (ASMK: the fixed registers above)
+  constexpr bool ASMK = NT == 2 && RING == 4 && !SPLIT;
+  v8 wf[ASMK ? 1 : RING][NT * WP];                    // !ASMK: the ring as C++ values (ASMK: the fixed registers above)
   unsigned int voff = (unsigned int)lane * 16u;  // ASMK: byte offset of the next fragment this lane requests
   long long gstep = 0;                           // !ASMK: k-steps of this wave's stream consumed so far
 #define wp(k, t) (*reinterpret_cast<const v8*>(wbase + (long long)(k) * kss + ((t) * 1024u + (unsigned int)lane * 16u)))
@@ -315,12 +335,45 @@ __device__ __forceinline__ void mlp_body(
 #pragma unroll
     for (int d = 0; d < PF; ++d)
 #pragma unroll
-      for (int t = 0; t < NT; ++t) wf[d][t] = wp(d, t);
+      for (int t = 0; t < NT * WP; ++t) wf[d][t] = wp(d, t);
   }
   __builtin_amdgcn_sched_barrier(0);
 
   // stage the states into the image; rows past N read as zero
-  for (int base = 0; !PRESTAGED && base < n_stage; base += NTHR * SU) {
+  if constexpr (SPLIT) {  // fp32 rows (strides in fp32 elements) -> hi plane, lo plane
+    const float* src32 = reinterpret_cast<const float*>(state_src);
+    for (int base = 0; base < n_stage; base += NTHR * SU) {
+      float4 v[SU][2];
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        const int i = base + tid + NTHR * u;
+        const int r = i / chunks, c = i % chunks;
+        const int row = row0 + r;
+        v[u][0] = v[u][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < n_stage && row < n_rows) {
+          const long long plane = base == 0 ? plane0[u] : (plane_index ? (long long)plane_index[row] * plane_stride : 0);
+          const float4* p = reinterpret_cast<const float4*>(src32 + plane + (long long)row * state_row_stride + c * 8);
+          v[u][0] = p[0];
+          v[u][1] = p[1];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        const int i = base + tid + NTHR * u;
+        if (i < n_stage) {
+          uint4 h, l;
+          EL::halves(v[u][0].x, v[u][0].y, h.x, l.x);
+          EL::halves(v[u][0].z, v[u][0].w, h.y, l.y);
+          EL::halves(v[u][1].x, v[u][1].y, h.z, l.z);
+          EL::halves(v[u][1].z, v[u][1].w, h.w, l.w);
+          uint16_t* d = lds + (size_t)(i / chunks) * rs + H.state_off + (i % chunks) * 8;
+          *reinterpret_cast<uint4*>(d) = h;
+          *reinterpret_cast<uint4*>(d + LP) = l;
+        }
+      }
+    }
+  }
+  for (int base = 0; !SPLIT && !PRESTAGED && base < n_stage; base += NTHR * SU) {
     uint4 v[SU];
 #pragma unroll
     for (int u = 0; u < SU; ++u) {
@@ -468,9 +521,16 @@ __device__ __forceinline__ void mlp_body(
       const int chunks = H.hidden / 8;
       for (int i = tid; i < MT * chunks; i += NTHR) {
         const int r = i / chunks, c = i % chunks;
-        if (row0 + r < n_rows)
-          *reinterpret_cast<uint4*>(hidden_out + (size_t)(row0 + r) * H.hidden + c * 8) =
-              *reinterpret_cast<const uint4*>(lds + (size_t)r * rs + H.hidden_off + c * 8);
+        if (row0 + r >= n_rows) continue;
+        const uint16_t* s = lds + (size_t)r * rs + H.hidden_off + c * 8;
+        if constexpr (SPLIT) {  // hi + lo -> fp32 rows of `hidden` elements
+          const uint4 h = *reinterpret_cast<const uint4*>(s), l = *reinterpret_cast<const uint4*>(s + LP);
+          float4* d = reinterpret_cast<float4*>(reinterpret_cast<float*>(hidden_out) + (size_t)(row0 + r) * H.hidden + c * 8);
+          d[0] = make_float4(EL::lo(h.x) + EL::lo(l.x), EL::hi(h.x) + EL::hi(l.x), EL::lo(h.y) + EL::lo(l.y), EL::hi(h.y) + EL::hi(l.y));
+          d[1] = make_float4(EL::lo(h.z) + EL::lo(l.z), EL::hi(h.z) + EL::hi(l.z), EL::lo(h.w) + EL::lo(l.w), EL::hi(h.w) + EL::hi(l.w));
+        } else {
+          *reinterpret_cast<uint4*>(hidden_out + (size_t)(row0 + r) * H.hidden + c * 8) = *reinterpret_cast<const uint4*>(s);
+        }
       }
     }
     PROF_ADD(p_bar, p_j0);
@@ -659,24 +719,33 @@ __device__ __forceinline__ void mlp_body(
       // measured no faster, with more spills; its four MFMAs per k-step cover the LDS round trip)
       constexpr int BQD = RT == 1 ? 4 : 2;
       constexpr int BQPF = BQD - 1;
-      v8 bq[BQD][RT];
+      v8 bq[BQD][RT * WP];
 #pragma unroll
       for (int d = 0; d < BQPF; ++d)
         if (d < J.ks) {
 #pragma unroll
-          for (int rt = 0; rt < RT; ++rt) bq[d][rt] = *reinterpret_cast<const v8*>(src + (size_t)(16 * rt) * rs + 32 * d);
+          for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int p = 0; p < WP; ++p)
+              bq[d][WP * rt + p] = *reinterpret_cast<const v8*>(src + (size_t)(16 * rt) * rs + p * LP + 32 * d);
         }
       __builtin_amdgcn_sched_barrier(0);
       // one k-step: request the fragments PF steps ahead (weights) / BQPF steps ahead (activations; unconditional: the last
       // trips read past the K range, into fragments nobody uses), then this step's MFMAs
 #define HZ_MLP_STEP(S, U)                                                                                            \
       {                                                                                                              \
-        _Pragma("unroll") for (int t = 0; t < NT; ++t) wf[((U) + PF) % RING][t] = wp(gstep + (S) + PF, t);            \
-        _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                                            \
-            bq[((U) + BQPF) % BQD][rt] = *reinterpret_cast<const v8*>(src + (size_t)(16 * rt) * rs + 32 * ((S) + BQPF)); \
+        _Pragma("unroll") for (int t = 0; t < NT * WP; ++t) wf[((U) + PF) % RING][t] = wp(gstep + (S) + PF, t);       \
+        _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) _Pragma("unroll") for (int p = 0; p < WP; ++p)             \
+            bq[((U) + BQPF) % BQD][WP * rt + p] =                                                                    \
+                *reinterpret_cast<const v8*>(src + (size_t)(16 * rt) * rs + p * LP + 32 * ((S) + BQPF));             \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
-        _Pragma("unroll") for (int t = 0; t < NT; ++t) _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)             \
-            acc[t][rt] = EL::mfma(wf[(U) % RING][t], bq[(U) % BQD][rt], acc[t][rt]);                                  \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t) _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) {           \
+          acc[t][rt] = EL::mfma(wf[(U) % RING][WP * t], bq[(U) % BQD][WP * rt], acc[t][rt]);                          \
+          if constexpr (SPLIT) {  /* hi * lo, lo * hi */                                                             \
+            acc[t][rt] = EL::mfma(wf[(U) % RING][WP * t], bq[(U) % BQD][WP * rt + WP - 1], acc[t][rt]);               \
+            acc[t][rt] = EL::mfma(wf[(U) % RING][WP * t + WP - 1], bq[(U) % BQD][WP * rt], acc[t][rt]);               \
+          }                                                                                                          \
+        }                                                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
       }
       // all but the last 8 k-steps in a loop, the last 8 peeled: the fragment loads they issue sit between the epilogue
@@ -716,18 +785,21 @@ __device__ __forceinline__ void mlp_body(
     // epilogue: (+ residual) (+ ReLU) in fp32, round to EL, 4 consecutive columns per lane
     const bool relu = J.flags & HZ_MLP_RELU;
     // all residual fragments in one batch of LDS reads (one wait), not one round trip per column tile
-    uint2 rr[NT][RT];
+    uint2 rr[NT][RT], rl[NT][RT];  // (rl: the residual's lo halves, SPLIT)
     if (J.res_off >= 0) {
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-          rr[t][rt] = *reinterpret_cast<const uint2*>(lds + (size_t)(16 * rt + r0) * rs + J.res_off + 16 * t + c4);
+        for (int rt = 0; rt < RT; ++rt) {
+          const uint16_t* rp = lds + (size_t)(16 * rt + r0) * rs + J.res_off + 16 * t + c4;
+          rr[t][rt] = *reinterpret_cast<const uint2*>(rp);
+          rl[t][rt] = SPLIT ? *reinterpret_cast<const uint2*>(rp + LP) : make_uint2(0u, 0u);
+        }
     } else {
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) rr[t][rt] = make_uint2(0u, 0u);  // +0 in either format: adds nothing
+        for (int rt = 0; rt < RT; ++rt) rr[t][rt] = rl[t][rt] = make_uint2(0u, 0u);  // +0 in either format: adds nothing
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -738,12 +810,22 @@ __device__ __forceinline__ void mlp_body(
         float v[4] = {acc[t][rt][0], acc[t][rt][1], acc[t][rt][2], acc[t][rt][3]};
         v[0] += EL::lo(rr[t][rt].x); v[1] += EL::hi(rr[t][rt].x);
         v[2] += EL::lo(rr[t][rt].y); v[3] += EL::hi(rr[t][rt].y);
+        if constexpr (SPLIT) {
+          v[0] += EL::lo(rl[t][rt].x); v[1] += EL::hi(rl[t][rt].x);
+          v[2] += EL::lo(rl[t][rt].y); v[3] += EL::hi(rl[t][rt].y);
+        }
         if (relu) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = (v[r] > 0.0f || v[r] != v[r]) ? v[r] : 0.0f;
         }
         if (J.flags & HZ_MLP_F32_OUT) {  // the head's last layer: fp32 to the scalar transform / the tree (include/hz_mlp.h)
           *reinterpret_cast<float4*>(lds + rowbase + J.dst_off + 2 * col) = make_float4(v[0], v[1], v[2], v[3]);
+        } else if constexpr (SPLIT) {
+          uint2 o, ol;
+          EL::halves(v[0], v[1], o.x, ol.x);
+          EL::halves(v[2], v[3], o.y, ol.y);
+          *reinterpret_cast<uint2*>(lds + rowbase + J.dst_off + col) = o;
+          *reinterpret_cast<uint2*>(lds + rowbase + J.dst_off + LP + col) = ol;
         } else {
           uint2 o;
           o.x = EL::pack(v[0], v[1]);

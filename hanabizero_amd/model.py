@@ -223,7 +223,13 @@ class InferenceEngine:
 
     def __init__(self, net, support, dtype=torch.bfloat16, device="cuda", fused=None):
         """fused: run the search loop's recurrent inference as the single hand-written MFMA kernel of
-        include/hz_mlp.h (default: whenever the engine is bf16 on a GPU); False keeps the hipBLASLt GEMM chain."""
+        include/hz_mlp.h (default: whenever the engine is bf16 on a GPU); False keeps the hipBLASLt GEMM chain.
+        fused="fp16x2" (dtype float32): the engine inside the contract's 1e-3 of the reference's fp32 nets with a hand-written
+        kernel behind its search -- states, pool and the root inference's GEMMs stay fp32, the recurrent inference is the
+        MFMA kernel in its fp16-pair build (HZ_F16X2: every fp32 number as hi + lo halves, three MFMAs per product)."""
+        self.split = fused == "fp16x2"
+        assert not self.split or dtype == torch.float32, "fused='fp16x2' is the hand-written recurrent inference of an fp32 engine"
+        fused = True if self.split else fused
         self.dtype, self.device = dtype, torch.device(device)
         self.A, self.H = net.action_space_n, net.feature_size
         self.support = int(support)
@@ -233,6 +239,9 @@ class InferenceEngine:
         self._obs_pad = None  # (D, Dp, stack) once pad_observations() has been asked for
         self._dev, self._seq = {}, 0  # device tensors by creation order within a load()
         self._fused_shapes, self.fused_tail = {}, None
+        # (the stand-alone kernel's shape; the fp16-pair build streams twice the weights and hides their latency better with eight
+        # wavefronts: 77 us against 84 us per 4096-row inference of the Hanabi-Full nets)
+        self._fused_default = (8, 4) if self.split else (4, 4)
         self.version = 0
         self.load(net)
 
@@ -309,14 +318,15 @@ class InferenceEngine:
         self._net = net
         if self.use_fused:
             if not self._fused_shapes:
-                self._fused_shapes[(4, 4)] = FusedRecurrent(net, self)
-                self.fused_tail = FusedInitialTail(net, self, 16, 2) if self.full else None  # (the shape that has the arrival counters)
+                self._fused_shapes[self._fused_default] = FusedRecurrent(net, self, *self._fused_default)
+                # (the root inference's tail in the 16 x 2 shape, the one that has the arrival counters; fp32 engine: GEMMs)
+                self.fused_tail = FusedInitialTail(net, self, 16, 2) if self.full and not self.split else None
             else:  # same job tables, new numbers: into the tensors the kernels (and captured graphs) already point at
                 for (waves, tiles), chain in self._fused_shapes.items():
                     chain.reload(FusedRecurrent(net, self, waves, tiles, values_only=True))
                 if self.fused_tail is not None:
                     self.fused_tail.reload(FusedInitialTail(net, self, 16, 2, values_only=True))
-            self.fused = self._fused_shapes[(4, 4)]
+            self.fused = self._fused_shapes[self._fused_default]
         self.version += 1
 
     def pad_observations(self, D, stack, multiple=8):
@@ -338,8 +348,8 @@ class InferenceEngine:
     def fused_shape(self, waves, tiles):
         """The fused recurrent inference laid out for another workgroup shape (16 x 2: the persistent search kernel);
         built on first use, refreshed in place by every later load()."""
-        if not self.use_fused:
-            return None
+        if not self.use_fused or (self.split and (waves, tiles) == (16, 2)):
+            return None   # (no fp16-pair build of the persistent search kernel: MCTS.run_multi launches per phase)
         if (waves, tiles) not in self._fused_shapes:
             self._fused_shapes[(waves, tiles)] = FusedRecurrent(self._net, self, waves, tiles)
         return self._fused_shapes[(waves, tiles)]
@@ -525,13 +535,28 @@ class _FusedChain:
         values_only (implies host_only): only the NUMBERS -- weight streams, biases, action table -- wherever the module's
         parameters live (on the GPU for a learner's module: nothing crosses PCIe); the job table and its synchronisation plan
         (mlp_sync: two thirds of a full build's host time) depend on the layer shapes alone and are the built chain's."""
-        assert engine.dtype in (torch.bfloat16, torch.float16), "the fused kernel computes in bf16 or fp16 (fp32 accumulate)"
+        # split: the fp16-pair build (include/hz_mlp.h, HZ_F16X2) of an fp32 engine -- every number as hi + lo halves
+        self.split = bool(getattr(engine, "split", False))
+        assert self.split or engine.dtype in (torch.bfloat16, torch.float16), "the fused kernel computes in bf16 or fp16 (fp32 accumulate)"
+        assert not self.split or (engine.dtype == torch.float32 and (waves, tiles) in ((4, 4), (8, 4))), \
+            "the fp16-pair build: fp32 engine, stand-alone kernel shapes"
         assert (waves, tiles) in ((4, 4), (8, 4), (16, 2))
+        self.wdtype = torch.float16 if self.split else engine.dtype   # element format of the weight streams
         self.engine, self.device, self.waves, self.tiles = engine, engine.device, waves, tiles
         self.host_only, self.values_only = host_only or values_only, values_only
         self.cw = 16 * tiles   # output columns of one job
         self._jobs = []        # [pass] -> dict(entries [wave] -> dict or None, barrier, store_hidden)
         self.blockwise = (waves, tiles) == (16, 2) and os.environ.get("HANABIZERO_MLP_BLOCKWISE", "1") != "0"
+
+    def _fragments(self, w, ks):
+        """A job's weight block as the fragments of its wave's stream (fp32 values that the stream's format holds exactly)."""
+        x = _pack_fragments(w, ks, self.tiles)
+        if not self.split:
+            return x
+        x = x.view(ks, self.tiles, 512)
+        hi = x.to(torch.float16).float()
+        lo = (x - hi).to(torch.float16).float()
+        return torch.stack((hi, lo), 2).reshape(-1)   # [k-step][tile][hi | lo][64 lanes x 8]
 
     def add_dense(self, w, b, K, src_off, dst_off, relu, res_off=None, barrier=True, store_hidden=False, act_w=None, f32=False):
         """out[:, dst_off:dst_off+nout] = act(in[:, src_off:src_off+K] @ w^T + b ...), nout split into cw-column
@@ -615,7 +640,10 @@ class _FusedChain:
         streams = [[] for _ in range(waves)]
         bias_chunks = []       # cw-float chunks
         act_rows = []          # (bias chunk index, [A, cw] block)
-        rs = width + ((8 - width) % 128)
+        assert width % 8 == 0
+        lo_plane = width if self.split else 0            # (split: [hi image | lo image] per row)
+        rs = (2 * width if self.split else width)
+        rs += (8 - rs) % 128
         # flatten: job table, per-wave weight streams, biases, action table.  A pass with fewer jobs than waves goes to
         # the waves that have streamed the least so far (the kernel is bound by the CU's weight stream: every wave
         # should carry the same share of it and none should idle through whole layers)
@@ -680,7 +708,7 @@ class _FusedChain:
                                         producer=producer))
                     continue
                 assert e["ks"] % 8 == 0, "K must be a multiple of 256 (8 k-steps)"
-                streams[wave].append(_pack_fragments(e["w"], e["ks"], tiles))
+                streams[wave].append(self._fragments(e["w"], e["ks"]))
                 bias_off = cw * len(bias_chunks)
                 bc = torch.zeros(cw, device=e["b"].device)
                 bc[:e["b"].shape[0]] = e["b"]
@@ -702,8 +730,9 @@ class _FusedChain:
         hdr = MlpHeader(n_jobs=len(jobs), row_stride=rs, hidden=hidden, state_off=state_off, hidden_off=hidden_off,
                         off_reward=off_r, off_value=off_v, off_policy=off_p, support_size=V, support_min=-engine.support,
                         num_actions=A, action_table_stride=biases.numel(), in_width=in_width,
-                        dtype={torch.bfloat16: 1, torch.float16: 2}[engine.dtype],  # HZ_BF16 / HZ_F16 (include/hz_tree.h)
-                        num_waves=waves, tiles_per_wave=tiles, kstep_stride=waves * tiles * 512,
+                        dtype=3 if self.split else {torch.bfloat16: 1, torch.float16: 2}[engine.dtype],  # HZ_F16X2 / HZ_BF16 / HZ_F16 (include/hz_tree.h)
+                        lo_plane=lo_plane,
+                        num_waves=waves, tiles_per_wave=tiles, kstep_stride=waves * frag,
                         logit_split=256 if logit_split is None else logit_split, off_reward2=off_r2, off_value2=off_v2)
         assert hdr.logit_split % 32 == 0 and off_r % 8 == 0 and off_v % 8 == 0 and off_p % 8 == 0 and off_r2 % 8 == 0 and off_v2 % 8 == 0
         for wave in range(waves):
@@ -712,7 +741,7 @@ class _FusedChain:
         self.n_jobs = len(jobs)
         buf = (MlpJob * len(table))(*table)
         self._host = dict(jobs=torch.frombuffer(bytearray(bytes(buf)), dtype=torch.uint8),
-                          weights=W.reshape(-1).to(engine.dtype).contiguous(),  # (round-to-nearest-even from the fp32 fold)
+                          weights=W.reshape(-1).to(self.wdtype).contiguous(),  # (round-to-nearest-even from the fp32 fold)
                           biases=biases.float().contiguous(), act_table=act_table.float().contiguous())
         if not self.host_only:
             for k, v in self._host.items():
@@ -734,7 +763,7 @@ class _FusedChain:
             act_table[:A, off:off + blk.shape[0]] += blk.t()
         # weight streams, interleaved k-step by k-step: [k-step][wave][tiles * 512]; at any moment the waves of a
         # workgroup (all near the same k-step) read one contiguous region
-        frag = tiles * 512
+        frag = tiles * 512 * (2 if self.split else 1)
         steps = [sum(x.numel() for x in st) // frag for st in streams]
         P = max(steps) + 8                                  # 8 k-steps of zeros behind each stream (ring overrun)
         W = torch.zeros(P, waves, frag, device=biases.device)
@@ -752,7 +781,7 @@ class _FusedChain:
             for wave, e in enumerate(row):
                 if e is None:
                     continue
-                streams[wave].append(_pack_fragments(e["w"], e["ks"], tiles))
+                streams[wave].append(self._fragments(e["w"], e["ks"]))
                 bc = torch.zeros(cw, device=e["b"].device)
                 bc[:e["b"].shape[0]] = e["b"]
                 if e["act"] is not None:
@@ -760,7 +789,7 @@ class _FusedChain:
                 bias_chunks.append(bc)
         biases, act_table, W, _ = self._assemble(bias_chunks, act_rows, streams, A)
         self.n_jobs = len(rows)
-        self._host = dict(weights=W.reshape(-1).to(self.engine.dtype), biases=biases.float(), act_table=act_table.float())
+        self._host = dict(weights=W.reshape(-1).to(self.wdtype), biases=biases.float(), act_table=act_table.float())
         self._jobs = None
 
     def reload(self, other):

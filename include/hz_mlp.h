@@ -20,6 +20,12 @@
  * between layers, fp32 accumulation and epilogue; the last layer of every head (value / reward / policy logits) stays fp32
  * through the scalar transform (HZ_MLP_F32_OUT).  Measured against the reference nets' fp32 outputs AND against the
  * reference run under fp16 autocast (tests/golden/nets_*.npz, nets_*_autocast.npz; tests/test_model.py).
+ * HZ_F16X2 (4- and 8-wave shapes, hz_mlp_recurrent only) is the build inside the contract's 1e-3 of the reference's fp32 nets:
+ * every fp32 weight and activation as a pair of fp16 (hi = fp16(x), lo = fp16(x - hi)), every product as hi*hi + hi*lo + lo*hi
+ * on the same v_mfma_f32_16x16x32_f16 into the same fp32 accumulators (twice the weight stream, three times the MFMAs,
+ * which the matrix cores have to spare).  Its state rows, hidden_out rows and strides are fp32; a wave's weight stream holds a
+ * tile's lo fragment behind its hi fragment (kstep_stride counts both); the image keeps the lo halves `lo_plane` columns
+ * behind the hi halves.
  * Conventions as include/hz_tree.h.
  */
 #ifndef HZ_MLP_H
@@ -95,15 +101,15 @@ typedef struct {
   int32_t in_width;              /* elements of an input row staged at state_off (multiple of 8; = hidden for the
                                     recurrent inference, the width of the last big representation layer for the tail
                                     of the initial inference) */
-  int32_t dtype;                 /* element format of weights, activations and state rows: HZ_BF16 or HZ_F16
-                                    (include/hz_tree.h); accumulation and epilogues are fp32 in both */
+  int32_t dtype;                 /* element format of weights, activations and state rows: HZ_BF16, HZ_F16 or HZ_F16X2
+                                    (include/hz_tree.h); accumulation and epilogues are fp32 in all */
   int32_t num_waves;             /* 4 (stand-alone kernel) or 16 (inside hz_search_run) */
   int32_t tiles_per_wave;        /* 16-column MFMA tiles per job: 4 with 4 waves, 2 with 16 waves */
   int32_t logit_split;           /* ... value / reward logits k >= logit_split (a multiple of 32; >= support_size: none), which sit
                                     2 (k - logit_split) columns behind off_value2 / off_reward2: a head's fp32 logits may
                                     occupy two dead regions of the image instead of one contiguous range */
   int32_t off_reward2, off_value2;
-  int32_t reserved1;
+  int32_t lo_plane;              /* HZ_F16X2 only (0 otherwise): image columns between the hi half of an element and its lo half */
   int64_t kstep_stride;          /* elements between consecutive k-steps of one wave's stream: 512 * tiles_per_wave when
                                     each stream is contiguous, 512 * tiles_per_wave * num_waves when the streams are
                                     interleaved k-step by k-step (all waves of a workgroup then read one contiguous

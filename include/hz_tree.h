@@ -26,7 +26,7 @@ extern "C" {
 typedef struct hz_tree hz_tree_t;
 
 /* dtype of a hidden-state pool / net-input buffer element */
-enum { HZ_F32 = 0, HZ_BF16 = 1, HZ_F16 = 2 };
+enum { HZ_F32 = 0, HZ_BF16 = 1, HZ_F16 = 2, HZ_F16X2 = 3 /* include/hz_mlp.h only: fp32 numbers as fp16 pairs */ };
 
 #define HZ_MAX_ACTIONS 64      /* one lane per child; Hanabi needs at most 48 (5 players) */
 #define HZ_MAX_SIMULATIONS 4096

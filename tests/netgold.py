@@ -28,7 +28,7 @@ def fill_state_dict(state_dict):
     return {k: make_weight(k, tuple(v.shape)) for k, v in state_dict.items()}
 
 
-def golden_net_error(game, dtype, device="cuda"):
+def golden_net_error(game, dtype, device="cuda", fused=None):
     """Error of the product's inference path in `dtype` -- InferenceEngine.initial (the fused tail of the root inference
     where it exists) and the fused MFMA recurrent kernel the search launches -- against the reference nets' own fp32
     outputs (tests/golden/nets_<game>.npz, written by tools/gen_golden.py from config/hanabi_control/model.py).
@@ -44,7 +44,7 @@ def golden_net_error(game, dtype, device="cuda"):
     net = (MuZeroNet if game == "Hanabi-Small" else MuZeroNetFull)(D * stack, A, 2 * sup + 1, 2 * sup + 1, inv, inv)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in fill_state_dict(net.state_dict()).items()})
     net.eval()
-    eng = InferenceEngine(net, sup, dtype=dtype, device=device)
+    eng = InferenceEngine(net, sup, dtype=dtype, device=device, fused=fused)
     obs = torch.from_numpy(fx["obs"]).to(device)
     hid = torch.from_numpy(fx["init_hidden"]).to(device).to(dtype)
     act = torch.from_numpy(fx["action"]).reshape(-1).to(device)

@@ -14,6 +14,8 @@ def _engine(game, sims, stack, dtype=torch.float32):
     net = cfg.get_uniform_network()
     net.load_state_dict({k: torch.from_numpy(v) for k, v in fill_state_dict(net.state_dict()).items()})
     net.eval()
+    if dtype == "fp16x2":  # the fp32 engine whose recurrent inference is the MFMA kernel's fp16-pair build (include/hz_mlp.h)
+        return cfg, InferenceEngine(net, cfg.value_support.max, dtype=torch.float32, device="cuda", fused="fp16x2")
     return cfg, InferenceEngine(net, cfg.value_support.max, dtype=dtype, device="cuda")
 
 
@@ -24,8 +26,9 @@ def _oracle_search(cfg, eng, tree, hidden0, sims):
     oracle_search(cfg, eng, tree, hidden0, sims)
 
 
-# fp32: the launch-per-phase search; fp16: the benched engine -- root inference through the fused tail, ONE persistent search kernel
-ENGINES = [("Hanabi-Small", torch.float32), ("Hanabi-Small", torch.float16), ("Hanabi-Full", torch.float16)]
+# fp32: the launch-per-phase search; fp16: the benched engine -- root inference through the fused tail, ONE persistent search kernel;
+# fp16x2: launch-per-phase search around the hand-written recurrent inference that stays within 1e-3 of the reference's fp32 nets
+ENGINES = [("Hanabi-Small", torch.float32), ("Hanabi-Small", torch.float16), ("Hanabi-Full", torch.float16), ("Hanabi-Full", "fp16x2")]
 
 
 @pytest.mark.parametrize("game,dtype", ENGINES)
@@ -34,7 +37,7 @@ def test_evaluation_loop_matches_oracle_replay(game, dtype):
     from hanabizero_amd.evaluate import test as run_test
     from oracle.cport import OracleEnv, OracleTree
     cfg, eng = _engine(game, 10 if game == "Hanabi-Small" else 16, 2 if game == "Hanabi-Small" else 4, dtype)
-    assert (eng.fused is not None) == (dtype != torch.float32)
+    assert (eng.fused is not None) == (dtype is not torch.float32)
     E, A, S, stack = 12 if game == "Hanabi-Small" else 21, cfg.action_space_size, cfg.num_simulations, cfg.stacked_observations
     scores, steps = run_test(cfg, eng, test_episodes=E, tie_seed=5)
     env = OracleEnv(game, np.arange(E))

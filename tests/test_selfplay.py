@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 from tests.restate import ref_select_action  # noqa: E402  (checked against the reference: tests/test_reference_callers.py)
 
 
-def make(game, N, sims, stack, dtype, use_graph, seed=3, peaked=False, fused_tail=True, max_moves=None):
+def make(game, N, sims, stack, dtype, use_graph, seed=3, peaked=False, fused_tail=True, max_moves=None, fused=None):
     from hanabizero_amd.config import make_config
     from hanabizero_amd.model import InferenceEngine
     from hanabizero_amd.selfplay import SelfPlayActor
@@ -35,7 +35,7 @@ def make(game, N, sims, stack, dtype, use_graph, seed=3, peaked=False, fused_tai
             net._prediction_actor[-1].weight.mul_(40.0)
             net._prediction_actor[-1].bias.mul_(40.0)
     net.eval()
-    eng = InferenceEngine(net, cfg.value_support.max, dtype=dtype, device="cuda")
+    eng = InferenceEngine(net, cfg.value_support.max, dtype=dtype, device="cuda", fused=fused)
     return cfg, eng, SelfPlayActor(cfg, eng, N, seed=seed, use_graph=use_graph, fused_tail=fused_tail)
 
 
