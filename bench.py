@@ -770,9 +770,10 @@ def main():
             rows_wg = 16 if (abs(actor.mcts.rows_per_workgroup) == 16 or (actor.mcts.rows_per_workgroup == 0 and (Nk + 15) // 16 <= torch.cuda.get_device_properties(device).multi_processor_count)) else 32
             wgs = (Nk + rows_wg - 1) // rows_wg
             l2_bytes = wgs * engine.fused.weight_bytes_per_wg * (S - 1) + 2 * Nk * H * e * (S - 1)
-            out["roofline"] = {"bound": "mfma", "kernel": "k_search", "achieved": fl / t / 1e12, "peak": MFMA_PEAK_TFLOPS,
+            pairs = run.fused == "fp16x2"  # (the fp16-pair build: the same algorithmic flops through three MFMAs per product, twice the stream)
+            out["roofline"] = {"bound": "mfma", "kernel": "k_search_pairs" if pairs else "k_search", "achieved": fl / t / 1e12, "peak": MFMA_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": fl / t / 1e12 / MFMA_PEAK_TFLOPS,
-                               "traffic": traffic_all.get("k_search"), "traffic_source": traffic_src,
+                               "traffic": None if pairs else traffic_all.get("k_search"), "traffic_source": None if pairs else traffic_src,
                                "avg_launch_us": t * 1e6, "min_launch_us": search["min_s"] * 1e6, "launches_timed": search["launches"], "empty_event_pair_us": search["empty_event_pair_us"], "eager_step_us": search["eager_step_us"],
                                "poll_giveups": _poll_giveups(),  # waits on arrival counters that timed out in this process (must be 0)
                                "flop_per_launch": fl, "simulations_per_launch": S - 1, "trees_per_workgroup": rows_wg, "workgroups": wgs,

@@ -268,7 +268,7 @@ __device__ __forceinline__ void mlp_body(
   constexpr int MT = 16 * RT;
   constexpr bool SPLIT = EL::split;   // ElF16x2: hi / lo planes, three MFMAs per fragment pair, fp32 state rows
   constexpr int WP = SPLIT ? 2 : 1;   // fragments per tile and k-step (weights) / per row tile and k-step (activations)
-  static_assert(!SPLIT || (STAGE == STAGE_GATHER && NT != 2), "the fp16-pair build: stand-alone kernel, compiler-scheduled k-loop");
+  static_assert(!SPLIT || STAGE != STAGE_REGS_HALF, "the fp16-pair build: stand-alone kernel or one tree per wave; compiler-scheduled k-loop");
   const int LP = H.lo_plane;          // SPLIT: columns between an element's hi half and its lo half
   // (opaque to the optimiser: inside a caller's loop -- the simulations of the persistent search kernel -- everything
   // derived from the thread index would otherwise be hoisted out of that loop, kept alive across the other phases and,
@@ -312,8 +312,10 @@ __device__ __forceinline__ void mlp_body(
   // Prefetch distance in k-steps.  16-row shapes: RING - 1 (2 costs 1.7 % moves/s at 4096 envs).  32-row shape: 2 -- one
   // ring slot stays spare, so the refill of a slot does not have to wait for the four MFMAs that have just read it
   // (3: -2.1 % moves/s at 8192 envs, 1: -1.6 %; A/B on one box, tools/ab_bench.sh).
-  constexpr int RING = 4;
-  constexpr int PF = RT == 1 ? RING - 1 : RING - 2;
+  // (the fp16-pair build inside the persistent search kernel -- two fragments per tile and step, 128 registers per lane, sixteen
+  // wavefronts to hide latency with: a ring of two)
+  constexpr int RING = (SPLIT && NT == 2) ? 2 : 4;
+  constexpr int PF = (SPLIT && NT == 2) ? 1 : (RT == 1 ? RING - 1 : RING - 2);
   // NT == 2 (the 16 x 2 shape of the persistent search kernel): the k-loop is hand-scheduled assembly (below) and its
   // loads are invisible to the compiler; the other shapes keep the compiler-scheduled loop.
   constexpr bool ASMK = NT == 2 && RING == 4 && !SPLIT;
@@ -407,9 +409,21 @@ __device__ __forceinline__ void mlp_body(
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
-        if (lane + 64 * u < chunks)
+      for (int u = 0; u < 2; ++u) {
+        if constexpr (SPLIT) {  // the wave's row in fp32: lane l holds elements [4 (l + 64 u), + 4)
+          if ((lane + 64 * u) * 4 < H.in_width) {
+            const uint4 f = row_frag[rt].v[u];
+            uint2 h, l;
+            EL::halves(__uint_as_float(f.x), __uint_as_float(f.y), h.x, l.x);
+            EL::halves(__uint_as_float(f.z), __uint_as_float(f.w), h.y, l.y);
+            uint16_t* d = lds + (size_t)(16 * rt + wave) * rs + H.state_off + (lane + 64 * u) * 4;
+            *reinterpret_cast<uint2*>(d) = h;
+            *reinterpret_cast<uint2*>(d + LP) = l;
+          }
+        } else if (lane + 64 * u < chunks) {
           *reinterpret_cast<uint4*>(lds + (size_t)(16 * rt + wave) * rs + H.state_off + (lane + 64 * u) * 8) = row_frag[rt].v[u];
+        }
+      }
   }
   if (STAGE == STAGE_REGS_HALF) {  // the first 8 RT waves hold two rows each: wave w row w in lanes 0-31 and row 8 RT + w in
     static_assert(STAGE != STAGE_REGS_HALF || NW == 16, "two rows per tree-owning wave");  // lanes 32-63; lane l of a half its chunks l, 32 + l
@@ -717,7 +731,7 @@ __device__ __forceinline__ void mlp_body(
       // ---- the compiler-scheduled k-loop of the other shapes
       // activation fragments, BQPF k-steps ahead of their use (RT = 2 has the registers for one step ahead only -- two
       // measured no faster, with more spills; its four MFMAs per k-step cover the LDS round trip)
-      constexpr int BQD = RT == 1 ? 4 : 2;
+      constexpr int BQD = (SPLIT && NT == 2) ? 2 : (RT == 1 ? 4 : 2);
       constexpr int BQPF = BQD - 1;
       v8 bq[BQD][RT * WP];
 #pragma unroll

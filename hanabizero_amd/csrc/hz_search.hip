@@ -61,15 +61,18 @@ __device__ __forceinline__ TraverseOut search_traverse_out(const hz_mlp_header_t
   return to;
 }
 
+template <class EL>
 __device__ __forceinline__ RowFrag search_request_row(const TreeView& tv, const hz_mlp_header_t& H, const SearchArgs& a,
                                                       int entry, int tree, int lane) {
   RowFrag f;
-  const uint4* src = reinterpret_cast<const uint4*>(a.pool + ((size_t)entry * tv.N + tree) * (size_t)H.hidden);
+  constexpr int EB = EL::split ? 4 : 2;   // bytes per pool element (the fp16-pair build keeps its pool in fp32)
+  const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.pool) + ((size_t)entry * tv.N + tree) * (size_t)H.hidden * EB);
 #pragma unroll
-  for (int u = 0; u < 2; ++u) f.v[u] = (lane + 64 * u) * 8 < H.hidden ? src[lane + 64 * u] : make_uint4(0u, 0u, 0u, 0u);
+  for (int u = 0; u < 2; ++u) f.v[u] = (lane + 64 * u) * (16 / EB) < H.hidden ? src[lane + 64 * u] : make_uint4(0u, 0u, 0u, 0u);
   return f;
 }
 
+template <class EL>
 __device__ __forceinline__ RowFrag search_first_descent(const TreeView& tv, const hz_mlp_header_t& H, const SearchArgs& a,
                                                         const SearchLds& L, int row0, int tree, int lane, TreeLocal& tl,
                                                         float4& root_row) {
@@ -81,7 +84,7 @@ __device__ __forceinline__ RowFrag search_first_descent(const TreeView& tv, cons
   root_row = make_float4(0.f, 0.f, 0.f, 0.f);
   if (lane < tv.A) root_row = tv.rec[(size_t)tree * tv.S * tv.A + lane];  // from now on kept in registers, patched per backup
   traverse_body<true>(tv, tree, lane, 0, tv.mm_min[tree], tv.mm_max[tree], tl.root_visit, to, true, root_row, &entry, &tl);
-  return search_request_row(tv, H, a, entry, tree, lane);
+  return search_request_row<EL>(tv, H, a, entry, tree, lane);
 }
 
 template <class EL, bool REPLAY>
@@ -126,7 +129,7 @@ __device__ __forceinline__ RowFrag search_backup_descent(const TreeView& tv, con
     tl.publish = sim + 2 == a.sims;  // the last descent
     traverse_body<true, REPLAY>(tv, tree, lane, sim + 1, mn, mx, rv, to, true, root_row, &entry, &tl);
     TP(13);
-    f = search_request_row(tv, H, a, entry, tree, lane);
+    f = search_request_row<EL>(tv, H, a, entry, tree, lane);
   }
   return f;
 }
@@ -134,9 +137,9 @@ __device__ __forceinline__ RowFrag search_backup_descent(const TreeView& tv, con
 template <class EL, int RT>
 __device__ __forceinline__ void search_inference(const hz_mlp_header_t& H, const SearchArgs& a, const SearchLds& L, int sim,
                                                  int n_rows, int row0, const RowFrag* rows, const int* jv) {
+  uint16_t* hidden_out = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(a.pool) + (size_t)(sim + 1) * a.plane_stride * (EL::split ? 4 : 2));
   mlp_body<EL, RT, 16, 2, STAGE_REGS, false, RT == 1>(H, a.jobs, a.wstream, a.bias, a.act_tab, a.pool, a.row_stride, nullptr, a.plane_stride,
-                                 L.act_s - row0, a.pool + (size_t)(sim + 1) * a.plane_stride, nullptr, nullptr, nullptr,
-                                 n_rows, L.image, row0, rows, jv);
+                                 L.act_s - row0, hidden_out, nullptr, nullptr, nullptr, n_rows, L.image, row0, rows, jv);
 }
 
 // Diagnostic build only (-DHZ_SEARCH_PROFILE, tools/search_profile.py): per-phase s_memtime sums of workgroup 100.
@@ -199,7 +202,7 @@ __device__ __forceinline__ void search_kernel_body(const TreeView& tv, const hz_
   unsigned long long t0 = SP_NOW();
 #pragma unroll
   for (int s = 0; s < RT; ++s)
-    if (mine[s]) rows[s] = search_first_descent(tv, H, a, L, row0, row0 + 16 * s + wave, lane, tl[s], root_row[s]);
+    if (mine[s]) rows[s] = search_first_descent<EL>(tv, H, a, L, row0, row0 + 16 * s + wave, lane, tl[s], root_row[s]);
   // this wave's job entries of the inference: the same for every simulation, loaded once (two registers hold 16 jobs; the in-turn
   // 32-row kernel has none to spare and reloads them per inference)
   int jvc[4] = {0, 0, 0, 0};
@@ -243,6 +246,12 @@ __device__ __forceinline__ void search_kernel_body(const TreeView& tv, const hz_
 template <class EL, bool RP>
 __global__ __launch_bounds__(1024, 1) __attribute__((amdgpu_num_vgpr(HZ_ASMK_VGPRS))) void k_search(TreeView tv, hz_mlp_header_t H, SearchArgs a) {
   search_kernel_body<EL, 1, RP>(tv, H, a);
+}
+// the fp16-pair build (include/hz_mlp.h, HZ_F16X2; fp32 pool): one tree per wave, the inference's k-loop compiler-scheduled -- no
+// weight ring in fixed registers, so no register budget of its own
+template <bool RP>
+__global__ __launch_bounds__(1024, 1) void k_search_pairs(TreeView tv, hz_mlp_header_t H, SearchArgs a) {
+  search_kernel_body<ElF16x2, 1, RP>(tv, H, a);
 }
 // the two trees of a wave one after the other: its register pressure peaks above the others', and amdgpu_num_vgpr is a budget the
 // allocator was seen to overdraw by four registers -- into the ring (tools/scan_ring_registers.py) -- so this one gets a lower one.
@@ -425,7 +434,11 @@ extern "C" int hz_search_run(hz_tree_t* t, int num_simulations, const hz_mlp_hea
                  rows_per_workgroup == -16,
              "hz_search_run: rows_per_workgroup %d (0 = auto, 16, 32; -16: 16 with two trees side by side on 8 waves; -32: 32 with the two trees of a wave one after the other)",
              rows_per_workgroup);
-  HZ_REQUIRE(H->dtype == HZ_BF16 || H->dtype == HZ_F16, "hz_search_run: header dtype must be HZ_BF16 or HZ_F16 (got %d)", H->dtype);
+  HZ_REQUIRE(H->dtype == HZ_BF16 || H->dtype == HZ_F16 || H->dtype == HZ_F16X2,
+             "hz_search_run: header dtype must be HZ_BF16, HZ_F16 or HZ_F16X2 (got %d)", H->dtype);
+  HZ_REQUIRE(H->dtype != HZ_F16X2 || (H->lo_plane > 0 && H->lo_plane % 8 == 0 && 2 * H->lo_plane <= H->row_stride &&
+                                      (rows_per_workgroup == 0 || rows_per_workgroup == 16)),
+             "hz_search_run: the fp16-pair build keeps 16 trees per workgroup (one per wave); its image's lo plane lies lo_plane columns behind the hi plane");
   HZ_REQUIRE(H->num_waves == 16 && H->tiles_per_wave == 2, "hz_search_run: the MLP must be laid out for 16 waves x 2 tiles");
   HZ_REQUIRE(H->num_actions == t->A, "hz_search_run: the MLP has %d actions, the tree %d", H->num_actions, t->A);
   HZ_REQUIRE(H->n_jobs > 0 && H->n_jobs <= 32 && H->support_size > 0 && H->support_size <= 256 &&
@@ -448,7 +461,7 @@ extern "C" int hz_search_run(hz_tree_t* t, int num_simulations, const hz_mlp_hea
   HZ_REQUIRE(t->device >= 0 && t->device < 64, "hz_search_run: device ordinal %d outside [0, 64)", t->device);
   SearchDevice& dev = g_search_dev[t->device];
   if (dev.n_cu == 0) HZ_HIP(hipDeviceGetAttribute(&dev.n_cu, hipDeviceAttributeMultiprocessorCount, t->device));
-  if (rows_wg == 0) rows_wg = (t->N + 15) / 16 > dev.n_cu ? 32 : 16;
+  if (rows_wg == 0) rows_wg = ((t->N + 15) / 16 > dev.n_cu && H->dtype != HZ_F16X2) ? 32 : 16;
   auto lds_for = [&](int mt) {
     return (size_t)mt * H->row_stride * sizeof(uint16_t) + (size_t)mt * (t->S + 1) * (16 + 4) + (size_t)mt * t->S * sizeof(float) +
            (size_t)(mt + 2) * sizeof(float) + 32 * 8 + 128 * sizeof(float) + 128;  // (+128: slack behind the last array)
@@ -500,7 +513,10 @@ extern "C" int hz_search_run(hz_tree_t* t, int num_simulations, const hz_mlp_hea
   int cur = -1;
   HZ_HIP(hipGetDevice(&cur));
   HZ_REQUIRE(cur == t->device, "hz_search_run: the calling thread's current device is %d, the tree lives on %d", cur, t->device);
-  if (H->dtype == HZ_F16) HZ_SEARCH_LAUNCH_EL(8, ElF16);
+  if (H->dtype == HZ_F16X2) {
+    if (use_nextact) HZ_SEARCH_LAUNCH(7, (k_search_pairs<true>), (t->N + 15) / 16);
+    else HZ_SEARCH_LAUNCH(6, (k_search_pairs<false>), (t->N + 15) / 16);
+  } else if (H->dtype == HZ_F16) HZ_SEARCH_LAUNCH_EL(8, ElF16);
   else HZ_SEARCH_LAUNCH_EL(0, ElBf16);
 #undef HZ_SEARCH_LAUNCH_EL
 #undef HZ_SEARCH_LAUNCH

@@ -348,8 +348,8 @@ class InferenceEngine:
     def fused_shape(self, waves, tiles):
         """The fused recurrent inference laid out for another workgroup shape (16 x 2: the persistent search kernel);
         built on first use, refreshed in place by every later load()."""
-        if not self.use_fused or (self.split and (waves, tiles) == (16, 2)):
-            return None   # (no fp16-pair build of the persistent search kernel: MCTS.run_multi launches per phase)
+        if not self.use_fused:
+            return None
         if (waves, tiles) not in self._fused_shapes:
             self._fused_shapes[(waves, tiles)] = FusedRecurrent(self._net, self, waves, tiles)
         return self._fused_shapes[(waves, tiles)]
@@ -538,15 +538,15 @@ class _FusedChain:
         # split: the fp16-pair build (include/hz_mlp.h, HZ_F16X2) of an fp32 engine -- every number as hi + lo halves
         self.split = bool(getattr(engine, "split", False))
         assert self.split or engine.dtype in (torch.bfloat16, torch.float16), "the fused kernel computes in bf16 or fp16 (fp32 accumulate)"
-        assert not self.split or (engine.dtype == torch.float32 and (waves, tiles) in ((4, 4), (8, 4))), \
-            "the fp16-pair build: fp32 engine, stand-alone kernel shapes"
+        assert not self.split or engine.dtype == torch.float32, "the fp16-pair build belongs to an fp32 engine"
         assert (waves, tiles) in ((4, 4), (8, 4), (16, 2))
         self.wdtype = torch.float16 if self.split else engine.dtype   # element format of the weight streams
         self.engine, self.device, self.waves, self.tiles = engine, engine.device, waves, tiles
         self.host_only, self.values_only = host_only or values_only, values_only
         self.cw = 16 * tiles   # output columns of one job
         self._jobs = []        # [pass] -> dict(entries [wave] -> dict or None, barrier, store_hidden)
-        self.blockwise = (waves, tiles) == (16, 2) and os.environ.get("HANABIZERO_MLP_BLOCKWISE", "1") != "0"
+        # (arrival counters instead of barriers: the hand-scheduled k-loop's; the fp16-pair build runs the compiler-scheduled one)
+        self.blockwise = (waves, tiles) == (16, 2) and not self.split and os.environ.get("HANABIZERO_MLP_BLOCKWISE", "1") != "0"
 
     def _fragments(self, w, ks):
         """A job's weight block as the fragments of its wave's stream (fp32 values that the stream's format holds exactly)."""

@@ -71,9 +71,10 @@ def test_benched_search_kernel_equals_oracle_tree(game, N, net, moves):
 @pytest.mark.parametrize("game,N,net,moves", [("Hanabi-Full", 4096, "random", 2), ("Hanabi-Full", 1500, "sharp", 2), ("Hanabi-Small", 1000, "random", 3)])
 def test_fp16_pair_engine_search_equals_oracle_tree(game, N, net, moves):
     """The engine inside the contract's 1e-3 (InferenceEngine(dtype=float32, fused="fp16x2"): fp32 pool, recurrent inference =
-    hz_mlp_recurrent's HZ_F16X2 build) searches launch by launch -- descent / backup kernels around the inference kernel, two
-    launches per simulation (MCTS.run_multi) -- and must leave what the oracle tree leaves when the same inference kernel
-    evaluates the oracle's own leaves: visit counts, root values, trajectories, min-max statistics, pool planes, bit for bit."""
+    the MFMA kernel's HZ_F16X2 build) searches in ONE persistent kernel (k_search_pairs, 16 trees per workgroup) or launch by
+    launch -- descent / backup kernels around the stand-alone inference kernel, two launches per simulation -- and either way
+    must leave what the oracle tree leaves when the stand-alone inference kernel evaluates the oracle's own leaves: visit counts,
+    root values, trajectories, min-max statistics, pool planes, bit for bit."""
     from hanabizero_amd import cytree
     from hanabizero_amd.mcts import MCTS
     from oracle.cport import OracleTree
@@ -81,7 +82,7 @@ def test_fp16_pair_engine_search_equals_oracle_tree(game, N, net, moves):
     from tests.test_selfplay import make
     sims = 50
     cfg, eng, actor = make(game, N, sims, 4, torch.float32, use_graph=False, seed=31, peaked="sharp" if net == "sharp" else False, fused="fp16x2")
-    assert eng.fused is not None and eng.fused.header.dtype == 3 and eng.fused_shape(16, 2) is None
+    assert eng.fused is not None and eng.fused.header.dtype == 3 and eng.fused_shape(16, 2).header.dtype == 3
     A = cfg.action_space_size
     for _ in range(moves):
         actor.step()
@@ -92,14 +93,17 @@ def test_fp16_pair_engine_search_equals_oracle_tree(game, N, net, moves):
     tree = OracleTree(N, A, sims, seed=7, value_delta_max=cfg.value_delta_max, tree_id_base=1000)
     tree.prepare(cfg.root_exploration_fraction, noise.cpu().numpy(), np.zeros(N, np.float32), logits0.cpu().numpy(), legal.cpu().numpy())
     pool_o = oracle_search(cfg, eng, tree, hidden0, sims)
-    roots = cytree.Roots(N, A, sims, tie_seed=7, tree_id_base=1000)
-    roots.prepare(cfg.root_exploration_fraction, noise, torch.zeros(N, device="cuda"), logits0, legal)
-    pool = torch.zeros(sims, N, eng.H, dtype=torch.float32, device="cuda")
-    MCTS(cfg).run_multi(roots, eng, hidden0, pool=pool)
-    torch.cuda.synchronize()
-    assert np.array_equal(roots.distributions_tensor().cpu().numpy(), tree.distributions())
-    assert np.array_equal(bits(roots.values_tensor().cpu().numpy()), bits(tree.values()))
-    assert np.array_equal(roots.trajectories_tensor().cpu().numpy(), tree.trajectories())
-    mn, mx = roots.minmax_tensors()
-    assert np.array_equal(bits(mn.cpu().numpy()), bits(tree.minmax()[0])) and np.array_equal(bits(mx.cpu().numpy()), bits(tree.minmax()[1]))
-    assert torch.equal(bits(pool), bits(pool_o))
+    for persistent in (True, False):
+        roots = cytree.Roots(N, A, sims, tie_seed=7, tree_id_base=1000)
+        roots.prepare(cfg.root_exploration_fraction, noise, torch.zeros(N, device="cuda"), logits0, legal)
+        pool = torch.zeros(sims, N, eng.H, dtype=torch.float32, device="cuda")
+        MCTS(cfg, persistent=persistent).run_multi(roots, eng, hidden0, pool=pool)
+        torch.cuda.synchronize()
+        assert roots._sim == sims - 1
+        assert np.array_equal(roots.distributions_tensor().cpu().numpy(), tree.distributions()), persistent
+        assert np.array_equal(bits(roots.values_tensor().cpu().numpy()), bits(tree.values())), persistent
+        assert np.array_equal(roots.trajectories_tensor().cpu().numpy(), tree.trajectories()), persistent
+        mn, mx = roots.minmax_tensors()
+        assert np.array_equal(bits(mn.cpu().numpy()), bits(tree.minmax()[0])) and np.array_equal(bits(mx.cpu().numpy()), bits(tree.minmax()[1]))
+        assert torch.equal(bits(pool), bits(pool_o)), persistent
+        del roots
