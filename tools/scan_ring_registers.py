@@ -37,7 +37,8 @@ def scan():
             if run.returncode != 0:
                 raise RuntimeError("scan_ring_registers: %s did not compile to assembly:\n%s" % (unit, run.stdout[-4000:]))
             txt = open(out).read()
-            for name in re.findall(r"^(_Z\w*k_(?:search|mlp_recurrent16)\w*):", txt, re.M):
+            # (k_search_pairs, the fp16-pair build, runs the compiler-scheduled k-loop: no ring in fixed registers, all 128 are the compiler's)
+            for name in re.findall(r"^(_Z\w*k_(?:search(?!_pairs)|mlp_recurrent16)\w*):", txt, re.M):
                 i = txt.index("\n" + name + ":")
                 body = txt[i:txt.index("s_endpgm", i)]
                 seen += 1
