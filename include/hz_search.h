@@ -38,7 +38,9 @@ extern "C" {
  *                  With num_actions <= 20, where the workgroup's LDS has room for a table of the nodes' last selections, a
  *                  tree whose descents have grown 6 levels long walks its predicted lines 16 (side by side: 8) levels at a time
  *                  (csrc/hz_tree_replay_dev.h) -- again the same bits, only sooner when the policy is sharp.
- * The MLP header's dtype (HZ_BF16 / HZ_F16) selects the element format of pool, weights and activations.
+ * The MLP header's dtype (HZ_BF16 / HZ_F16) selects the element format of pool, weights and activations; HZ_F16X2 (include/hz_mlp.h:
+ * fp32 numbers as fp16 pairs, the build inside 1e-3 of the reference's fp32 nets) takes an fp32 pool -- strides in fp32 elements --
+ * and keeps 16 trees per workgroup at any tree count (rows_per_workgroup 0 or 16).
  * Limits (HZ_ERR otherwise -- the launch-per-phase calls of hz_tree.h / hz_mlp.h have none of them and compute the same
  * bits): fewer than 64 simulations per tree (t's S; the reference's configs have 50), hidden <= 512, support_size <= 256,
  * 160 KiB of LDS for 16 (or 32) row images + search state.
