@@ -114,7 +114,10 @@ def _load():
         # include/hz_train.h
         "hz_bn_act_forward": [V, I64, V, I64, V, I64, I, I, V, V, V, V, F, F, V, V, I, I, V],
         "hz_bn_act_backward": [V, I64, V, I64, V, I64, V, I64, V, I64, I, I, V, V, V, V, V, I, I, V],
+        "hz_bn_act_forward_groups": [V, I64, V, I64, V, I64, I, I, I, V, V, V, V, F, F, V, V, V, V, I, I, V],
+        "hz_bn_act_backward_groups": [V, I64, V, I64, V, I64, V, I64, V, I64, I, I, I, V, V, V, V, V, V, V, I, I, V],
         "hz_muzero_head_losses": [V, I64, V, I64, V, I64, I, I, I, I, I, V, I64, V, I64, V, I64, V, F, F, F, V, V, V, V, V, V],
+        "hz_muzero_unrolled_losses": [V, I64, V, I64, V, I64, I, I, I, I, I, I, V, I64, I64, V, I64, I64, V, I64, I64, V, F, F, F, V, V, V, V, V, V],
         # include/hz_netglue.h
         "hz_add_relu": [V, I64, V, I64, I, I, I, V],
         "hz_test_expf": [V, V, I64, V],

@@ -76,10 +76,19 @@ __global__ __launch_bounds__(256) void k_bn_act_forward(const uint16_t* __restri
                                                         long long rs, uint16_t* __restrict__ out, long long os, int rows, int cols,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
-                                                        float* __restrict__ smean, float* __restrict__ sinv, int relu, int vec) {
+                                                        float* __restrict__ smean, float* __restrict__ sinv, int relu, int vec,
+                                                        float* __restrict__ scratch, int* __restrict__ tickets) {
   __shared__ float4 s_r[4][4];
+  __shared__ int s_last;
   const int g = threadIdx.x >> 2, p = threadIdx.x & 3, c = blockIdx.x * TR_COLS + 2 * p;
   const bool on = c < cols, both = vec && c + 1 < cols, on1 = c + 1 < cols;
+  // blockIdx.y = the row group: `rows` consecutive rows normalised by their own statistics (one BatchNorm call of the module each)
+  const int gy = blockIdx.y, G = gridDim.y;
+  x += (long long)gy * rows * xs;
+  out += (long long)gy * rows * os;
+  if (res != nullptr) res += (long long)gy * rows * rs;
+  smean += (long long)gy * cols;
+  sinv += (long long)gy * cols;
   float2 v[TR_HOLD];
 #pragma unroll
   for (int i = 0; i < TR_HOLD; ++i) {
@@ -122,20 +131,51 @@ __global__ __launch_bounds__(256) void k_bn_act_forward(const uint16_t* __restri
     const float4 t = tr_reduce(make_float4(sq.x, sq.y, 0.0f, 0.0f), s_r);
     sq = make_float2(t.x, t.y);
   }
-  if (!on) return;
   const float2 var = make_float2(sq.x / (float)rows, sq.y / (float)rows);
   const float2 inv = make_float2(rsqrtf(var.x + eps), rsqrtf(var.y + eps));
-  if (g == 0) {
-    const float ub = rows > 1 ? (float)rows / (float)(rows - 1) : 1.0f;
+  const float ub = rows > 1 ? (float)rows / (float)(rows - 1) : 1.0f;
+  if (on && g == 0) {
     smean[c] = mean.x; sinv[c] = inv.x;
-    rmean[c] = (1.0f - momentum) * rmean[c] + momentum * mean.x;
-    rvar[c] = (1.0f - momentum) * rvar[c] + momentum * (var.x * ub);
-    if (on1) {
-      smean[c + 1] = mean.y; sinv[c + 1] = inv.y;
-      rmean[c + 1] = (1.0f - momentum) * rmean[c + 1] + momentum * mean.y;
-      rvar[c + 1] = (1.0f - momentum) * rvar[c + 1] + momentum * (var.y * ub);
+    if (on1) { smean[c + 1] = mean.y; sinv[c + 1] = inv.y; }
+    if (G == 1) {
+      rmean[c] = (1.0f - momentum) * rmean[c] + momentum * mean.x;
+      rvar[c] = (1.0f - momentum) * rvar[c] + momentum * (var.x * ub);
+      if (on1) {
+        rmean[c + 1] = (1.0f - momentum) * rmean[c + 1] + momentum * mean.y;
+        rvar[c + 1] = (1.0f - momentum) * rvar[c + 1] + momentum * (var.y * ub);
+      }
+    } else {  // the running statistics take the groups' batches one after the other, as the module's G calls would: by the last workgroup
+      scratch[((long long)gy * 2 + 0) * cols + c] = mean.x;
+      scratch[((long long)gy * 2 + 1) * cols + c] = var.x * ub;
+      if (on1) {
+        scratch[((long long)gy * 2 + 0) * cols + c + 1] = mean.y;
+        scratch[((long long)gy * 2 + 1) * cols + c + 1] = var.y * ub;
+      }
     }
   }
+  if (G > 1) {
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int t = atomicAdd(&tickets[blockIdx.x], 1);
+      s_last = t == G - 1;
+      if (s_last) tickets[blockIdx.x] = 0;  // (ready for the next launch)
+    }
+    __syncthreads();
+    if (s_last && on && g == 0) {
+      __threadfence();
+      for (int e = 0; e < (on1 ? 2 : 1); ++e) {
+        float rm = rmean[c + e], rv = rvar[c + e];
+        for (int k = 0; k < G; ++k) {
+          rm = (1.0f - momentum) * rm + momentum * __hip_atomic_load(scratch + ((long long)k * 2 + 0) * cols + c + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          rv = (1.0f - momentum) * rv + momentum * __hip_atomic_load(scratch + ((long long)k * 2 + 1) * cols + c + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        rmean[c + e] = rm;
+        rvar[c + e] = rv;
+      }
+    }
+  }
+  if (!on) return;
   const float2 ga = make_float2(gamma[c], on1 ? gamma[c + 1] : 0.0f), be = make_float2(beta[c], on1 ? beta[c + 1] : 0.0f);
   auto finish = [&](int r, float2 xv) {
     float a = (xv.x - mean.x) * inv.x * ga.x + be.x, b = (xv.y - mean.y) * inv.y * ga.y + be.y;
@@ -165,10 +205,20 @@ __global__ __launch_bounds__(256) void k_bn_act_backward(const uint16_t* __restr
                                                          uint16_t* __restrict__ dx, long long dxs, uint16_t* __restrict__ dres,
                                                          long long drs, int rows, int cols, const float* __restrict__ gamma,
                                                          const float* __restrict__ smean, const float* __restrict__ sinv,
-                                                         float* __restrict__ dgamma, float* __restrict__ dbeta, int relu, int vec) {
+                                                         float* __restrict__ dgamma, float* __restrict__ dbeta, int relu, int vec,
+                                                         float* __restrict__ scratch, int* __restrict__ tickets) {
   __shared__ float4 s_r[4][4];
+  __shared__ int s_last;
   const int g = threadIdx.x >> 2, p = threadIdx.x & 3, c = blockIdx.x * TR_COLS + 2 * p;
   const bool on = c < cols, both = vec && c + 1 < cols, on1 = c + 1 < cols;
+  const int gy = blockIdx.y, G = gridDim.y;  // row groups as in the forward kernel
+  dout += (long long)gy * rows * ds;
+  x += (long long)gy * rows * xs;
+  dx += (long long)gy * rows * dxs;
+  if (out != nullptr) out += (long long)gy * rows * os;
+  if (dres != nullptr) dres += (long long)gy * rows * drs;
+  smean += (long long)gy * cols;
+  sinv += (long long)gy * cols;
   const float2 mean = make_float2(on ? smean[c] : 0.0f, on1 ? smean[c + 1] : 0.0f);
   const float2 inv = make_float2(on ? sinv[c] : 0.0f, on1 ? sinv[c + 1] : 0.0f);
   auto fetch = [&](int r, float2& dz, float2& xh) {  // dz = dout masked by the ReLU, xh = the normalised input
@@ -209,11 +259,42 @@ __global__ __launch_bounds__(256) void k_bn_act_backward(const uint16_t* __restr
     s1 = make_float2(t.x, t.y);
     s2 = make_float2(t.z, t.w);
   }
-  if (!on) return;
-  if (g == 0) {
-    dbeta[c] += s1.x; dgamma[c] += s2.x;
-    if (on1) { dbeta[c + 1] += s1.y; dgamma[c + 1] += s2.y; }
+  if (on && g == 0) {
+    if (G == 1) {
+      dbeta[c] += s1.x; dgamma[c] += s2.x;
+      if (on1) { dbeta[c + 1] += s1.y; dgamma[c + 1] += s2.y; }
+    } else {  // the groups' sums added up in the order of the groups by the last workgroup: the same bits whatever the schedule
+      scratch[((long long)gy * 2 + 0) * cols + c] = s1.x;
+      scratch[((long long)gy * 2 + 1) * cols + c] = s2.x;
+      if (on1) {
+        scratch[((long long)gy * 2 + 0) * cols + c + 1] = s1.y;
+        scratch[((long long)gy * 2 + 1) * cols + c + 1] = s2.y;
+      }
+    }
   }
+  if (G > 1) {
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int t = atomicAdd(&tickets[blockIdx.x], 1);
+      s_last = t == G - 1;
+      if (s_last) tickets[blockIdx.x] = 0;
+    }
+    __syncthreads();
+    if (s_last && on && g == 0) {
+      __threadfence();
+      for (int e = 0; e < (on1 ? 2 : 1); ++e) {
+        float b = 0.0f, a = 0.0f;
+        for (int k = 0; k < G; ++k) {
+          b += __hip_atomic_load(scratch + ((long long)k * 2 + 0) * cols + c + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          a += __hip_atomic_load(scratch + ((long long)k * 2 + 1) * cols + c + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        dbeta[c + e] += b;
+        dgamma[c + e] += a;
+      }
+    }
+  }
+  if (!on) return;
   const float2 m1 = make_float2(s1.x / (float)rows, s1.y / (float)rows), m2 = make_float2(s2.x / (float)rows, s2.y / (float)rows);
   const float2 k = make_float2(gamma[c] * inv.x, on1 ? gamma[c + 1] * inv.y : 0.0f);
   auto finish = [&](int r, float2 dz, float2 xh) {
@@ -238,23 +319,32 @@ __global__ __launch_bounds__(256) void k_bn_act_backward(const uint16_t* __restr
 extern "C" int hz_bn_act_forward(const void* x, int64_t x_stride, const void* res, int64_t res_stride, void* out, int64_t out_stride, int rows,
                                  int cols, const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
                                  float eps, float* save_mean, float* save_invstd, int relu, int dtype, void* stream) {
+  return hz_bn_act_forward_groups(x, x_stride, res, res_stride, out, out_stride, rows, 1, cols, gamma, beta, running_mean, running_var, momentum,
+                                  eps, save_mean, save_invstd, nullptr, nullptr, relu, dtype, stream);
+}
+
+extern "C" int hz_bn_act_forward_groups(const void* x, int64_t x_stride, const void* res, int64_t res_stride, void* out, int64_t out_stride,
+                                        int rows, int groups, int cols, const float* gamma, const float* beta, float* running_mean,
+                                        float* running_var, float momentum, float eps, float* save_mean, float* save_invstd, float* scratch,
+                                        int* tickets, int relu, int dtype, void* stream) {
   HZ_REQUIRE(x && out && gamma && beta && running_mean && running_var && save_mean && save_invstd, "hz_bn_act_forward: null pointer");
+  HZ_REQUIRE(groups >= 1 && groups <= 1024 && (groups == 1 || (scratch && tickets)), "hz_bn_act_forward_groups: groups=%d (more than one needs scratch and tickets)", groups);
   HZ_REQUIRE(rows >= 1 && cols >= 1 && x_stride >= cols && out_stride >= cols && (!res || res_stride >= cols),
              "hz_bn_act_forward: rows=%d cols=%d strides %lld / %lld / %lld", rows, cols, (long long)x_stride, (long long)out_stride, (long long)res_stride);
   HZ_REQUIRE(dtype == HZ_BF16 || dtype == HZ_F16, "hz_bn_act_forward: dtype %d (HZ_BF16 or HZ_F16)", dtype);
   HZ_REQUIRE(eps > 0.0f && momentum >= 0.0f && momentum <= 1.0f, "hz_bn_act_forward: eps=%g momentum=%g", (double)eps, (double)momentum);
-  const dim3 grid((cols + TR_COLS - 1) / TR_COLS);
+  const dim3 grid((cols + TR_COLS - 1) / TR_COLS, groups);
   // (two adjacent columns per 4-B access where every row starts 4-B aligned)
   const int vec = (x_stride % 2 == 0 && out_stride % 2 == 0 && (!res || res_stride % 2 == 0) && ((uintptr_t)x % 4) == 0 && ((uintptr_t)out % 4) == 0 &&
                    (!res || ((uintptr_t)res % 4) == 0)) ? 1 : 0;
   if (dtype == HZ_BF16)
     hipLaunchKernelGGL(k_bn_act_forward<HZ_BF16>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, (long long)x_stride, (const uint16_t*)res,
                        (long long)res_stride, (uint16_t*)out, (long long)out_stride, rows, cols, gamma, beta, running_mean, running_var, momentum, eps,
-                       save_mean, save_invstd, relu, vec);
+                       save_mean, save_invstd, relu, vec, scratch, tickets);
   else
     hipLaunchKernelGGL(k_bn_act_forward<HZ_F16>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, (long long)x_stride, (const uint16_t*)res,
                        (long long)res_stride, (uint16_t*)out, (long long)out_stride, rows, cols, gamma, beta, running_mean, running_var, momentum, eps,
-                       save_mean, save_invstd, relu, vec);
+                       save_mean, save_invstd, relu, vec, scratch, tickets);
   HZ_HIP(hipGetLastError());
   return 0;
 }
@@ -263,22 +353,31 @@ extern "C" int hz_bn_act_backward(const void* dout, int64_t dout_stride, const v
                                   void* dx, int64_t dx_stride, void* dres, int64_t dres_stride, int rows, int cols, const float* gamma,
                                   const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, int relu, int dtype,
                                   void* stream) {
+  return hz_bn_act_backward_groups(dout, dout_stride, out, out_stride, x, x_stride, dx, dx_stride, dres, dres_stride, rows, 1, cols, gamma, save_mean,
+                                   save_invstd, dgamma, dbeta, nullptr, nullptr, relu, dtype, stream);
+}
+
+extern "C" int hz_bn_act_backward_groups(const void* dout, int64_t dout_stride, const void* out, int64_t out_stride, const void* x,
+                                         int64_t x_stride, void* dx, int64_t dx_stride, void* dres, int64_t dres_stride, int rows, int groups,
+                                         int cols, const float* gamma, const float* save_mean, const float* save_invstd, float* dgamma,
+                                         float* dbeta, float* scratch, int* tickets, int relu, int dtype, void* stream) {
   HZ_REQUIRE(dout && x && dx && gamma && save_mean && save_invstd && dgamma && dbeta && (out || !relu), "hz_bn_act_backward: null pointer");
+  HZ_REQUIRE(groups >= 1 && groups <= 1024 && (groups == 1 || (scratch && tickets)), "hz_bn_act_backward_groups: groups=%d (more than one needs scratch and tickets)", groups);
   HZ_REQUIRE(rows >= 1 && cols >= 1 && dout_stride >= cols && x_stride >= cols && dx_stride >= cols && (!relu || out_stride >= cols) &&
                  (!dres || dres_stride >= cols),
              "hz_bn_act_backward: rows=%d cols=%d and a row stride below cols", rows, cols);
   HZ_REQUIRE(dtype == HZ_BF16 || dtype == HZ_F16, "hz_bn_act_backward: dtype %d (HZ_BF16 or HZ_F16)", dtype);
-  const dim3 grid((cols + TR_COLS - 1) / TR_COLS);
+  const dim3 grid((cols + TR_COLS - 1) / TR_COLS, groups);
   auto al = [](const void* q, int64_t st) { return !q || (st % 2 == 0 && ((uintptr_t)q % 4) == 0); };
   const int vec = (al(dout, dout_stride) && al(relu ? out : nullptr, out_stride) && al(x, x_stride) && al(dx, dx_stride) && al(dres, dres_stride)) ? 1 : 0;
   if (dtype == HZ_BF16)
     hipLaunchKernelGGL(k_bn_act_backward<HZ_BF16>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dout, (long long)dout_stride,
                        (const uint16_t*)out, (long long)out_stride, (const uint16_t*)x, (long long)x_stride, (uint16_t*)dx, (long long)dx_stride,
-                       (uint16_t*)dres, (long long)dres_stride, rows, cols, gamma, save_mean, save_invstd, dgamma, dbeta, relu, vec);
+                       (uint16_t*)dres, (long long)dres_stride, rows, cols, gamma, save_mean, save_invstd, dgamma, dbeta, relu, vec, scratch, tickets);
   else
     hipLaunchKernelGGL(k_bn_act_backward<HZ_F16>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dout, (long long)dout_stride,
                        (const uint16_t*)out, (long long)out_stride, (const uint16_t*)x, (long long)x_stride, (uint16_t*)dx, (long long)dx_stride,
-                       (uint16_t*)dres, (long long)dres_stride, rows, cols, gamma, save_mean, save_invstd, dgamma, dbeta, relu, vec);
+                       (uint16_t*)dres, (long long)dres_stride, rows, cols, gamma, save_mean, save_invstd, dgamma, dbeta, relu, vec, scratch, tickets);
   HZ_HIP(hipGetLastError());
   return 0;
 }
@@ -367,26 +466,35 @@ __global__ __launch_bounds__(256) void k_head_losses(const void* __restrict__ vl
                                                      const float* __restrict__ tv, long long tvs, const float* __restrict__ trw, long long trs,
                                                      const float* __restrict__ tp, long long tps, const float* __restrict__ weights,
                                                      float vc, float rc, float pc, void* dv, void* dr, void* dp,
-                                                     float* __restrict__ losses, float* __restrict__ preds) {
-  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
+                                                     float* __restrict__ losses, float* __restrict__ preds, int batch, long long tvk,
+                                                     long long trk, long long tpk) {
+  // rows = steps * batch: row R is position b = R % batch of inference k = R / batch of the unrolled step (steps == 1: one
+  // inference, as hz_muzero_head_losses).  Logit rows are stacked inference by inference; the reward head has none for the
+  // initial inference (its row of R is R - batch); targets are indexed [b][k] through their two strides; weights by b.
+  const int lane = threadIdx.x & 63, R = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (R >= rows) return;
   constexpr long long ES = DT == HZ_F32 ? 4 : 2;
-  const float wfac = weights[row] / (float)rows;
-  auto at = [&](const void* b, long long stride) { return reinterpret_cast<const char*>(b) + (long long)row * stride * ES; };
-  auto atw = [&](void* b, long long stride) { return b ? reinterpret_cast<char*>(b) + (long long)row * stride * ES : nullptr; };
+  const bool unrolled = rows != batch;
+  const int k = R / batch, b = R - k * batch;
+  const long long row = R, rrow = unrolled ? R - batch : R;
+  const float wfac = weights[b] / (float)batch;
+  auto at = [&](const void* p, long long r, long long stride) { return reinterpret_cast<const char*>(p) + r * stride * ES; };
+  auto atw = [&](void* p, long long r, long long stride) { return p ? reinterpret_cast<char*>(p) + r * stride * ES : nullptr; };
   float vl, vpred, rl = 0.0f, rpred = 0.0f;
-  hl_support_head<DT>(at(vlog, vs), atw(dv, V), V, smin, tv[(long long)row * tvs], wfac * vc, lane, vl, vpred);
-  if (rlog != nullptr) hl_support_head<DT>(at(rlog, rs), atw(dr, V), V, smin, trw[(long long)row * trs], wfac * rc, lane, rl, rpred);
+  hl_support_head<DT>(at(vlog, row, vs), atw(dv, row, V), V, smin, tv[(long long)b * tvs + (long long)k * tvk], wfac * vc, lane, vl, vpred);
+  if (rlog != nullptr && !(unrolled && k == 0))
+    hl_support_head<DT>(at(rlog, rrow, rs), atw(dr, rrow, V), V, smin, trw[(long long)b * trs + (long long)(unrolled ? k - 1 : 0) * trk], wfac * rc, lane, rl,
+                        rpred);
   // policy: -(log_softmax . target); gradient softmax * sum(target) - target
   float x[1], mx, lse;
-  hl_row_stats<DT, 1>(at(plog, ps), A, lane, x, mx, lse);
-  const float t = lane < A ? tp[(long long)row * tps + lane] : 0.0f;
+  hl_row_stats<DT, 1>(at(plog, row, ps), A, lane, x, mx, lse);
+  const float t = lane < A ? tp[(long long)b * tps + (long long)k * tpk + lane] : 0.0f;
   const float tsum = hl_wave_sum(t);
   float pl = 0.0f;
   if (lane < A) {
     const float logp = x[0] - mx - lse;
     pl = -logp * t;
-    if (dp != nullptr) hl_store<DT>(atw(dp, A), lane, wfac * pc * (expf(logp) * tsum - t));
+    if (dp != nullptr) hl_store<DT>(atw(dp, row, A), lane, wfac * pc * (expf(logp) * tsum - t));
   }
   pl = hl_wave_sum(pl);
   if (lane == 0) {
@@ -403,6 +511,22 @@ extern "C" int hz_muzero_head_losses(const void* value_logits, int64_t value_str
                                      int64_t target_reward_stride, const float* target_policy, int64_t target_policy_stride, const float* weights,
                                      float value_coeff, float reward_coeff, float policy_coeff, void* d_value, void* d_reward, void* d_policy,
                                      float* losses, float* preds, void* stream) {
+  return hz_muzero_unrolled_losses(value_logits, value_stride, reward_logits, reward_stride, policy_logits, policy_stride, rows, 1, support_size,
+                                   support_min, num_actions, dtype, target_value, target_value_stride, 0, target_reward, target_reward_stride, 0,
+                                   target_policy, target_policy_stride, 0, weights, value_coeff, reward_coeff, policy_coeff, d_value, d_reward,
+                                   d_policy, losses, preds, stream);
+}
+
+extern "C" int hz_muzero_unrolled_losses(const void* value_logits, int64_t value_stride, const void* reward_logits, int64_t reward_stride,
+                                         const void* policy_logits, int64_t policy_stride, int batch, int steps, int support_size, int support_min,
+                                         int num_actions, int dtype, const float* target_value, int64_t target_value_stride,
+                                         int64_t target_value_step_stride, const float* target_reward, int64_t target_reward_stride,
+                                         int64_t target_reward_step_stride, const float* target_policy, int64_t target_policy_stride,
+                                         int64_t target_policy_step_stride, const float* weights, float value_coeff, float reward_coeff,
+                                         float policy_coeff, void* d_value, void* d_reward, void* d_policy, float* losses, float* preds,
+                                         void* stream) {
+  HZ_REQUIRE(batch >= 1 && steps >= 1 && (long long)batch * steps < (1ll << 30), "hz_muzero_unrolled_losses: batch=%d steps=%d", batch, steps);
+  const int rows = batch * steps;
   HZ_REQUIRE(value_logits && policy_logits && target_value && target_policy && weights && losses && preds, "hz_muzero_head_losses: null pointer");
   HZ_REQUIRE(!reward_logits || target_reward, "hz_muzero_head_losses: reward logits without reward targets");
   HZ_REQUIRE(rows >= 1 && support_size >= 1 && support_size <= 256 && num_actions >= 1 && num_actions <= 64,
@@ -416,7 +540,8 @@ extern "C" int hz_muzero_head_losses(const void* value_logits, int64_t value_str
                      (long long)reward_stride, policy_logits, (long long)policy_stride, rows, support_size, support_min, num_actions,  \
                      target_value, (long long)target_value_stride, target_reward, (long long)target_reward_stride, target_policy,      \
                      (long long)target_policy_stride, weights, value_coeff, reward_coeff, policy_coeff, d_value, d_reward, d_policy,   \
-                     losses, preds)
+                     losses, preds, batch, (long long)target_value_step_stride, (long long)target_reward_step_stride,                  \
+                     (long long)target_policy_step_stride)
   if (dtype == HZ_F32) HZ_HL(HZ_F32);
   else if (dtype == HZ_BF16) HZ_HL(HZ_BF16);
   else HZ_HL(HZ_F16);

@@ -38,27 +38,42 @@ class _Block:
         self.lin, self.bn, self.uses = lin, bn, uses
         self.w16 = lin.weight.detach().to(dtype)
         self.b16 = lin.bias.detach().to(dtype)
+        self.scratch = self.tickets = None   # a call over several row groups (hz_bn_act_*_groups): where the groups' sums meet
+
+    def group_buffers(self, groups):
+        Cn = self.lin.weight.shape[0]
+        if self.scratch is None or self.scratch.shape[0] < groups:
+            self.scratch = torch.empty((groups, 2, Cn), dtype=torch.float32, device=self.w16.device)
+            self.tickets = torch.zeros((Cn + 7) // 8, dtype=torch.int32, device=self.w16.device)
+        return self.scratch, self.tickets
 
 
 class _LinBNAct(torch.autograd.Function):
     """out = act(batch_norm(x @ W^T + b) + res): forward GEMM + hz_bn_act_forward; backward hz_bn_act_backward + two GEMMs."""
 
     @staticmethod
-    def forward(ctx, x, res, blk, relu, anchor=None):
+    def forward(ctx, x, res, blk, relu, anchor=None, groups=1):
         """anchor: any tensor that requires grad (the parameters do not enter autograd here: the first block of a forward, whose
-        input is data, needs one for its output to be part of the graph); its gradient is None."""
+        input is data, needs one for its output to be part of the graph); its gradient is None.
+        groups: x stacks that many batches (the hidden states of the unrolled step's inferences): ONE GEMM over all rows, the
+        BatchNorm of each batch with its own statistics -- the arithmetic of `groups` calls of the module."""
         bn = blk.bn
         y = torch.addmm(blk.b16, x, blk.w16.t())
         out = torch.empty_like(y)
-        B, Cn = y.shape
-        stats = torch.empty((2, Cn), dtype=torch.float32, device=y.device)
+        rows, Cn = y.shape
+        assert rows % groups == 0
+        B = rows // groups
+        stats = torch.empty((2, groups, Cn), dtype=torch.float32, device=y.device)
+        scratch, tickets = blk.group_buffers(groups) if groups > 1 else (None, None)
         if res is not None:
             assert res.shape == y.shape and res.stride(1) == 1 and res.dtype == y.dtype
-        check(lib.hz_bn_act_forward(y.data_ptr(), y.stride(0), None if res is None else res.data_ptr(), 0 if res is None else res.stride(0),
-                                    out.data_ptr(), out.stride(0), B, Cn, bn.weight.data_ptr(), bn.bias.data_ptr(),
-                                    bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.momentum), float(bn.eps),
-                                    stats[0].data_ptr(), stats[1].data_ptr(), int(relu), _DT[y.dtype], _stream()), "hz_bn_act_forward")
-        ctx.blk, ctx.relu, ctx.has_res = blk, relu, res is not None
+        check(lib.hz_bn_act_forward_groups(y.data_ptr(), y.stride(0), None if res is None else res.data_ptr(), 0 if res is None else res.stride(0),
+                                           out.data_ptr(), out.stride(0), B, groups, Cn, bn.weight.data_ptr(), bn.bias.data_ptr(),
+                                           bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.momentum), float(bn.eps),
+                                           stats[0].data_ptr(), stats[1].data_ptr(), None if scratch is None else scratch.data_ptr(),
+                                           None if tickets is None else tickets.data_ptr(), int(relu), _DT[y.dtype], _stream()),
+              "hz_bn_act_forward_groups")
+        ctx.blk, ctx.relu, ctx.has_res, ctx.groups = blk, relu, res is not None, groups
         ctx.save_for_backward(x, y, out, stats)
         return out
 
@@ -71,17 +86,21 @@ class _LinBNAct(torch.autograd.Function):
                                "optimizer.zero_grad(set_to_none=False), do not drop them")
         if dout.stride(1) != 1:
             dout = dout.contiguous()
-        B, Cn = y.shape
+        rows, Cn = y.shape
+        groups = ctx.groups
         dy = torch.empty_like(y)
         dres = torch.empty_like(y) if ctx.has_res else None
-        check(lib.hz_bn_act_backward(dout.data_ptr(), dout.stride(0), out.data_ptr(), out.stride(0), y.data_ptr(), y.stride(0),
-                                     dy.data_ptr(), dy.stride(0), None if dres is None else dres.data_ptr(), 0 if dres is None else dres.stride(0),
-                                     B, Cn, bn.weight.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), bn.weight.grad.data_ptr(),
-                                     bn.bias.grad.data_ptr(), int(ctx.relu), _DT[y.dtype], _stream()), "hz_bn_act_backward")
+        scratch, tickets = blk.group_buffers(groups) if groups > 1 else (None, None)
+        check(lib.hz_bn_act_backward_groups(dout.data_ptr(), dout.stride(0), out.data_ptr(), out.stride(0), y.data_ptr(), y.stride(0),
+                                            dy.data_ptr(), dy.stride(0), None if dres is None else dres.data_ptr(),
+                                            0 if dres is None else dres.stride(0), rows // groups, groups, Cn, bn.weight.data_ptr(),
+                                            stats[0].data_ptr(), stats[1].data_ptr(), bn.weight.grad.data_ptr(), bn.bias.grad.data_ptr(),
+                                            None if scratch is None else scratch.data_ptr(), None if tickets is None else tickets.data_ptr(),
+                                            int(ctx.relu), _DT[y.dtype], _stream()), "hz_bn_act_backward_groups")
         g = blk.lin.weight.grad                                # W.grad += dy^T x: ONE GEMM, 16-bit operands, fp32 accumulate and output
         torch.addmm(g, dy.t(), x, out_dtype=torch.float32, out=g)
         dx = torch.mm(dy, blk.w16) if ctx.needs_input_grad[0] else None
-        return dx, dres, None, None, None
+        return dx, dres, None, None, None, None
 
 
 class _Lin(torch.autograd.Function):
@@ -140,21 +159,60 @@ class _HeadLosses(torch.autograd.Function):
         return dv * g, (dr * g if ctx.has_reward else None), dp * g, None, None, None, None, None, None
 
 
+class _UnrolledLosses(torch.autograd.Function):
+    """_HeadLosses for every inference of the unrolled step at once (include/hz_train.h hz_muzero_unrolled_losses): logits stacked
+    inference by inference (value / policy [(U + 1) B, .], reward [U B, .]), targets as the learner holds them ([B, U + 1], [B, U],
+    [B, U + 1, A]: indexed through their strides, nothing transposed).  Returns (row totals [(U + 1) B], losses [(U + 1) B, 4],
+    preds [(U + 1) B, 2])."""
+
+    @staticmethod
+    def forward(ctx, value, reward, policy, tv, tr, tp, weights, support, coeffs):
+        B = weights.shape[0]
+        rows, V = value.shape
+        steps = rows // B
+        A = policy.shape[1]
+        d = value.device
+        dt = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[value.dtype]
+        assert rows == steps * B and policy.shape[0] == rows and reward.shape[0] == rows - B and steps >= 2
+        assert policy.dtype == value.dtype and reward.dtype == value.dtype
+        assert value.stride(1) == 1 and reward.stride(1) == 1 and policy.stride(1) == 1 and tp.stride(2) == 1 and weights.is_contiguous()
+        assert tv.shape == (B, steps) and tr.shape[0] == B and tr.shape[1] >= steps - 1 and tp.shape == (B, steps, A)
+        dv, dp = torch.empty((rows, V), dtype=value.dtype, device=d), torch.empty((rows, A), dtype=value.dtype, device=d)
+        dr = torch.empty((rows - B, V), dtype=value.dtype, device=d)
+        losses = torch.empty((rows, 4), dtype=torch.float32, device=d)
+        preds = torch.empty((rows, 2), dtype=torch.float32, device=d)
+        vc, rc, pc = coeffs
+        check(lib.hz_muzero_unrolled_losses(value.data_ptr(), value.stride(0), reward.data_ptr(), reward.stride(0), policy.data_ptr(),
+                                            policy.stride(0), B, steps, V, support.min, A, dt, tv.data_ptr(), tv.stride(0), tv.stride(1),
+                                            tr.data_ptr(), tr.stride(0), tr.stride(1), tp.data_ptr(), tp.stride(0), tp.stride(1),
+                                            weights.data_ptr(), float(vc), float(rc), float(pc), dv.data_ptr(), dr.data_ptr(), dp.data_ptr(),
+                                            losses.data_ptr(), preds.data_ptr(), _stream()), "hz_muzero_unrolled_losses")
+        ctx.B = B
+        ctx.save_for_backward(dv, dr, dp)
+        ctx.mark_non_differentiable(losses, preds)
+        return losses[:, 3], losses, preds
+
+    @staticmethod
+    def backward(ctx, g, _gl, _gp):
+        dv, dr, dp = ctx.saved_tensors
+        g = g.to(dv.dtype).unsqueeze(1)
+        return dv * g, dr * g[ctx.B:], dp * g, None, None, None, None, None, None
+
+
 class FusedTrainNet:
     """The training-mode forward of `net` (MuZeroNet / MuZeroNetFull on a GPU) through the fused blocks.  Quacks like the module
     where the learner touches it: initial_inference / recurrent_inference (training branch of core/model.py:61-84: logits and the
     hidden state, no scalar transform), parameters / buffers / state_dict / load_state_dict / train; `net` is the module itself
     (weight hand-over: InferenceEngine.load(model.net))."""
 
-    def __init__(self, net, dtype=torch.bfloat16, unroll_steps=5, parallel_heads=None):
-        """parallel_heads (0..3; None: 2 where the heads have three layers or more, else 0): the value / reward / policy heads of an inference are three independent chains of small
-        launches; that many of them (in this order) run on streams of their own, forked from and joined into the caller's
-        (autograd runs a chain's backward on its forward's stream).  Inside the learner's captured step they become parallel
-        branches of the hipGraph, which the GPU does overlap for kernels this small: 4.35 ms per replayed step with 0, 3.91 with
-        1, 3.52 with 2, 3.65 with 3 (Hanabi-Full 5p, batch 256).  Two is the default for a second reason: a step three branches
-        wide keeps three of the GPU's four hardware queues busy, and the learner's prepare stream needs one to itself
-        (learner.LearnerPipeline._pick_prepare_stream).  Two-layer heads (Hanabi-Small) do not repay the fork and the join: 2.26 ms
-        per step as one chain, 2.52 with two branches."""
+    def __init__(self, net, dtype=torch.bfloat16, unroll_steps=5, parallel_heads=0):
+        """parallel_heads (0..3): that many of the value / reward / policy heads (in this order) run on streams of their own, forked
+        from and joined into the caller's (autograd runs a chain's backward on its forward's stream); inside the learner's captured
+        step they become parallel branches of the hipGraph.  While every inference ran its own heads -- six short chains of ~5-us
+        launches each per step -- two branches were worth 4.35 -> 3.52 ms per step (Hanabi-Full 5p, batch 256); with the heads run
+        ONCE over the stacked hidden states of all inferences (compute_losses) the chains are a fifth of the step and the fork / join
+        costs more than it hides: 1.74 ms without branches, 1.85 ms with two.  Hence 0; a step with branches also needs
+        learner.LearnerPipeline._pick_prepare_stream (hardware queues)."""
         assert next(net.parameters()).is_cuda, "the fused blocks are HIP kernels"
         self.net, self.dtype = net, dtype
         dev0 = next(net.parameters()).device
@@ -168,8 +226,7 @@ class FusedTrainNet:
         self.reward = self._chain(net._dynamics_reward, U, mk)
         self.actor = self._chain(net._prediction_actor, U + 1, mk)
         self.value = self._chain(net._prediction_value, U + 1, mk)
-        layers = sum(2 if st[0] == "res" else 1 for st in self.value)
-        n_side = (2 if layers >= 3 else 0) if parallel_heads is None else max(0, min(3, int(parallel_heads)))
+        n_side = max(0, min(3, int(parallel_heads or 0)))
         self._head_streams = [torch.cuda.Stream(device=dev0) for _ in range(n_side)] + [None] * (3 - n_side) if n_side else None
         for p in net.parameters():
             if p.grad is None:
@@ -231,12 +288,41 @@ class FusedTrainNet:
     fused_heads = True  # learner.compute_losses hands the whole unrolled forward + losses to compute_losses() below
 
     def compute_losses(self, config, obs_batch, action_batch, target_reward, target_value, target_policy, weights):
-        """learner.compute_losses (core/train.py:114-222) with every inference's losses, priorities' ingredients and logit
-        gradients in one launch (_HeadLosses).  Same returns."""
+        """learner.compute_losses (core/train.py:114-222).  Same returns.  The three heads run ONCE over the stacked hidden states
+        of all 1 + U inferences (they depend on nothing but their own state), every inference's losses, priorities' ingredients and
+        logit gradients come from one launch (_UnrolledLosses)."""
         U = config.num_unroll_steps
         B = obs_batch.shape[0]
         vs, rs = config.value_support, config.reward_support
         assert (vs.min, vs.size) == (rs.min, rs.size)
+        coeffs = (config.value_loss_coeff, config.reward_loss_coeff, config.policy_loss_coeff)
+        # the hidden states of all inferences first (representation, then the dynamics net step by step), ...
+        state = self._run(self.rep, obs_batch.reshape(B, -1).to(self.dtype))
+        states = [state]
+        for k in range(U):
+            state = self._dynamics(state, action_batch[:, k:k + 1])
+            state.register_hook(lambda grad: grad * 0.5)  # train.py:169 (the hook sees the heads' share and the next step's)
+            states.append(state)
+        stacked = torch.cat(states, 0)                    # [(U + 1) B, H]
+        # ... then every head ONCE over the stack -- one GEMM per layer instead of one per layer and inference, each inference's
+        # BatchNorm with its own statistics (hz_bn_act_*_groups) -- and all inferences' losses in one launch
+        value, reward, policy_logits = self._heads(stacked, True, groups=U + 1, reward_from=B)
+        tot, L, P = _UnrolledLosses.apply(value, reward, policy_logits, target_value, target_reward, target_policy, weights, vs, coeffs)
+        weighted_loss = tot.sum()
+        Ls = L.view(U + 1, B, 4).sum(0)
+        value_priority = (P[:B, 0] - target_value[:, 0]).abs()
+        reward_priority = (P[B:, 1].view(U, B) - target_reward[:, :U].t()).abs().mean(0)
+        vc, rc, pc = coeffs
+        return weighted_loss, dict(loss=pc * Ls[:, 0] + vc * Ls[:, 1] + rc * Ls[:, 2], policy_loss=Ls[:, 0], value_loss=Ls[:, 1],
+                                   reward_loss=Ls[:, 2], value_priority=value_priority, reward_priority=reward_priority)
+
+    def compute_losses_stepwise(self, config, obs_batch, action_batch, target_reward, target_value, target_policy, weights):
+        """compute_losses inference by inference, as the module itself is called (initial_inference, then recurrent_inference per
+        unroll step; one _HeadLosses launch each): the form the stacked one is tested against -- same arithmetic per batch row,
+        up to the GEMMs' own summation order at another row count."""
+        U = config.num_unroll_steps
+        B = obs_batch.shape[0]
+        vs, rs = config.value_support, config.reward_support
         coeffs = (config.value_loss_coeff, config.reward_loss_coeff, config.policy_loss_coeff)
         value, _, policy_logits, hidden_state = self.initial_inference(obs_batch.reshape(B, -1))
         tot, L, P = _HeadLosses.apply(value, None, policy_logits, target_value[:, 0], None, target_policy[:, 0], weights, vs, coeffs)
@@ -262,34 +348,37 @@ class FusedTrainNet:
             torch._foreach_add_(self._counters, self._uses)
 
     # -- forward ------------------------------------------------------------------------------------------------------------
-    def _run(self, steps, x):
+    def _run(self, steps, x, groups=1):
         for st in steps:
             if st[0] == "lbr":
-                x = _LinBNAct.apply(x, None, st[1], True, None if x.requires_grad else self._anchor)
+                x = _LinBNAct.apply(x, None, st[1], True, None if x.requires_grad else self._anchor, groups)
             elif st[0] == "res":
                 _, early, b1, b2 = st
                 if early:   # ResMLP: skip added behind the first BatchNorm (model.py:18-30)
-                    x = _LinBNAct.apply(_LinBNAct.apply(x, x, b1, True), None, b2, True)
+                    x = _LinBNAct.apply(_LinBNAct.apply(x, x, b1, True, None, groups), None, b2, True, None, groups)
                 else:       # NewResMLP: behind the second (model.py:43-57)
-                    x = _LinBNAct.apply(_LinBNAct.apply(x, None, b1, True), x, b2, True)
+                    x = _LinBNAct.apply(_LinBNAct.apply(x, None, b1, True, None, groups), x, b2, True, None, groups)
             else:
                 x = _Lin.apply(x, st[1])
         return x
 
-    def _heads(self, state, with_reward):
-        """(value logits, reward logits or None, policy logits) of a hidden state."""
+    def _heads(self, state, with_reward, groups=1, reward_from=0):
+        """(value logits, reward logits or None, policy logits) of a hidden state -- or of `groups` stacked batches of hidden
+        states, the reward head from row `reward_from` on (the initial inference has none)."""
         chains = [self.value, self.reward if with_reward else None, self.actor]
+        rows = state.shape[0] // groups
+        inputs = [(state, groups), (state[reward_from:], groups - reward_from // rows), (state, groups)]
         if self._head_streams is None:
-            return [None if c is None else self._run(c, state) for c in chains]
+            return [None if c is None else self._run(c, *i) for c, i in zip(chains, inputs)]
         cur = torch.cuda.current_stream(state.device)
         outs = []
-        for c, st in zip(chains, self._head_streams):
+        for c, st, i in zip(chains, self._head_streams, inputs):
             if c is None or st is None:
-                outs.append(None if c is None else self._run(c, state))
+                outs.append(None if c is None else self._run(c, *i))
                 continue
             st.wait_stream(cur)
             with torch.cuda.stream(st):
-                outs.append(self._run(c, state))
+                outs.append(self._run(c, *i))
         for c, st in zip(chains, self._head_streams):
             if c is not None and st is not None:
                 cur.wait_stream(st)
@@ -300,7 +389,7 @@ class FusedTrainNet:
         value, _, policy = self._heads(state, False)
         return NetworkOutput(value, [0.0] * obs.shape[0], policy, state)
 
-    def recurrent_inference(self, hidden_state, action):  # core/model.py:74-84, training branch
+    def _dynamics(self, hidden_state, action):  # config/hanabi_control/model.py:61-125 behind the one-hot concat of :215-219
         B = hidden_state.shape[0]
         one_hot = torch.zeros(B, self.A, dtype=self.dtype, device=hidden_state.device)
         one_hot.scatter_(1, action, 1.0)
@@ -308,6 +397,9 @@ class FusedTrainNet:
         sa = torch.cat((hidden_state, one_hot), 1)
         y = _LinBNAct.apply(sa, hidden_state if early else None, b1, True)
         y = _LinBNAct.apply(y, None, b2, True)
-        state = _LinBNAct.apply(y, None if early else hidden_state, b3, True)
+        return _LinBNAct.apply(y, None if early else hidden_state, b3, True)
+
+    def recurrent_inference(self, hidden_state, action):  # core/model.py:74-84, training branch
+        state = self._dynamics(hidden_state, action)
         value, reward, policy = self._heads(state, True)
         return NetworkOutput(value, reward, policy, state)

@@ -39,6 +39,23 @@ int hz_bn_act_backward(const void* dout, int64_t dout_stride, const void* out, i
                        void* dx, int64_t dx_stride, void* dres, int64_t dres_stride, int rows, int cols, const float* gamma,
                        const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, int relu, int dtype, void* stream);
 
+/* The same two over `groups` row groups of `rows` rows each, stacked in x / res / out (dout / dx / dres): every group is normalised by
+ * its OWN batch statistics -- one BatchNorm call of the module per group -- in one launch (grid: column tiles x groups).  That is
+ * what lets a head of the unrolled learner step run ONCE over the stacked hidden states of all its inferences ((1 + unroll) x batch
+ * rows: one GEMM instead of six) with the arithmetic of six calls.  save_mean / save_invstd: [groups][cols].  The running statistics
+ * take the groups' batches in group order (r <- (1 - m) r + m s_g, g = 0 .. groups - 1), dgamma / dbeta the groups' sums in group
+ * order: done by the LAST workgroup of a column tile to arrive (tickets[tile], zero before the first launch and left zero; the groups'
+ * contributions meet in scratch [groups][2][cols] fp32), so the bits do not depend on the schedule.  groups == 1: scratch / tickets
+ * may be NULL. */
+int hz_bn_act_forward_groups(const void* x, int64_t x_stride, const void* res, int64_t res_stride, void* out, int64_t out_stride, int rows,
+                             int groups, int cols, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                             float momentum, float eps, float* save_mean, float* save_invstd, float* scratch, int* tickets, int relu,
+                             int dtype, void* stream);
+int hz_bn_act_backward_groups(const void* dout, int64_t dout_stride, const void* out, int64_t out_stride, const void* x, int64_t x_stride,
+                              void* dx, int64_t dx_stride, void* dres, int64_t dres_stride, int rows, int groups, int cols,
+                              const float* gamma, const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
+                              float* scratch, int* tickets, int relu, int dtype, void* stream);
+
 /* The losses of ONE inference of the unrolled learner step (initial or recurrent; core/train.py:145-168, 196-216 with
  * config/hanabi_control/__init__.py:119-123 and core/config.py:192-253) in one launch, gradients included:
  *   value / reward   cross-entropy of the categorical head (logits [rows][support_size], 16-bit or fp32) against the two-hot
@@ -58,6 +75,19 @@ int hz_muzero_head_losses(const void* value_logits, int64_t value_stride, const 
                           int64_t target_policy_stride, const float* weights, float value_coeff, float reward_coeff, float policy_coeff,
                           void* d_value, void* d_reward, void* d_policy, float* losses /* [rows][4] */, float* preds /* [rows][2] */,
                           void* stream);
+
+/* hz_muzero_head_losses for ALL inferences of the unrolled step in one launch: logit rows stacked inference by inference
+ * (value / policy: steps x batch rows, row k * batch + b; reward: (steps - 1) x batch rows -- the initial inference has no reward
+ * head), targets indexed [b][k] through a batch stride and a step stride each (target_reward's k counts from the first recurrent
+ * inference), weights [batch]; a row's total is weight[b] / batch * (...), as one call per inference gives it.  losses / preds /
+ * d_*: stacked like their logits.  steps == 1 is hz_muzero_head_losses. */
+int hz_muzero_unrolled_losses(const void* value_logits, int64_t value_stride, const void* reward_logits, int64_t reward_stride,
+                              const void* policy_logits, int64_t policy_stride, int batch, int steps, int support_size, int support_min,
+                              int num_actions, int dtype, const float* target_value, int64_t target_value_stride,
+                              int64_t target_value_step_stride, const float* target_reward, int64_t target_reward_stride,
+                              int64_t target_reward_step_stride, const float* target_policy, int64_t target_policy_stride,
+                              int64_t target_policy_step_stride, const float* weights, float value_coeff, float reward_coeff,
+                              float policy_coeff, void* d_value, void* d_reward, void* d_policy, float* losses, float* preds, void* stream);
 
 #ifdef __cplusplus
 }

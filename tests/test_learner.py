@@ -598,3 +598,136 @@ def test_head_losses_kernel_against_fp32_reference(dtype, V, smin, A, with_rewar
     assert torch.allclose(P[:, 0], inverse_scalar_transform(value.float(), smin, smin + V - 1).reshape(-1), rtol=1e-4, atol=1e-4)
     if with_reward:
         assert torch.allclose(P[:, 1], inverse_scalar_transform(reward.float(), smin, smin + V - 1).reshape(-1), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("rows,groups,cols,relu,with_res", [(256, 6, 256, True, False), (256, 5, 512, True, True), (37, 3, 201, False, True),
+                                                            (300, 2, 40, True, False)])
+def test_grouped_bn_act_kernels_equal_one_call_per_group(dtype, rows, groups, cols, relu, with_res):
+    """hz_bn_act_forward_groups / _backward_groups over `groups` stacked batches == one hz_bn_act_forward / _backward call per
+    batch, in order, on the same running statistics and gradient accumulators: outputs, saved statistics, running statistics,
+    input / residual gradients and the accumulated affine gradients, bit for bit (twice in a row: the tickets return to zero)."""
+    import ctypes as C
+    from hanabizero_amd._lib import check, lib
+    g = torch.Generator(device="cuda").manual_seed(rows * cols + groups)
+    R = rows * groups
+    x = (torch.randn(R, cols, device="cuda", generator=g) * 1.7 + 0.3).to(dtype)
+    res = torch.randn(R, cols, device="cuda", generator=g).to(dtype) if with_res else None
+    gamma = torch.rand(cols, device="cuda", generator=g) + 0.5
+    beta = torch.randn(cols, device="cuda", generator=g) * 0.2
+    dout = torch.randn(R, cols, device="cuda", generator=g).to(dtype)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    dt = {torch.bfloat16: 1, torch.float16: 2}[dtype]
+    ptr = lambda t: None if t is None else t.data_ptr()
+    scratch = torch.full((groups, 2, cols), float("nan"), device="cuda")
+    tickets = torch.zeros((cols + 7) // 8, dtype=torch.int32, device="cuda")
+    rm0, rv0 = torch.randn(cols, device="cuda", generator=g) * 0.1, torch.rand(cols, device="cuda", generator=g) + 0.5
+    rm_a, rv_a, rm_b, rv_b = rm0.clone(), rv0.clone(), rm0.clone(), rv0.clone()
+    dg_a, db_a = torch.full((cols,), 0.5, device="cuda"), torch.full((cols,), -0.25, device="cuda")
+    dg_b, db_b = dg_a.clone(), db_a.clone()
+    for _ in range(2):
+        out_a, stats_a = torch.empty_like(x), torch.empty(2, groups, cols, device="cuda")
+        out_b, stats_b = torch.empty_like(x), torch.empty(2, groups, cols, device="cuda")
+        check(lib.hz_bn_act_forward_groups(x.data_ptr(), cols, ptr(res), cols, out_a.data_ptr(), cols, rows, groups, cols, gamma.data_ptr(), beta.data_ptr(),
+                                           rm_a.data_ptr(), rv_a.data_ptr(), 0.1, 1e-5, stats_a[0].data_ptr(), stats_a[1].data_ptr(), scratch.data_ptr(),
+                                           tickets.data_ptr(), int(relu), dt, st), "fwd groups")
+        for k in range(groups):
+            s = slice(k * rows, (k + 1) * rows)
+            check(lib.hz_bn_act_forward(x[s].data_ptr(), cols, ptr(None if res is None else res[s]), cols, out_b[s].data_ptr(), cols, rows, cols,
+                                        gamma.data_ptr(), beta.data_ptr(), rm_b.data_ptr(), rv_b.data_ptr(), 0.1, 1e-5, stats_b[0, k].data_ptr(),
+                                        stats_b[1, k].data_ptr(), int(relu), dt, st), "fwd")
+        assert torch.equal(out_a.view(torch.int16), out_b.view(torch.int16)) and torch.equal(stats_a, stats_b)
+        assert torch.equal(rm_a, rm_b) and torch.equal(rv_a, rv_b) and int(tickets.abs().sum()) == 0
+        dx_a, dx_b = torch.empty_like(x), torch.empty_like(x)
+        dr_a, dr_b = (torch.empty_like(x), torch.empty_like(x)) if with_res else (None, None)
+        check(lib.hz_bn_act_backward_groups(dout.data_ptr(), cols, out_a.data_ptr(), cols, x.data_ptr(), cols, dx_a.data_ptr(), cols, ptr(dr_a), cols, rows,
+                                            groups, cols, gamma.data_ptr(), stats_a[0].data_ptr(), stats_a[1].data_ptr(), dg_a.data_ptr(), db_a.data_ptr(),
+                                            scratch.data_ptr(), tickets.data_ptr(), int(relu), dt, st), "bwd groups")
+        acc_g, acc_b = torch.zeros(cols, device="cuda"), torch.zeros(cols, device="cuda")
+        for k in range(groups):   # (the grouped kernel adds the groups' sums up first, then adds the total to the accumulator)
+            s = slice(k * rows, (k + 1) * rows)
+            one_g, one_b = torch.zeros(cols, device="cuda"), torch.zeros(cols, device="cuda")
+            check(lib.hz_bn_act_backward(dout[s].data_ptr(), cols, out_b[s].data_ptr(), cols, x[s].data_ptr(), cols, dx_b[s].data_ptr(), cols,
+                                         ptr(None if dr_b is None else dr_b[s]), cols, rows, cols, gamma.data_ptr(), stats_b[0, k].data_ptr(),
+                                         stats_b[1, k].data_ptr(), one_g.data_ptr(), one_b.data_ptr(), int(relu), dt, st), "bwd")
+            acc_g, acc_b = acc_g + one_g, acc_b + one_b
+        dg_b, db_b = dg_b + acc_g, db_b + acc_b
+        assert torch.equal(dx_a.view(torch.int16), dx_b.view(torch.int16)) and int(tickets.abs().sum()) == 0
+        assert torch.equal(dg_a, dg_b) and torch.equal(db_a, db_b)
+        if with_res:
+            assert torch.equal(dr_a.view(torch.int16), dr_b.view(torch.int16))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_unrolled_losses_equal_one_launch_per_inference(dtype):
+    """hz_muzero_unrolled_losses (_UnrolledLosses: every inference of the unrolled step in one launch, targets read through their
+    strides) == hz_muzero_head_losses per inference (_HeadLosses) on the same logits: losses, predictions, row totals and the
+    gradients of all three heads' logits, bit for bit."""
+    import types
+    from hanabizero_amd.fused_train import _HeadLosses, _UnrolledLosses
+    B, U, V, smin, A = 77, 5, 201, -100, 48
+    g = torch.Generator(device="cuda").manual_seed(5)
+    mk = lambda *s: (torch.randn(*s, device="cuda", generator=g) * 2).to(dtype)
+    value, reward, policy = mk((U + 1) * B, V), mk(U * B, V), mk((U + 1) * B, A)
+    tv = torch.rand(B, U + 1, device="cuda", generator=g) * 60 - 20
+    tr = torch.randint(-3, 4, (B, U), device="cuda", generator=g).float()
+    tp = torch.rand(B, U + 1, A, device="cuda", generator=g)
+    tp = tp / tp.sum(-1, keepdim=True)
+    tp[5:9, 3:] = 0.0
+    weights = torch.rand(B, device="cuda", generator=g) + 0.5
+    support = types.SimpleNamespace(min=smin, max=smin + V - 1, size=V)
+    coeffs = (0.25, 1.0, 1.0)
+    va, ra, pa = (t.clone().requires_grad_(True) for t in (value, reward, policy))
+    tot, L, P = _UnrolledLosses.apply(va, ra, pa, tv, tr, tp, weights, support, coeffs)
+    up = torch.rand((U + 1) * B, device="cuda", generator=g)   # (an upstream gradient that differs per row)
+    (tot * up).sum().backward()
+    vb, rb, pb = (t.clone().requires_grad_(True) for t in (value, reward, policy))
+    tots, Ls, Ps = [], [], []
+    for k in range(U + 1):
+        s = slice(k * B, (k + 1) * B)
+        t, l, p = _HeadLosses.apply(vb[s], rb[(k - 1) * B:k * B] if k else None, pb[s], tv[:, k], tr[:, k - 1] if k else None, tp[:, k], weights,
+                                    support, coeffs)
+        tots.append(t), Ls.append(l), Ps.append(p)
+    (torch.cat(tots) * up).sum().backward()
+    assert torch.equal(tot, torch.cat(tots)) and torch.equal(L, torch.cat(Ls)) and torch.equal(P, torch.cat(Ps))
+    for a, b in ((va, vb), (ra, rb), (pa, pb)):   # (as numbers: adding the slices' zero-filled gradients up turns a -0 into +0)
+        assert torch.equal(a.grad, b.grad) and not bool(torch.isnan(a.grad).any())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("game,stack", [("Hanabi-Small", 2), ("Hanabi-Full-5p", 4)])
+def test_stacked_heads_equal_the_heads_inference_by_inference(game, stack):
+    """FusedTrainNet.compute_losses (the three heads once over the stacked hidden states of all inferences, every BatchNorm batch
+    with its own statistics) against compute_losses_stepwise (initial_inference / recurrent_inference as the module is called):
+    the same function of the same weights -- losses and priorities to 16-bit GEMM rounding (another row count, another summation
+    order inside the library), gradients in the same direction, the same running statistics and counters."""
+    import copy
+    from hanabizero_amd.fused_train import FusedTrainNet
+    from hanabizero_amd.learner import make_optimizer, update_weights
+    cfg = _cfg(game, stack)
+    torch.manual_seed(11)
+    net = cfg.get_uniform_network()
+    for p in net.parameters():
+        if float(p.detach().abs().sum()) == 0.0:
+            torch.nn.init.normal_(p, std=0.05)
+    net = net.cuda()
+    net2 = copy.deepcopy(net)
+    batch = _batch(cfg, 64, 11)
+    a, b = FusedTrainNet(net, unroll_steps=cfg.num_unroll_steps), FusedTrainNet(net2, unroll_steps=cfg.num_unroll_steps)
+    b.compute_losses = b.compute_losses_stepwise
+    l1, p1 = update_weights(a, batch, make_optimizer(net, cfg), cfg, amp=torch.bfloat16)
+    l2, p2 = update_weights(b, batch, make_optimizer(net2, cfg), cfg, amp=torch.bfloat16)
+    assert np.allclose(l1, l2, rtol=5e-3, atol=5e-4), (l1, l2)
+    assert np.allclose(p1, p2, rtol=2e-2, atol=2e-2)
+    cosine = lambda u, v: float((u * v).sum() / (u.norm() * v.norm() + 1e-30))
+    for (n, u), v in zip(net.named_parameters(), net2.parameters()):
+        if float(u.grad.norm()) < 1e-6 and float(v.grad.norm()) < 1e-6:
+            continue
+        assert cosine(u.grad, v.grad) > 0.98 and 0.95 < float(u.grad.norm() / v.grad.norm()) < 1.05, (n, cosine(u.grad, v.grad))
+    for (n, u), v in zip(net.state_dict().items(), net2.state_dict().values()):
+        if n.endswith("num_batches_tracked"):
+            assert int(u) == int(v), n
+        else:
+            assert torch.allclose(u, v, rtol=5e-3, atol=5e-4), (n, float((u - v).abs().max()))

@@ -21,7 +21,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--game", default="Hanabi-Full-5p")
     ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--parallel-heads", type=int, default=None, help="--fused: head chains on streams of their own (FusedTrainNet)")
+    ap.add_argument("--parallel-heads", type=int, default=0, help="--fused: head chains on streams of their own (FusedTrainNet)")
     ap.add_argument("--fused", action="store_true", help="the module forward through the fused Linear + BatchNorm + ReLU blocks (hanabizero_amd/fused_train.py)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)

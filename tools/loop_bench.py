@@ -58,7 +58,7 @@ def main():
     ap.add_argument("--share-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--learner-acts", action="store_true", help="N > 1: rank 0 plays too (default: it only learns)")
     ap.add_argument("--actor-stream", default="null", choices=["null", "normal", "low"], help="the stream the lock-steps run on")
-    ap.add_argument("--parallel-heads", type=int, default=None, help="head chains of the learner's inferences on streams of their own (FusedTrainNet)")
+    ap.add_argument("--parallel-heads", type=int, default=0, help="head chains of the learner's inferences on streams of their own (FusedTrainNet)")
     ap.add_argument("--one-host-thread", action="store_true", help="the learner half of a step enqueued by the thread that prepares the batches (default: by a second one)")
     ap.add_argument("--eager-blocks", action="store_true", help="the learner's module forward through PyTorch autograd under autocast instead of the fused Linear + BatchNorm + ReLU blocks (include/hz_train.h)")
     args = ap.parse_args()
