@@ -409,14 +409,18 @@ class _Slot:
 
 class LearnerPipeline:
     """What the reference spreads over BatchWorker_CPU x cpu_actor, BatchWorker_GPU x gpu_actor, the BatchStorage queue and
-    the learner process (/root/reference/core/train.py:317-431, 440-481; core/reanalyze_worker.py:402-440) as two streams of ONE
+    the learner process (/root/reference/core/train.py:317-431, 440-481; core/reanalyze_worker.py:402-440) as streams of ONE
     GPU with nothing on the host but the enqueueing:
 
-        prepare stream   priorities of step k - 2 back into the replay -> sample ids / weights -> re-searched policy targets for the
-                         first R rows with the TARGET model (policy_re_device) -> DeviceReplay.assemble into slot k % 2
+        prepare stream   priorities of step k - 3 back into the replay -> sample ids / weights -> DeviceReplay.assemble into slot
+                         k % 3 (value targets with the TARGET model) -> the re-search's inputs: everything that touches the replay
+        re-search stream k % 2: policy targets for the first R rows re-searched with the TARGET model (policy_re_device) -- 768 roots
+                         x 49 simulations are one latency-bound launch on a fifth of the GPU (1.4 of a batch's ~3 ms), so two
+                         consecutive batches' searches run side by side
         learner stream   slot -> the captured step's static inputs -> lr -> GraphedUpdate.run -> new priorities into the slot
 
-    so batch k + 1 is searched and assembled while step k trains (the reference's queue of prepared batches, depth 2).
+    so batches k + 1 and k + 2 are searched and assembled while step k trains (the reference's queue of prepared batches, depth 3).
+    (research_streams=0: the re-search on the prepare stream, two slots -- r04's first form.)
     Cadences as train.py:392-398: `on_checkpoint(step)` every checkpoint_interval steps (the caller hands the weights to the
     actors), the target model takes the learner's weights of one target_model_interval ago every target_model_interval steps.
     Nothing synchronises the host; `losses()` reads the last step's loss tuple (one small read-back) when somebody wants it.
@@ -427,7 +431,7 @@ class LearnerPipeline:
     either way; `flush()` before touching `learn` or a slot's `done` event from outside."""
 
     def __init__(self, config, replay, model, target_engine, batch_size=None, reanalyze_share=0.5, amp=torch.bfloat16, beta=0.4,
-                 on_checkpoint=None, seed=0, host_thread=True):
+                 on_checkpoint=None, seed=0, host_thread=True, research_streams=2):
         from .device_replay import policy_re_device
         self._policy_re = policy_re_device
         self.cfg, self.replay, self.model, self.target = config, replay, model, target_engine
@@ -440,12 +444,13 @@ class LearnerPipeline:
         U, A = config.num_unroll_steps, config.action_space_size
         self.Dp = target_engine.pad_observations(replay.D, replay.stack)
         win = (self.B * (U + 1), replay.stack * self.Dp)
-        self.slots = [_Slot(self.graphed, self.R, U, A, win, target_engine.dtype) for _ in range(2)]
         self.prep, self.learn = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        self.side = [torch.cuda.Stream(device=dev) for _ in range(research_streams if self.R else 0)]
+        self.slots = [_Slot(self.graphed, self.R, U, A, win, target_engine.dtype) for _ in range(3 if self.side else 2)]
         self.steps = 0
         self.host_wait_s = 0.0                  # what the host spent waiting for a slot (the GPU being the slower side)
         self._recent = None
-        self._re_roots = None
+        self._re_roots = {}
         self.gen = torch.Generator(device=dev)
         self.gen.manual_seed(int(seed))
         import copy
@@ -454,6 +459,8 @@ class LearnerPipeline:
         cur = torch.cuda.current_stream(dev)
         self.prep.wait_stream(cur)
         self.learn.wait_stream(cur)
+        for st in self.side:
+            st.wait_stream(cur)
         with torch.cuda.stream(self.learn):
             self.graphed._capture()             # (now, not inside the first step: a capture synchronises the device)
         self.prep_interference_ms = None
@@ -551,23 +558,27 @@ class LearnerPipeline:
     def step(self):
         """Enqueue learner step number self.steps (both halves).  Returns nothing; never blocks the host."""
         cfg, rp, k = self.cfg, self.replay, self.steps
-        slot = self.slots[k % 2]
+        ns = len(self.slots)
+        slot = self.slots[k % ns]
         if self._error is not None:
             self.flush()
         if slot.used:
             import time
-            slot.enqueued.wait()                # (step k - 2's learner half has been enqueued: `done` is that step's)
+            slot.enqueued.wait()                # (step k - ns's learner half has been enqueued: `done` is that step's)
             t0 = time.perf_counter()
-            slot.done.synchronize()             # (back-pressure: the host enqueues at most two steps ahead of the one training)
+            slot.done.synchronize()             # (back-pressure: the host enqueues at most `ns` steps ahead of the one training)
             self.host_wait_s += time.perf_counter() - t0
+        side = self.side[k % len(self.side)] if self.side else None
         with torch.cuda.stream(self.prep), torch.no_grad():
-            if slot.used:                       # step k - 2 has trained on this slot: its priorities go back, the slot is free
+            if slot.used:                       # step k - ns has trained on this slot: its priorities go back, the slot is free
                 self.prep.wait_event(slot.done)
                 rp.update_priorities(slot.ids, slot.priority)
             if k % cfg.target_model_interval == 0 and k > 0:   # train.py:396-398
-                prev = self.slots[(k - 1) % 2]
+                prev = self.slots[(k - 1) % ns]
                 prev.enqueued.wait()
                 self.prep.wait_event(prev.done)                # (the learner's weights as of step k - 1 are complete)
+                for st in self.side:
+                    self.prep.wait_stream(st)                  # (no re-search with the old target model is still running)
                 self.target.load(self._recent_net)
                 self._recent_net.load_state_dict(self.net.state_dict())
                 self._weights_taken = torch.cuda.Event()
@@ -579,14 +590,25 @@ class LearnerPipeline:
             inside = rp.assemble(ids, self._value_fn, slot, value_windows=slot.value_windows, slot_elems=self.Dp)
             if self.R:
                 legal, mask = rp.policy_re_inputs(ids[:self.R], slot.re_windows, slot_elems=self.Dp)
-                if self._re_roots is None:
-                    from . import cytree
-                    self._re_roots = cytree.Roots(slot.re_windows.shape[0], cfg.action_space_size, cfg.num_simulations,
-                                                  device=slot.obs.device)
-                pol = self._policy_re(cfg, self.target, slot.re_windows, legal, mask, generator=self.gen, tie_seed=k,
-                                      padded=self.Dp != rp.D, roots=self._re_roots)
-                slot.target_policy[:self.R] = pol.view(self.R, cfg.num_unroll_steps + 1, -1)   # [reanalyzed | stored], :412-419
-            slot.ready.record(self.prep)
+            if self.R and side is not None:
+                inputs_ready = torch.cuda.Event()
+                inputs_ready.record(self.prep)
+            with torch.cuda.stream(side if (self.R and side is not None) else self.prep):
+                if self.R:
+                    where = torch.cuda.current_stream(slot.obs.device)
+                    if side is not None:
+                        side.wait_event(inputs_ready)
+                        legal.record_stream(side)              # (allocated on the prepare stream, read here)
+                        mask.record_stream(side)
+                    roots = self._re_roots.get(where.cuda_stream)
+                    if roots is None:                          # (one tree pool per stream that searches)
+                        from . import cytree
+                        roots = self._re_roots[where.cuda_stream] = cytree.Roots(slot.re_windows.shape[0], cfg.action_space_size,
+                                                                                  cfg.num_simulations, device=slot.obs.device)
+                    pol = self._policy_re(cfg, self.target, slot.re_windows, legal, mask, generator=self.gen, tie_seed=k,
+                                          padded=self.Dp != rp.D, roots=roots)
+                    slot.target_policy[:self.R] = pol.view(self.R, cfg.num_unroll_steps + 1, -1)   # [reanalyzed | stored], :412-419
+                slot.ready.record(torch.cuda.current_stream(slot.obs.device))
         if self._thread is not None:
             slot.enqueued.clear()
             self._queue.put((slot, k))

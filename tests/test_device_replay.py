@@ -212,8 +212,8 @@ def test_policy_re_on_the_device_equals_the_host_context_path():
 
 
 def test_learner_pipeline_equals_its_single_stream_schedule():
-    """learner.LearnerPipeline (two streams fed by two host threads, batch k + 1 prepared while step k trains, priorities written
-    back two steps later, target model refreshed one interval behind) leaves the same weights, priorities and target model as the SAME sequence of
+    """learner.LearnerPipeline (prepare / re-search x 2 / learner streams fed by two host threads, batches k + 1 and k + 2 prepared
+    while step k trains, priorities written back three steps later, target model refreshed one interval behind) leaves the same weights, priorities and target model as the SAME sequence of
     operations enqueued on one stream -- where ordering is trivially right: any missing event between the streams shows here."""
     import copy
     from hanabizero_amd.learner import LearnerPipeline
@@ -231,6 +231,7 @@ def test_learner_pipeline_equals_its_single_stream_schedule():
                                host_thread=pipelined)
         if not pipelined:
             pipe.prep = pipe.learn = torch.cuda.current_stream()
+            pipe.side = [torch.cuda.current_stream()] * len(pipe.side)
         for _ in range(11):
             pipe.step()
         pipe.flush()

@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--learner-acts", action="store_true", help="N > 1: rank 0 plays too (default: it only learns)")
     ap.add_argument("--actor-stream", default="null", choices=["null", "normal", "low"], help="the stream the lock-steps run on")
     ap.add_argument("--parallel-heads", type=int, default=0, help="head chains of the learner's inferences on streams of their own (FusedTrainNet)")
+    ap.add_argument("--research-streams", type=int, default=2, help="streams the batches' re-searches alternate on (0: on the prepare stream, two batch slots)")
     ap.add_argument("--one-host-thread", action="store_true", help="the learner half of a step enqueued by the thread that prepares the batches (default: by a second one)")
     ap.add_argument("--eager-blocks", action="store_true", help="the learner's module forward through PyTorch autograd under autocast instead of the fused Linear + BatchNorm + ReLU blocks (include/hz_train.h)")
     args = ap.parse_args()
@@ -121,7 +122,7 @@ def main():
         def on_checkpoint(step, done_event):
             handover["pending"], handover["event"] = True, done_event
         pipe = LearnerPipeline(cfg, replay, learner, target, batch_size=cfg.batch_size, reanalyze_share=args.reanalyze_share,
-                               on_checkpoint=on_checkpoint, host_thread=not args.one_host_thread)
+                               on_checkpoint=on_checkpoint, host_thread=not args.one_host_thread, research_streams=args.research_streams)
     A = cfg.action_space_size
     W = (cfg.obs_dim + 31) // 32
 
@@ -244,7 +245,7 @@ def main():
     wall = float(wall_t)
     # one weight hand-over timed on its own
     if learns:
-        handover["event"] = pipe.slots[(pipe.steps - 1) % 2].done if pipe.steps else torch.cuda.Event()
+        handover["event"] = pipe.slots[(pipe.steps - 1) % len(pipe.slots)].done if pipe.steps else torch.cuda.Event()
         if not pipe.steps:
             handover["event"].record(pipe.learn)
     handover_each = []
