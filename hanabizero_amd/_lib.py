@@ -31,6 +31,11 @@ class MlpHeader(C.Structure):  # include/hz_mlp.h hz_mlp_header_t
                 ("kstep_stride", C.c_int64), ("wave_stream_off", C.c_int64 * 16)]
 
 
+class BnFinish(C.Structure):  # include/hz_train.h hz_bn_finish_t
+    _fields_ = [("dst0", C.c_void_p), ("dst1", C.c_void_p), ("scratch", C.c_void_p), ("cols", C.c_int32), ("groups", C.c_int32),
+                ("momentum", C.c_float), ("reserved", C.c_int32)]
+
+
 class RowsJob(C.Structure):  # include/hz_rows.h hz_rows_job_t
     _fields_ = [("slot", C.c_void_p), ("list", C.c_void_p), ("count", C.c_void_p), ("num_arrays", C.c_int32),
                 ("max_rows", C.c_int32), ("src", C.c_void_p * 8), ("dst", C.c_void_p * 8), ("row_bytes", C.c_int64 * 8)]
@@ -114,8 +119,9 @@ def _load():
         # include/hz_train.h
         "hz_bn_act_forward": [V, I64, V, I64, V, I64, I, I, V, V, V, V, F, F, V, V, I, I, V],
         "hz_bn_act_backward": [V, I64, V, I64, V, I64, V, I64, V, I64, I, I, V, V, V, V, V, I, I, V],
-        "hz_bn_act_forward_groups": [V, I64, V, I64, V, I64, I, I, I, V, V, V, V, F, F, V, V, V, V, I, I, V],
-        "hz_bn_act_backward_groups": [V, I64, V, I64, V, I64, V, I64, V, I64, I, I, I, V, V, V, V, V, V, V, I, I, V],
+        "hz_bn_act_forward_groups": [V, I64, V, I64, V, I64, I, I, I, V, V, V, V, F, F, V, V, V, I, I, V],
+        "hz_bn_act_backward_groups": [V, I64, V, I64, V, I64, V, I64, V, I64, I, I, I, V, V, V, V, V, V, I, I, V],
+        "hz_bn_groups_finish": [V, I, I, I, V],
         "hz_muzero_head_losses": [V, I64, V, I64, V, I64, I, I, I, I, I, V, I64, V, I64, V, I64, V, F, F, F, V, V, V, V, V, V],
         "hz_muzero_unrolled_losses": [V, I64, V, I64, V, I64, I, I, I, I, I, I, V, I64, I64, V, I64, I64, V, I64, I64, V, F, F, F, V, V, V, V, V, V],
         # include/hz_netglue.h

@@ -77,9 +77,8 @@ __global__ __launch_bounds__(256) void k_bn_act_forward(const uint16_t* __restri
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
                                                         float* __restrict__ smean, float* __restrict__ sinv, int relu, int vec,
-                                                        float* __restrict__ scratch, int* __restrict__ tickets) {
+                                                        float* __restrict__ scratch) {
   __shared__ float4 s_r[4][4];
-  __shared__ int s_last;
   const int g = threadIdx.x >> 2, p = threadIdx.x & 3, c = blockIdx.x * TR_COLS + 2 * p;
   const bool on = c < cols, both = vec && c + 1 < cols, on1 = c + 1 < cols;
   // blockIdx.y = the row group: `rows` consecutive rows normalised by their own statistics (one BatchNorm call of the module each)
@@ -144,34 +143,12 @@ __global__ __launch_bounds__(256) void k_bn_act_forward(const uint16_t* __restri
         rmean[c + 1] = (1.0f - momentum) * rmean[c + 1] + momentum * mean.y;
         rvar[c + 1] = (1.0f - momentum) * rvar[c + 1] + momentum * (var.y * ub);
       }
-    } else {  // the running statistics take the groups' batches one after the other, as the module's G calls would: by the last workgroup
+    } else {  // the running statistics take the groups' batches one after the other, as the module's G calls would: hz_bn_groups_finish
       scratch[((long long)gy * 2 + 0) * cols + c] = mean.x;
       scratch[((long long)gy * 2 + 1) * cols + c] = var.x * ub;
       if (on1) {
         scratch[((long long)gy * 2 + 0) * cols + c + 1] = mean.y;
         scratch[((long long)gy * 2 + 1) * cols + c + 1] = var.y * ub;
-      }
-    }
-  }
-  if (G > 1) {
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const int t = atomicAdd(&tickets[blockIdx.x], 1);
-      s_last = t == G - 1;
-      if (s_last) tickets[blockIdx.x] = 0;  // (ready for the next launch)
-    }
-    __syncthreads();
-    if (s_last && on && g == 0) {
-      __threadfence();
-      for (int e = 0; e < (on1 ? 2 : 1); ++e) {
-        float rm = rmean[c + e], rv = rvar[c + e];
-        for (int k = 0; k < G; ++k) {
-          rm = (1.0f - momentum) * rm + momentum * __hip_atomic_load(scratch + ((long long)k * 2 + 0) * cols + c + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          rv = (1.0f - momentum) * rv + momentum * __hip_atomic_load(scratch + ((long long)k * 2 + 1) * cols + c + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        rmean[c + e] = rm;
-        rvar[c + e] = rv;
       }
     }
   }
@@ -206,9 +183,8 @@ __global__ __launch_bounds__(256) void k_bn_act_backward(const uint16_t* __restr
                                                          long long drs, int rows, int cols, const float* __restrict__ gamma,
                                                          const float* __restrict__ smean, const float* __restrict__ sinv,
                                                          float* __restrict__ dgamma, float* __restrict__ dbeta, int relu, int vec,
-                                                         float* __restrict__ scratch, int* __restrict__ tickets) {
+                                                         float* __restrict__ scratch) {
   __shared__ float4 s_r[4][4];
-  __shared__ int s_last;
   const int g = threadIdx.x >> 2, p = threadIdx.x & 3, c = blockIdx.x * TR_COLS + 2 * p;
   const bool on = c < cols, both = vec && c + 1 < cols, on1 = c + 1 < cols;
   const int gy = blockIdx.y, G = gridDim.y;  // row groups as in the forward kernel
@@ -263,34 +239,12 @@ __global__ __launch_bounds__(256) void k_bn_act_backward(const uint16_t* __restr
     if (G == 1) {
       dbeta[c] += s1.x; dgamma[c] += s2.x;
       if (on1) { dbeta[c + 1] += s1.y; dgamma[c + 1] += s2.y; }
-    } else {  // the groups' sums added up in the order of the groups by the last workgroup: the same bits whatever the schedule
+    } else {  // the groups' sums are added up in the order of the groups (the same bits whatever the schedule): hz_bn_groups_finish
       scratch[((long long)gy * 2 + 0) * cols + c] = s1.x;
       scratch[((long long)gy * 2 + 1) * cols + c] = s2.x;
       if (on1) {
         scratch[((long long)gy * 2 + 0) * cols + c + 1] = s1.y;
         scratch[((long long)gy * 2 + 1) * cols + c + 1] = s2.y;
-      }
-    }
-  }
-  if (G > 1) {
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const int t = atomicAdd(&tickets[blockIdx.x], 1);
-      s_last = t == G - 1;
-      if (s_last) tickets[blockIdx.x] = 0;
-    }
-    __syncthreads();
-    if (s_last && on && g == 0) {
-      __threadfence();
-      for (int e = 0; e < (on1 ? 2 : 1); ++e) {
-        float b = 0.0f, a = 0.0f;
-        for (int k = 0; k < G; ++k) {
-          b += __hip_atomic_load(scratch + ((long long)k * 2 + 0) * cols + c + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          a += __hip_atomic_load(scratch + ((long long)k * 2 + 1) * cols + c + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        dbeta[c + e] += b;
-        dgamma[c + e] += a;
       }
     }
   }
@@ -320,15 +274,15 @@ extern "C" int hz_bn_act_forward(const void* x, int64_t x_stride, const void* re
                                  int cols, const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
                                  float eps, float* save_mean, float* save_invstd, int relu, int dtype, void* stream) {
   return hz_bn_act_forward_groups(x, x_stride, res, res_stride, out, out_stride, rows, 1, cols, gamma, beta, running_mean, running_var, momentum,
-                                  eps, save_mean, save_invstd, nullptr, nullptr, relu, dtype, stream);
+                                  eps, save_mean, save_invstd, nullptr, relu, dtype, stream);
 }
 
 extern "C" int hz_bn_act_forward_groups(const void* x, int64_t x_stride, const void* res, int64_t res_stride, void* out, int64_t out_stride,
                                         int rows, int groups, int cols, const float* gamma, const float* beta, float* running_mean,
                                         float* running_var, float momentum, float eps, float* save_mean, float* save_invstd, float* scratch,
-                                        int* tickets, int relu, int dtype, void* stream) {
+                                        int relu, int dtype, void* stream) {
   HZ_REQUIRE(x && out && gamma && beta && running_mean && running_var && save_mean && save_invstd, "hz_bn_act_forward: null pointer");
-  HZ_REQUIRE(groups >= 1 && groups <= 1024 && (groups == 1 || (scratch && tickets)), "hz_bn_act_forward_groups: groups=%d (more than one needs scratch and tickets)", groups);
+  HZ_REQUIRE(groups >= 1 && groups <= 1024 && (groups == 1 || scratch), "hz_bn_act_forward_groups: groups=%d (more than one needs scratch)", groups);
   HZ_REQUIRE(rows >= 1 && cols >= 1 && x_stride >= cols && out_stride >= cols && (!res || res_stride >= cols),
              "hz_bn_act_forward: rows=%d cols=%d strides %lld / %lld / %lld", rows, cols, (long long)x_stride, (long long)out_stride, (long long)res_stride);
   HZ_REQUIRE(dtype == HZ_BF16 || dtype == HZ_F16, "hz_bn_act_forward: dtype %d (HZ_BF16 or HZ_F16)", dtype);
@@ -340,11 +294,11 @@ extern "C" int hz_bn_act_forward_groups(const void* x, int64_t x_stride, const v
   if (dtype == HZ_BF16)
     hipLaunchKernelGGL(k_bn_act_forward<HZ_BF16>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, (long long)x_stride, (const uint16_t*)res,
                        (long long)res_stride, (uint16_t*)out, (long long)out_stride, rows, cols, gamma, beta, running_mean, running_var, momentum, eps,
-                       save_mean, save_invstd, relu, vec, scratch, tickets);
+                       save_mean, save_invstd, relu, vec, scratch);
   else
     hipLaunchKernelGGL(k_bn_act_forward<HZ_F16>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, (long long)x_stride, (const uint16_t*)res,
                        (long long)res_stride, (uint16_t*)out, (long long)out_stride, rows, cols, gamma, beta, running_mean, running_var, momentum, eps,
-                       save_mean, save_invstd, relu, vec, scratch, tickets);
+                       save_mean, save_invstd, relu, vec, scratch);
   HZ_HIP(hipGetLastError());
   return 0;
 }
@@ -354,15 +308,15 @@ extern "C" int hz_bn_act_backward(const void* dout, int64_t dout_stride, const v
                                   const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, int relu, int dtype,
                                   void* stream) {
   return hz_bn_act_backward_groups(dout, dout_stride, out, out_stride, x, x_stride, dx, dx_stride, dres, dres_stride, rows, 1, cols, gamma, save_mean,
-                                   save_invstd, dgamma, dbeta, nullptr, nullptr, relu, dtype, stream);
+                                   save_invstd, dgamma, dbeta, nullptr, relu, dtype, stream);
 }
 
 extern "C" int hz_bn_act_backward_groups(const void* dout, int64_t dout_stride, const void* out, int64_t out_stride, const void* x,
                                          int64_t x_stride, void* dx, int64_t dx_stride, void* dres, int64_t dres_stride, int rows, int groups,
                                          int cols, const float* gamma, const float* save_mean, const float* save_invstd, float* dgamma,
-                                         float* dbeta, float* scratch, int* tickets, int relu, int dtype, void* stream) {
+                                         float* dbeta, float* scratch, int relu, int dtype, void* stream) {
   HZ_REQUIRE(dout && x && dx && gamma && save_mean && save_invstd && dgamma && dbeta && (out || !relu), "hz_bn_act_backward: null pointer");
-  HZ_REQUIRE(groups >= 1 && groups <= 1024 && (groups == 1 || (scratch && tickets)), "hz_bn_act_backward_groups: groups=%d (more than one needs scratch and tickets)", groups);
+  HZ_REQUIRE(groups >= 1 && groups <= 1024 && (groups == 1 || scratch), "hz_bn_act_backward_groups: groups=%d (more than one needs scratch)", groups);
   HZ_REQUIRE(rows >= 1 && cols >= 1 && dout_stride >= cols && x_stride >= cols && dx_stride >= cols && (!relu || out_stride >= cols) &&
                  (!dres || dres_stride >= cols),
              "hz_bn_act_backward: rows=%d cols=%d and a row stride below cols", rows, cols);
@@ -373,11 +327,44 @@ extern "C" int hz_bn_act_backward_groups(const void* dout, int64_t dout_stride, 
   if (dtype == HZ_BF16)
     hipLaunchKernelGGL(k_bn_act_backward<HZ_BF16>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dout, (long long)dout_stride,
                        (const uint16_t*)out, (long long)out_stride, (const uint16_t*)x, (long long)x_stride, (uint16_t*)dx, (long long)dx_stride,
-                       (uint16_t*)dres, (long long)dres_stride, rows, cols, gamma, save_mean, save_invstd, dgamma, dbeta, relu, vec, scratch, tickets);
+                       (uint16_t*)dres, (long long)dres_stride, rows, cols, gamma, save_mean, save_invstd, dgamma, dbeta, relu, vec, scratch);
   else
     hipLaunchKernelGGL(k_bn_act_backward<HZ_F16>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dout, (long long)dout_stride,
                        (const uint16_t*)out, (long long)out_stride, (const uint16_t*)x, (long long)x_stride, (uint16_t*)dx, (long long)dx_stride,
-                       (uint16_t*)dres, (long long)dres_stride, rows, cols, gamma, save_mean, save_invstd, dgamma, dbeta, relu, vec, scratch, tickets);
+                       (uint16_t*)dres, (long long)dres_stride, rows, cols, gamma, save_mean, save_invstd, dgamma, dbeta, relu, vec, scratch);
+  HZ_HIP(hipGetLastError());
+  return 0;
+}
+
+
+// What crosses the groups of hz_bn_act_*_groups, for any number of BatchNorm layers in one launch: thread = one column of one entry.
+__global__ __launch_bounds__(256) void k_bn_groups_finish(const hz_bn_finish_t* __restrict__ entries, int backward) {
+  const hz_bn_finish_t e = entries[blockIdx.y];
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= e.cols) return;
+  float a = e.dst0[c], b = e.dst1[c];
+  if (backward) {
+    float sa = 0.0f, sb = 0.0f;
+    for (int k = 0; k < e.groups; ++k) {
+      sa += e.scratch[((long long)k * 2 + 0) * e.cols + c];
+      sb += e.scratch[((long long)k * 2 + 1) * e.cols + c];
+    }
+    a += sa;
+    b += sb;
+  } else {
+    for (int k = 0; k < e.groups; ++k) {
+      a = (1.0f - e.momentum) * a + e.momentum * e.scratch[((long long)k * 2 + 0) * e.cols + c];
+      b = (1.0f - e.momentum) * b + e.momentum * e.scratch[((long long)k * 2 + 1) * e.cols + c];
+    }
+  }
+  e.dst0[c] = a;
+  e.dst1[c] = b;
+}
+
+extern "C" int hz_bn_groups_finish(const hz_bn_finish_t* entries, int num_entries, int max_cols, int backward, void* stream) {
+  HZ_REQUIRE(entries && num_entries >= 1 && num_entries <= 65535 && max_cols >= 1, "hz_bn_groups_finish: entries=%p n=%d max_cols=%d", (const void*)entries,
+             num_entries, max_cols);
+  hipLaunchKernelGGL(k_bn_groups_finish, dim3((max_cols + 255) / 256, num_entries), dim3(256), 0, (hipStream_t)stream, entries, backward);
   HZ_HIP(hipGetLastError());
   return 0;
 }

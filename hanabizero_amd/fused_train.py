@@ -38,14 +38,15 @@ class _Block:
         self.lin, self.bn, self.uses = lin, bn, uses
         self.w16 = lin.weight.detach().to(dtype)
         self.b16 = lin.bias.detach().to(dtype)
-        self.scratch = self.tickets = None   # a call over several row groups (hz_bn_act_*_groups): where the groups' sums meet
+        self.scratch, self.groups = None, 1   # a call over several row groups (hz_bn_act_*_groups): what crosses the groups waits here
+                                              # for hz_bn_groups_finish (FusedTrainNet._finish_groups)
 
-    def group_buffers(self, groups):
+    def group_scratch(self, groups):
         Cn = self.lin.weight.shape[0]
-        if self.scratch is None or self.scratch.shape[0] < groups:
+        if self.scratch is None or self.scratch.shape[0] != groups:
             self.scratch = torch.empty((groups, 2, Cn), dtype=torch.float32, device=self.w16.device)
-            self.tickets = torch.zeros((Cn + 7) // 8, dtype=torch.int32, device=self.w16.device)
-        return self.scratch, self.tickets
+        self.groups = groups
+        return self.scratch
 
 
 class _LinBNAct(torch.autograd.Function):
@@ -64,14 +65,14 @@ class _LinBNAct(torch.autograd.Function):
         assert rows % groups == 0
         B = rows // groups
         stats = torch.empty((2, groups, Cn), dtype=torch.float32, device=y.device)
-        scratch, tickets = blk.group_buffers(groups) if groups > 1 else (None, None)
+        scratch = blk.group_scratch(groups) if groups > 1 else None
         if res is not None:
             assert res.shape == y.shape and res.stride(1) == 1 and res.dtype == y.dtype
         check(lib.hz_bn_act_forward_groups(y.data_ptr(), y.stride(0), None if res is None else res.data_ptr(), 0 if res is None else res.stride(0),
                                            out.data_ptr(), out.stride(0), B, groups, Cn, bn.weight.data_ptr(), bn.bias.data_ptr(),
                                            bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.momentum), float(bn.eps),
                                            stats[0].data_ptr(), stats[1].data_ptr(), None if scratch is None else scratch.data_ptr(),
-                                           None if tickets is None else tickets.data_ptr(), int(relu), _DT[y.dtype], _stream()),
+                                           int(relu), _DT[y.dtype], _stream()),
               "hz_bn_act_forward_groups")
         ctx.blk, ctx.relu, ctx.has_res, ctx.groups = blk, relu, res is not None, groups
         ctx.save_for_backward(x, y, out, stats)
@@ -90,13 +91,13 @@ class _LinBNAct(torch.autograd.Function):
         groups = ctx.groups
         dy = torch.empty_like(y)
         dres = torch.empty_like(y) if ctx.has_res else None
-        scratch, tickets = blk.group_buffers(groups) if groups > 1 else (None, None)
+        scratch = blk.group_scratch(groups) if groups > 1 else None
         check(lib.hz_bn_act_backward_groups(dout.data_ptr(), dout.stride(0), out.data_ptr(), out.stride(0), y.data_ptr(), y.stride(0),
                                             dy.data_ptr(), dy.stride(0), None if dres is None else dres.data_ptr(),
                                             0 if dres is None else dres.stride(0), rows // groups, groups, Cn, bn.weight.data_ptr(),
                                             stats[0].data_ptr(), stats[1].data_ptr(), bn.weight.grad.data_ptr(), bn.bias.grad.data_ptr(),
-                                            None if scratch is None else scratch.data_ptr(), None if tickets is None else tickets.data_ptr(),
-                                            int(ctx.relu), _DT[y.dtype], _stream()), "hz_bn_act_backward_groups")
+                                            None if scratch is None else scratch.data_ptr(), int(ctx.relu), _DT[y.dtype], _stream()),
+              "hz_bn_act_backward_groups")
         g = blk.lin.weight.grad                                # W.grad += dy^T x: ONE GEMM, 16-bit operands, fp32 accumulate and output
         torch.addmm(g, dy.t(), x, out_dtype=torch.float32, out=g)
         dx = torch.mm(dy, blk.w16) if ctx.needs_input_grad[0] else None
@@ -234,6 +235,7 @@ class FusedTrainNet:
         self._w32 = [b.lin.weight for b in self._blocks] + [b.lin.bias for b in self._blocks]
         self._w16 = [b.w16 for b in self._blocks] + [b.b16 for b in self._blocks]
         self._anchor = torch.zeros(1, device=self._w16[0].device, requires_grad=True)
+        self._finish_tables = {}
         self._counters = [b.bn.num_batches_tracked for b in self._blocks if b.bn is not None]
         self._uses = [b.uses for b in self._blocks if b.bn is not None]
 
@@ -307,6 +309,11 @@ class FusedTrainNet:
         # ... then every head ONCE over the stack -- one GEMM per layer instead of one per layer and inference, each inference's
         # BatchNorm with its own statistics (hz_bn_act_*_groups) -- and all inferences' losses in one launch
         value, reward, policy_logits = self._heads(stacked, True, groups=U + 1, reward_from=B)
+        # what crosses the groups of the heads' BatchNorms -- running statistics now, the affine gradients once the heads' backward
+        # has run (the gradient of `stacked` is complete exactly then) -- in one launch each (hz_bn_groups_finish)
+        self._finish_groups(backward=False)
+        if stacked.requires_grad:
+            stacked.register_hook(self._finish_groups_backward)
         tot, L, P = _UnrolledLosses.apply(value, reward, policy_logits, target_value, target_reward, target_policy, weights, vs, coeffs)
         weighted_loss = tot.sum()
         Ls = L.view(U + 1, B, 4).sum(0)
@@ -341,6 +348,27 @@ class FusedTrainNet:
         vc, rc, pc = coeffs
         return weighted_loss, dict(loss=pc * Ls[:, 0] + vc * Ls[:, 1] + rc * Ls[:, 2], policy_loss=Ls[:, 0], value_loss=Ls[:, 1],
                                    reward_loss=Ls[:, 2], value_priority=value_priority, reward_priority=torch.stack(reward_priority).mean(0))
+
+    def _finish_groups(self, backward):
+        from ._lib import BnFinish
+        blocks = [b for b in self._blocks if b.bn is not None and b.groups > 1 and b.scratch is not None]
+        if not blocks:
+            return
+        if backward:
+            ptrs = [(b.bn.bias.grad.data_ptr(), b.bn.weight.grad.data_ptr(), b.scratch.data_ptr(), b.scratch.shape[2], b.groups, 0.0) for b in blocks]
+        else:
+            ptrs = [(b.bn.running_mean.data_ptr(), b.bn.running_var.data_ptr(), b.scratch.data_ptr(), b.scratch.shape[2], b.groups, float(b.bn.momentum))
+                    for b in blocks]
+        cached = self._finish_tables.get(backward)
+        if cached is None or cached[0] != ptrs:   # (a table of pointers: rebuilt only if a buffer has moved -- never inside a captured step)
+            arr = (BnFinish * len(ptrs))(*[BnFinish(dst0=a, dst1=b, scratch=s, cols=c, groups=g, momentum=m) for a, b, s, c, g, m in ptrs])
+            dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(blocks[0].scratch.device)
+            cached = self._finish_tables[backward] = (ptrs, dev, max(p[3] for p in ptrs))
+        check(lib.hz_bn_groups_finish(cached[1].data_ptr(), len(ptrs), cached[2], int(backward), _stream()), "hz_bn_groups_finish")
+
+    def _finish_groups_backward(self, grad):
+        self._finish_groups(backward=True)
+        return None
 
     def count_batches(self):
         """num_batches_tracked of every BatchNorm as the module's own forward would have left it after one learner step."""

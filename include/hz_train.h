@@ -42,19 +42,33 @@ int hz_bn_act_backward(const void* dout, int64_t dout_stride, const void* out, i
 /* The same two over `groups` row groups of `rows` rows each, stacked in x / res / out (dout / dx / dres): every group is normalised by
  * its OWN batch statistics -- one BatchNorm call of the module per group -- in one launch (grid: column tiles x groups).  That is
  * what lets a head of the unrolled learner step run ONCE over the stacked hidden states of all its inferences ((1 + unroll) x batch
- * rows: one GEMM instead of six) with the arithmetic of six calls.  save_mean / save_invstd: [groups][cols].  The running statistics
- * take the groups' batches in group order (r <- (1 - m) r + m s_g, g = 0 .. groups - 1), dgamma / dbeta the groups' sums in group
- * order: done by the LAST workgroup of a column tile to arrive (tickets[tile], zero before the first launch and left zero; the groups'
- * contributions meet in scratch [groups][2][cols] fp32), so the bits do not depend on the schedule.  groups == 1: scratch / tickets
- * may be NULL. */
+ * rows: one GEMM instead of six) with the arithmetic of six calls.  save_mean / save_invstd: [groups][cols].
+ * groups > 1: what crosses the groups is NOT done here -- running_mean / running_var and dgamma / dbeta stay untouched; the groups'
+ * contributions (forward: batch mean and unbiased variance; backward: the two column sums) go to scratch [groups][2][cols] fp32, and
+ * hz_bn_groups_finish applies them in group order (r <- (1 - m) r + m s_g for g = 0 .. groups - 1; dbeta += sum_g, dgamma += sum_g),
+ * for every layer of the step in ONE launch.  (A workgroup that waited for its column tile's other groups inside these kernels
+ * paid an L2 write-back per fence on this multi-die part: 20 us instead of 5.)  groups == 1: as hz_bn_act_forward / _backward,
+ * scratch may be NULL. */
 int hz_bn_act_forward_groups(const void* x, int64_t x_stride, const void* res, int64_t res_stride, void* out, int64_t out_stride, int rows,
                              int groups, int cols, const float* gamma, const float* beta, float* running_mean, float* running_var,
-                             float momentum, float eps, float* save_mean, float* save_invstd, float* scratch, int* tickets, int relu,
-                             int dtype, void* stream);
+                             float momentum, float eps, float* save_mean, float* save_invstd, float* scratch, int relu, int dtype,
+                             void* stream);
 int hz_bn_act_backward_groups(const void* dout, int64_t dout_stride, const void* out, int64_t out_stride, const void* x, int64_t x_stride,
                               void* dx, int64_t dx_stride, void* dres, int64_t dres_stride, int rows, int groups, int cols,
                               const float* gamma, const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
-                              float* scratch, int* tickets, int relu, int dtype, void* stream);
+                              float* scratch, int relu, int dtype, void* stream);
+
+/* One entry per BatchNorm layer that ran over groups: forward (backward == 0) dst0 / dst1 = running_mean / running_var, backward
+ * dst0 / dst1 = dbeta / dgamma (the parameters' .grad); scratch as the grouped kernels left it.  `entries`: DEVICE array. */
+typedef struct {
+  float* dst0;
+  float* dst1;
+  const float* scratch;
+  int32_t cols, groups;
+  float momentum;
+  int32_t reserved;
+} hz_bn_finish_t;
+int hz_bn_groups_finish(const hz_bn_finish_t* entries, int num_entries, int max_cols, int backward, void* stream);
 
 /* The losses of ONE inference of the unrolled learner step (initial or recurrent; core/train.py:145-168, 196-216 with
  * config/hanabi_control/__init__.py:119-123 and core/config.py:192-253) in one launch, gradients included:

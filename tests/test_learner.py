@@ -605,11 +605,12 @@ def test_head_losses_kernel_against_fp32_reference(dtype, V, smin, A, with_rewar
 @pytest.mark.parametrize("rows,groups,cols,relu,with_res", [(256, 6, 256, True, False), (256, 5, 512, True, True), (37, 3, 201, False, True),
                                                             (300, 2, 40, True, False)])
 def test_grouped_bn_act_kernels_equal_one_call_per_group(dtype, rows, groups, cols, relu, with_res):
-    """hz_bn_act_forward_groups / _backward_groups over `groups` stacked batches == one hz_bn_act_forward / _backward call per
-    batch, in order, on the same running statistics and gradient accumulators: outputs, saved statistics, running statistics,
-    input / residual gradients and the accumulated affine gradients, bit for bit (twice in a row: the tickets return to zero)."""
+    """hz_bn_act_forward_groups / _backward_groups over `groups` stacked batches (+ hz_bn_groups_finish for what crosses the groups)
+    == one hz_bn_act_forward / _backward call per batch, in order, on the same running statistics and gradient accumulators:
+    outputs, saved statistics, running statistics, input / residual gradients and the accumulated affine gradients, bit for bit
+    (twice in a row)."""
     import ctypes as C
-    from hanabizero_amd._lib import check, lib
+    from hanabizero_amd._lib import BnFinish, check, lib
     g = torch.Generator(device="cuda").manual_seed(rows * cols + groups)
     R = rows * groups
     x = (torch.randn(R, cols, device="cuda", generator=g) * 1.7 + 0.3).to(dtype)
@@ -621,7 +622,11 @@ def test_grouped_bn_act_kernels_equal_one_call_per_group(dtype, rows, groups, co
     dt = {torch.bfloat16: 1, torch.float16: 2}[dtype]
     ptr = lambda t: None if t is None else t.data_ptr()
     scratch = torch.full((groups, 2, cols), float("nan"), device="cuda")
-    tickets = torch.zeros((cols + 7) // 8, dtype=torch.int32, device="cuda")
+    def finish(dst0, dst1, backward):
+        e = (BnFinish * 1)(BnFinish(dst0=dst0.data_ptr(), dst1=dst1.data_ptr(), scratch=scratch.data_ptr(), cols=cols, groups=groups, momentum=0.1))
+        table = torch.frombuffer(bytearray(bytes(e)), dtype=torch.uint8).cuda()
+        check(lib.hz_bn_groups_finish(table.data_ptr(), 1, cols, int(backward), st), "finish")
+        torch.cuda.synchronize()
     rm0, rv0 = torch.randn(cols, device="cuda", generator=g) * 0.1, torch.rand(cols, device="cuda", generator=g) + 0.5
     rm_a, rv_a, rm_b, rv_b = rm0.clone(), rv0.clone(), rm0.clone(), rv0.clone()
     dg_a, db_a = torch.full((cols,), 0.5, device="cuda"), torch.full((cols,), -0.25, device="cuda")
@@ -631,19 +636,21 @@ def test_grouped_bn_act_kernels_equal_one_call_per_group(dtype, rows, groups, co
         out_b, stats_b = torch.empty_like(x), torch.empty(2, groups, cols, device="cuda")
         check(lib.hz_bn_act_forward_groups(x.data_ptr(), cols, ptr(res), cols, out_a.data_ptr(), cols, rows, groups, cols, gamma.data_ptr(), beta.data_ptr(),
                                            rm_a.data_ptr(), rv_a.data_ptr(), 0.1, 1e-5, stats_a[0].data_ptr(), stats_a[1].data_ptr(), scratch.data_ptr(),
-                                           tickets.data_ptr(), int(relu), dt, st), "fwd groups")
+                                           int(relu), dt, st), "fwd groups")
+        finish(rm_a, rv_a, False)
         for k in range(groups):
             s = slice(k * rows, (k + 1) * rows)
             check(lib.hz_bn_act_forward(x[s].data_ptr(), cols, ptr(None if res is None else res[s]), cols, out_b[s].data_ptr(), cols, rows, cols,
                                         gamma.data_ptr(), beta.data_ptr(), rm_b.data_ptr(), rv_b.data_ptr(), 0.1, 1e-5, stats_b[0, k].data_ptr(),
                                         stats_b[1, k].data_ptr(), int(relu), dt, st), "fwd")
         assert torch.equal(out_a.view(torch.int16), out_b.view(torch.int16)) and torch.equal(stats_a, stats_b)
-        assert torch.equal(rm_a, rm_b) and torch.equal(rv_a, rv_b) and int(tickets.abs().sum()) == 0
+        assert torch.equal(rm_a, rm_b) and torch.equal(rv_a, rv_b)
         dx_a, dx_b = torch.empty_like(x), torch.empty_like(x)
         dr_a, dr_b = (torch.empty_like(x), torch.empty_like(x)) if with_res else (None, None)
         check(lib.hz_bn_act_backward_groups(dout.data_ptr(), cols, out_a.data_ptr(), cols, x.data_ptr(), cols, dx_a.data_ptr(), cols, ptr(dr_a), cols, rows,
                                             groups, cols, gamma.data_ptr(), stats_a[0].data_ptr(), stats_a[1].data_ptr(), dg_a.data_ptr(), db_a.data_ptr(),
-                                            scratch.data_ptr(), tickets.data_ptr(), int(relu), dt, st), "bwd groups")
+                                            scratch.data_ptr(), int(relu), dt, st), "bwd groups")
+        finish(db_a, dg_a, True)
         acc_g, acc_b = torch.zeros(cols, device="cuda"), torch.zeros(cols, device="cuda")
         for k in range(groups):   # (the grouped kernel adds the groups' sums up first, then adds the total to the accumulator)
             s = slice(k * rows, (k + 1) * rows)
@@ -653,7 +660,7 @@ def test_grouped_bn_act_kernels_equal_one_call_per_group(dtype, rows, groups, co
                                          stats_b[1, k].data_ptr(), one_g.data_ptr(), one_b.data_ptr(), int(relu), dt, st), "bwd")
             acc_g, acc_b = acc_g + one_g, acc_b + one_b
         dg_b, db_b = dg_b + acc_g, db_b + acc_b
-        assert torch.equal(dx_a.view(torch.int16), dx_b.view(torch.int16)) and int(tickets.abs().sum()) == 0
+        assert torch.equal(dx_a.view(torch.int16), dx_b.view(torch.int16))
         assert torch.equal(dg_a, dg_b) and torch.equal(db_a, db_b)
         if with_res:
             assert torch.equal(dr_a.view(torch.int16), dr_b.view(torch.int16))
