@@ -116,6 +116,8 @@ def _load():
         "hz_search_poll_giveups_async": [V, V],
         # include/hz_replay.h
         "hz_replay_windows": [V, I, V, V, I, I, I, V, I64, I64, I, V],
+        "hz_replay_windows_seq": [V, I, V, V, V, V, I, I, I, I, I, V, I64, I64, I, V, I, I64, V, V, V],
+        "hz_replay_targets": [V, I, I, I, I, I64, V, V, V, V, V, V, V, V, V, V, V, V, V, V],
         # include/hz_train.h
         "hz_bn_act_forward": [V, I64, V, I64, V, I64, I, I, V, V, V, V, F, F, V, V, I, I, V],
         "hz_bn_act_backward": [V, I64, V, I64, V, I64, V, I64, V, I64, I, I, V, V, V, V, V, I, I, V],

@@ -65,6 +65,7 @@ class DeviceReplay:
         self.games = 0                   # games ingested so far
         self.gen = torch.Generator(device=d)
         self.gen.manual_seed(int(seed))
+        self._gpow = {}                  # (discount, td_steps) -> discount ** i, i = 0 .. td_steps, float64 on the device
 
     # -- bookkeeping ----------------------------------------------------------------------------------------------
     def get_total_len(self):
@@ -188,6 +189,20 @@ class DeviceReplay:
                                     out.data_ptr(), out.stride(0), slot, _OBS_CODE[out.dtype], _stream()), "hz_replay_windows")
         return out
 
+    def windows_seq(self, phys, G, shift0, out, slot_elems=None, legal_out=None, valid_out=None):
+        """windows() for B x G rows addressed through the position arrays (include/hz_replay.h hz_replay_windows_seq): row b * G + j =
+        the window `shift0 + j` moves behind position phys[b], a zero row where the game has no such position; optionally the legal
+        moves there and the validity mask.  One launch."""
+        B = phys.numel()
+        slot = self.D if slot_elems is None else int(slot_elems)
+        assert out.shape[0] == B * G and out.stride(1) == 1 and phys.dtype == torch.int64 and phys.is_contiguous()
+        check(lib.hz_replay_windows_seq(self.frames.data_ptr(), self.W, self.pos_row0.data_ptr(), self.pos_t.data_ptr(), self.pos_T.data_ptr(),
+                                        phys.data_ptr(), B, G, int(shift0), self.stack, self.D, out.data_ptr(), out.stride(0), slot,
+                                        _OBS_CODE[out.dtype], self.legal.data_ptr(), self.A, max(1, self.fhead),
+                                        None if legal_out is None else legal_out.data_ptr(), None if valid_out is None else valid_out.data_ptr(),
+                                        _stream()), "hz_replay_windows_seq")
+        return out
+
     # -- one learner batch (reanalyze_worker.py:148-168, 249-304, 374-399) ------------------------------------------------------
     def assemble(self, ids, value_fn, out, rand_actions=None, value_windows=None, slot_elems=None):
         """Fills `out` -- an object with the learner's static input tensors: obs [B, stack, D] f32, action [B, U] int64,
@@ -208,37 +223,28 @@ class DeviceReplay:
         d = self.device
         phys = (ids - self.origin).contiguous()
         B = phys.numel()
-        t, T = self.pos_t[phys].to(torch.int64), self.pos_T[phys].to(torch.int64)
-        k = torch.arange(U + 1, device=d)
-        inside = (t[:, None] + k[None, :]) < T[:, None]                        # [B, U + 1]: position pos + k exists
-        # model input
-        zero = torch.zeros(B, dtype=torch.int32, device=d)
-        self.windows(phys, zero, torch.ones(B, dtype=torch.bool, device=d), out.obs.view(B, -1))
-        # actions
+        # model input; bootstrap windows td steps ahead of every unroll position, the target model's values of them
+        self.windows_seq(phys, 1, 0, out.obs.view(B, -1))
         if rand_actions is None:
             rand_actions = torch.randint(0, A, (B, U), device=d, generator=self.gen)
-        pk = (phys[:, None] + k[None, :U]).clamp_(max=self.head - 1)
-        out.action.copy_(torch.where(inside[:, :U], self.action[pk].to(torch.int64), rand_actions))
-        # value targets
-        reach = (t[:, None] + k[None, :] + td) < T[:, None]                     # a bootstrap window td steps ahead exists
         slot = self.D if slot_elems is None else int(slot_elems)
         if value_windows is None:
             value_windows = torch.empty(B * (U + 1), self.stack * slot, dtype=torch.float32, device=d)
-        rep = phys.repeat_interleave(U + 1)
-        self.windows(rep, (k + td).to(torch.int32).repeat(B), reach.reshape(-1), value_windows, slot_elems=slot)
-        v = value_fn(value_windows).to(torch.float64).reshape(B, U + 1) * (g ** td) * reach.to(torch.float64)
-        ki = torch.arange(U + td, device=d)
-        pr = (phys[:, None] + ki[None, :]).clamp_(max=self.head - 1)
-        rew = torch.where((t[:, None] + ki[None, :]) < T[:, None], self.reward[pr].to(torch.float64), torch.zeros((), dtype=torch.float64, device=d))
-        for i in range(td):
-            v = v + rew[:, i:i + U + 1] * g ** i   # (the reference's order, i = 0 .. td - 1; a term past the end is + 0.0)
-        out.target_value.copy_(torch.where(inside, v, torch.zeros_like(v)).to(torch.float32))
-        out.target_reward.copy_(rew[:, :U].to(torch.float32))
-        # stored policy targets
-        pu = (phys[:, None] + k[None, :]).clamp_(max=self.head - 1)
-        counts = self.visits[pu].to(torch.float64)
-        pol = counts / counts.sum(2, keepdim=True)
-        out.target_policy.copy_(torch.where(inside[:, :, None], pol, torch.zeros_like(pol)).to(torch.float32))
+        self.windows_seq(phys, U + 1, td, value_windows, slot_elems=slot)
+        boot = value_fn(value_windows).to(torch.float32).contiguous()
+        # actions, reward / value / policy targets: one launch over the replay's arrays (include/hz_replay.h hz_replay_targets)
+        gp = self._gpow.get((g, td))
+        if gp is None:
+            gp = self._gpow[(g, td)] = torch.tensor([g ** i for i in range(td + 1)], dtype=torch.float64, device=d)
+        inside = torch.empty((B, U + 1), dtype=torch.bool, device=d)
+        for t, dt in ((out.action, torch.int64), (out.target_reward, torch.float32), (out.target_value, torch.float32), (out.target_policy, torch.float32)):
+            assert t.dtype == dt and t.is_contiguous()
+        assert out.action.shape == (B, U) and out.target_reward.shape == (B, U) and out.target_value.shape == (B, U + 1) and \
+            out.target_policy.shape == (B, U + 1, A) and rand_actions.shape == (B, U) and rand_actions.dtype == torch.int64 and boot.numel() == B * (U + 1)
+        check(lib.hz_replay_targets(phys.data_ptr(), B, U, td, A, self.head, self.pos_t.data_ptr(), self.pos_T.data_ptr(), self.action.data_ptr(),
+                                    self.reward.data_ptr(), self.visits.data_ptr(), boot.data_ptr(), gp.data_ptr(), rand_actions.contiguous().data_ptr(),
+                                    out.action.data_ptr(), out.target_reward.data_ptr(), out.target_value.data_ptr(), out.target_policy.data_ptr(),
+                                    inside.data_ptr(), _stream()), "hz_replay_targets")
         return inside
 
     # -- reanalyze context (reanalyze_worker.py:101-144) on the device ---------------------------------------------------------
@@ -246,17 +252,11 @@ class DeviceReplay:
         """For the positions `ids` [R]: the windows of their U + 1 unroll positions into `out_windows` [R * (U + 1), ...] (zero rows
         past the end of the game) plus (legal [R * (U + 1), A] uint8, all-zero past the end; mask [R * (U + 1)] bool)."""
         U = self.config.num_unroll_steps
-        d = self.device
         phys = (ids - self.origin).contiguous()
         R = phys.numel()
-        k = torch.arange(U + 1, device=d)
-        t, T = self.pos_t[phys].to(torch.int64), self.pos_T[phys].to(torch.int64)
-        mask = ((t[:, None] + k[None, :]) < T[:, None]).reshape(-1)
-        rep = phys.repeat_interleave(U + 1)
-        shift = k.to(torch.int32).repeat(R)
-        self.windows(rep, shift, mask, out_windows, slot_elems=slot_elems)
-        frow = (self.pos_row0[rep] + self.pos_t[rep].to(torch.int64) + shift).clamp_(max=self.fhead - 1)
-        legal = torch.where(mask[:, None], self.legal[frow], torch.zeros((), dtype=torch.uint8, device=d))
+        legal = torch.empty((R * (U + 1), self.A), dtype=torch.uint8, device=self.device)
+        mask = torch.empty(R * (U + 1), dtype=torch.bool, device=self.device)
+        self.windows_seq(phys, U + 1, 0, out_windows, slot_elems=slot_elems, legal_out=legal, valid_out=mask)
         return legal, mask
 
 

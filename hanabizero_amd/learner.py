@@ -407,6 +407,57 @@ class _Slot:
         self.enqueued.set()
 
 
+def streams_on_distinct_queues(dev, n, candidates=12, launches=150):
+    """`n` PyTorch streams that run side by side.  A process has more streams than the GPU has hardware queues (4), two streams
+    on one queue take turns, and which pool streams share one is not for the caller to know (measured: the two re-search streams of
+    the learner pipeline, created one after the other, sat on the same queue and gained nothing over one).  So measure: a captured
+    chain of small dependent GEMMs (one workgroup each, ~7 us: long against the dispatch of a launch, tiny against the GPU) on a
+    candidate beside another chain on each stream chosen so far; side by side the pair takes what one takes, on one queue twice that.
+    Returns (streams, ms of one chain, [ms of every pair tried])."""
+    def train():
+        x = torch.eye(128, device=dev)
+        y = torch.eye(128, device=dev)
+        for _ in range(3):
+            y = x @ y
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            for _ in range(launches):
+                y = x @ y
+        return g, x, y
+    torch.cuda.synchronize(dev)
+    ta, tb = train(), train()   # (two graphs: launches of one and the same executable graph queue up behind each other)
+
+    def both(a, b):
+        torch.cuda.synchronize(dev)
+        e0, ea, eb = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        cur = torch.cuda.current_stream(dev)
+        e0.record(cur)
+        for st, g, e in ((a, ta[0], ea), (b, tb[0], eb)):
+            if st is None:
+                continue
+            st.wait_event(e0)
+            with torch.cuda.stream(st):
+                g.replay()
+                e.record(st)
+        torch.cuda.synchronize(dev)
+        return max(e0.elapsed_time(ea), e0.elapsed_time(eb) if b is not None else 0.0)
+    cands = [torch.cuda.Stream(device=dev) for _ in range(candidates)]
+    both(cands[0], cands[1])    # (first launches of both graphs)
+    both(cands[0], None)
+    one = both(cands[0], None)
+    chosen, pairs = [cands[0]], []
+    for c in cands[1:]:
+        if len(chosen) == n:
+            break
+        ms = [both(c, st) for st in chosen]
+        pairs.append(ms)
+        if max(ms) < 1.4 * one:
+            chosen.append(c)
+    chosen += [c for c in cands if c not in chosen][:n - len(chosen)]   # (fewer queues than asked for: the rest share)
+    return chosen, one, pairs
+
+
 class LearnerPipeline:
     """What the reference spreads over BatchWorker_CPU x cpu_actor, BatchWorker_GPU x gpu_actor, the BatchStorage queue and
     the learner process (/root/reference/core/train.py:317-431, 440-481; core/reanalyze_worker.py:402-440) as streams of ONE
@@ -444,9 +495,11 @@ class LearnerPipeline:
         U, A = config.num_unroll_steps, config.action_space_size
         self.Dp = target_engine.pad_observations(replay.D, replay.stack)
         win = (self.B * (U + 1), replay.stack * self.Dp)
-        self.prep, self.learn = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
-        self.side = [torch.cuda.Stream(device=dev) for _ in range(research_streams if self.R else 0)]
-        self.slots = [_Slot(self.graphed, self.R, U, A, win, target_engine.dtype) for _ in range(3 if self.side else 2)]
+        n_side = research_streams if self.R else 0
+        picked, one_ms, pair_ms = streams_on_distinct_queues(dev, 2 + n_side)
+        self.prep, self.learn, self.side = picked[0], picked[1], picked[2:]
+        self.stream_probe_ms = {"one": one_ms, "pairs": pair_ms}
+        self.slots = [_Slot(self.graphed, self.R, U, A, win, target_engine.dtype) for _ in range(len(self.side) + 1 if self.side else 2)]
         self.steps = 0
         self.host_wait_s = 0.0                  # what the host spent waiting for a slot (the GPU being the slower side)
         self._recent = None

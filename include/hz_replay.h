@@ -32,6 +32,35 @@ extern "C" {
 int hz_replay_windows(const int32_t* frames, int packed_words, const int64_t* row0, const int32_t* t, int M, int stack, int D,
                       void* out, int64_t out_row_elems, int64_t slot_elems, int out_dtype, void* stream);
 
+/* The same windows for B x G rows addressed through the replay's own position arrays instead of per-row (row0, t) lists: output row
+ * m = b * G + j looks at position p = phys[b], `shift0 + j` moves behind it:
+ *     t = pos_t[p] + shift0 + j  if that is < pos_T[p] (the game has such a position), else none (a zero row);  row0 = pos_row0[p].
+ * G = 1, shift0 = 0: the model inputs of a batch; G = U + 1, shift0 = td_steps: its bootstrap windows; G = U + 1, shift0 = 0: the
+ * windows of the positions to re-search -- for those, optionally, legal_out [B * G][num_actions] (the legal-move row of the window's
+ * last frame, from legal [frame_rows][num_actions]; zeros where there is no such position) and valid_out [B * G] (1 / 0).
+ * One launch where the per-row form needs the caller to build two index arrays first (six small launches in PyTorch). */
+int hz_replay_windows_seq(const int32_t* frames, int packed_words, const int64_t* pos_row0, const int32_t* pos_t, const int32_t* pos_T,
+                          const int64_t* phys, int B, int G, int shift0, int stack, int D, void* out, int64_t out_row_elems,
+                          int64_t slot_elems, int out_dtype, const uint8_t* legal, int num_actions, int64_t frame_rows, uint8_t* legal_out,
+                          uint8_t* valid_out, void* stream);
+
+/* The other tensors of a learner batch from the replay's arrays, as BatchWorker_CPU.make_batch + BatchWorker_GPU's target arithmetic
+ * build them (/root/reference/core/reanalyze_worker.py:148-168, 249-304, 374-399), one thread per (batch row b, unroll position k):
+ *   out_action [B][U] int64     action[p + k], or rand_actions[b][k] past the end of the game
+ *   out_reward [B][U] f32       reward[p + k], 0 past the end
+ *   out_value  [B][U + 1] f32   bootstrap[b][k] * discount^td (where position p + k + td exists) + sum_{i < td} discount^i *
+ *                               reward[p + k + i] (0 past the end), float64 in the reference's order of additions, cast once; 0 where
+ *                               p + k itself is past the end
+ *   out_policy [B][U + 1][A] f32   visits / their sum (float64 quotient), 0 past the end
+ *   out_inside [B][U + 1] u8 (or NULL)   p + k inside its game
+ * phys [B] int64 positions; pos_t / pos_T / action int8 / reward int16 / visits int16 [.][A]: the replay's arrays, `head` = live
+ * positions (reads are clamped below it); bootstrap [B][U + 1] f32: the target model's values of the bootstrap windows;
+ * discount_powers [td + 1] f64: discount^0 .. discount^td as the HOST computes them (pow on the device may differ in the last bit). */
+int hz_replay_targets(const int64_t* phys, int B, int unroll_steps, int td_steps, int num_actions, int64_t head, const int32_t* pos_t,
+                      const int32_t* pos_T, const int8_t* action, const int16_t* reward, const int16_t* visits, const float* bootstrap,
+                      const double* discount_powers, const int64_t* rand_actions, int64_t* out_action, float* out_reward, float* out_value,
+                      float* out_policy, uint8_t* out_inside, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

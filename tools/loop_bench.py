@@ -282,7 +282,7 @@ def main():
                "host_wait_for_the_gpu_ms_per_learner_step": (1e3 * pipe.host_wait_s / max(1, pipe.steps)),
                "checkpoint_interval": cfg.checkpoint_interval, "target_model_interval": cfg.target_model_interval,
                "loss_last": losses[1] if losses else None, "learner_blocks": "autograd (autocast)" if args.eager_blocks else "fused (include/hz_train.h)",
-               "prepare_stream_candidates_ms": pipe.prep_interference_ms,
+               "prepare_stream_candidates_ms": pipe.prep_interference_ms, "stream_probe_ms": pipe.stream_probe_ms,
                "host_threads_on_the_learner_rank": 1 if args.one_host_thread else 2}
         print(json.dumps(out), flush=True)
         pipe.close()
