@@ -280,3 +280,14 @@ def test_config5_loop_roles_on_one_gpu(ranks):
     assert d["selfplay_moves_per_s"] == pytest.approx(moves / d["wall_s"], rel=1e-6)
     assert d["games_ingested"] > 50 and d["replay_positions"] > 1000 and d["weight_handovers_in_run"] >= 2 and d["weight_handover_first_ms"] > 0
     assert d["loss_last"] is not None and np.isfinite(d["loss_last"]) and d["weight_handover_ms"] > 0
+
+
+def test_streams_on_distinct_queues_run_side_by_side():
+    """learner.streams_on_distinct_queues: the streams it returns overlap pairwise (a chain of small dependent GEMMs on each of two
+    takes about what one takes), which two arbitrary streams of the process need not (the GPU has 4 hardware queues)."""
+    from hanabizero_amd.learner import streams_on_distinct_queues
+    dev = torch.device("cuda", torch.cuda.current_device())
+    streams, one, pairs = streams_on_distinct_queues(dev, 4)
+    assert len(streams) == 4 and len({s.cuda_stream for s in streams}) == 4 and one > 0
+    accepted = [p for p in pairs if max(p) < 1.4 * one]
+    assert len(accepted) >= 3, (one, pairs)     # (three candidates joined the first stream: four hardware queues found)

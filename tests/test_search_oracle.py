@@ -68,7 +68,8 @@ def test_benched_search_kernel_equals_oracle_tree(game, N, net, moves):
     assert poll_giveups() == giveups_before, "a wave gave up waiting for an arrival counter (include/hz_mlp.h)"
 
 
-@pytest.mark.parametrize("game,N,net,moves", [("Hanabi-Full", 4096, "random", 2), ("Hanabi-Full", 1500, "sharp", 2), ("Hanabi-Small", 1000, "random", 3)])
+@pytest.mark.parametrize("game,N,net,moves", [("Hanabi-Full", 4096, "random", 2), ("Hanabi-Full", 1500, "sharp", 2), ("Hanabi-Small", 1000, "random", 3),
+                                               ("Hanabi-Full-5p", 700, "random", 2)])   # (A = 48: the widest tree rows beside the two-plane image)
 def test_fp16_pair_engine_search_equals_oracle_tree(game, N, net, moves):
     """The engine inside the contract's 1e-3 (InferenceEngine(dtype=float32, fused="fp16x2"): fp32 pool, recurrent inference =
     the MFMA kernel's HZ_F16X2 build) searches in ONE persistent kernel (k_search_pairs, 16 trees per workgroup) or launch by
