@@ -463,15 +463,16 @@ class LearnerPipeline:
     the learner process (/root/reference/core/train.py:317-431, 440-481; core/reanalyze_worker.py:402-440) as streams of ONE
     GPU with nothing on the host but the enqueueing:
 
-        prepare stream   priorities of step k - 3 back into the replay -> sample ids / weights -> DeviceReplay.assemble into slot
-                         k % 3 (value targets with the TARGET model) -> the re-search's inputs: everything that touches the replay
+        prepare stream   priorities of step k - 4 back into the replay -> sample ids / weights -> DeviceReplay.assemble into slot
+                         k % 4 (value targets with the TARGET model) -> the re-search's inputs: everything that touches the replay
         re-search stream k % 2: policy targets for the first R rows re-searched with the TARGET model (policy_re_device) -- 768 roots
                          x 49 simulations are one latency-bound launch on a fifth of the GPU (1.4 of a batch's ~3 ms), so two
                          consecutive batches' searches run side by side
         learner stream   slot -> the captured step's static inputs -> lr -> GraphedUpdate.run -> new priorities into the slot
 
-    so batches k + 1 and k + 2 are searched and assembled while step k trains (the reference's queue of prepared batches, depth 3).
-    (research_streams=0: the re-search on the prepare stream, two slots -- r04's first form.)
+    so batches k + 1 .. k + 3 are in preparation while step k trains (the reference's queue of prepared batches; `slots` = batches
+    in flight, by default one more than the three stages).  (research_streams=0: the re-search on the prepare stream, two slots --
+    r04's first form.)
     Cadences as train.py:392-398: `on_checkpoint(step)` every checkpoint_interval steps (the caller hands the weights to the
     actors), the target model takes the learner's weights of one target_model_interval ago every target_model_interval steps.
     Nothing synchronises the host; `losses()` reads the last step's loss tuple (one small read-back) when somebody wants it.
@@ -482,7 +483,7 @@ class LearnerPipeline:
     either way; `flush()` before touching `learn` or a slot's `done` event from outside."""
 
     def __init__(self, config, replay, model, target_engine, batch_size=None, reanalyze_share=0.5, amp=torch.bfloat16, beta=0.4,
-                 on_checkpoint=None, seed=0, host_thread=True, research_streams=2):
+                 on_checkpoint=None, seed=0, host_thread=True, research_streams=2, slots=None):
         from .device_replay import policy_re_device
         self._policy_re = policy_re_device
         self.cfg, self.replay, self.model, self.target = config, replay, model, target_engine
@@ -499,7 +500,9 @@ class LearnerPipeline:
         picked, one_ms, pair_ms = streams_on_distinct_queues(dev, 2 + n_side)
         self.prep, self.learn, self.side = picked[0], picked[1], picked[2:]
         self.stream_probe_ms = {"one": one_ms, "pairs": pair_ms}
-        self.slots = [_Slot(self.graphed, self.R, U, A, win, target_engine.dtype) for _ in range(len(self.side) + 1 if self.side else 2)]
+        n_slots = int(slots) if slots else (len(self.side) + 2 if self.side else 2)   # (one more than the stages: 465 -> 491 steps/s)
+        assert n_slots >= 2
+        self.slots = [_Slot(self.graphed, self.R, U, A, win, target_engine.dtype) for _ in range(n_slots)]
         self.steps = 0
         self.host_wait_s = 0.0                  # what the host spent waiting for a slot (the GPU being the slower side)
         self._recent = None

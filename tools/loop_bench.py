@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--actor-stream", default="null", choices=["null", "normal", "low"], help="the stream the lock-steps run on")
     ap.add_argument("--parallel-heads", type=int, default=0, help="head chains of the learner's inferences on streams of their own (FusedTrainNet)")
     ap.add_argument("--research-streams", type=int, default=2, help="streams the batches' re-searches alternate on (0: on the prepare stream, two batch slots)")
+    ap.add_argument("--slots", type=int, default=0, help="batches in flight (0: the pipeline's default)")
     ap.add_argument("--one-host-thread", action="store_true", help="the learner half of a step enqueued by the thread that prepares the batches (default: by a second one)")
     ap.add_argument("--eager-blocks", action="store_true", help="the learner's module forward through PyTorch autograd under autocast instead of the fused Linear + BatchNorm + ReLU blocks (include/hz_train.h)")
     args = ap.parse_args()
@@ -122,7 +123,7 @@ def main():
         def on_checkpoint(step, done_event):
             handover["pending"], handover["event"] = True, done_event
         pipe = LearnerPipeline(cfg, replay, learner, target, batch_size=cfg.batch_size, reanalyze_share=args.reanalyze_share,
-                               on_checkpoint=on_checkpoint, host_thread=not args.one_host_thread, research_streams=args.research_streams)
+                               on_checkpoint=on_checkpoint, host_thread=not args.one_host_thread, research_streams=args.research_streams, slots=args.slots or None)
     A = cfg.action_space_size
     W = (cfg.obs_dim + 31) // 32
 
