@@ -314,11 +314,16 @@ __device__ __forceinline__ void mlp_body(
   // (3: -2.1 % moves/s at 8192 envs, 1: -1.6 %; A/B on one box, tools/ab_bench.sh).
   // (the fp16-pair build inside the persistent search kernel -- two fragments per tile and step, 128 registers per lane, sixteen
   // wavefronts to hide latency with: a ring of two)
-  constexpr int RING = (SPLIT && NT == 2) ? 2 : 4;
-  constexpr int PF = (SPLIT && NT == 2) ? 1 : (RT == 1 ? RING - 1 : RING - 2);
+#ifdef HZ_NO_ASMK   // (diagnostic build: the 16 x 2 shape on the compiler-scheduled k-loop, as the fp16-pair build runs it)
+  constexpr bool NOASM = true;
+#else
+  constexpr bool NOASM = false;
+#endif
+  constexpr int RING = ((SPLIT || NOASM) && NT == 2) ? 2 : 4;
+  constexpr int PF = ((SPLIT || NOASM) && NT == 2) ? 1 : (RT == 1 ? RING - 1 : RING - 2);
   // NT == 2 (the 16 x 2 shape of the persistent search kernel): the k-loop is hand-scheduled assembly (below) and its
   // loads are invisible to the compiler; the other shapes keep the compiler-scheduled loop.
-  constexpr bool ASMK = NT == 2 && RING == 4 && !SPLIT;
+  constexpr bool ASMK = NT == 2 && RING == 4 && !SPLIT && !NOASM;
   v8 wf[ASMK ? 1 : RING][NT * WP];                    // !ASMK: the ring as C++ values (ASMK: the fixed registers above)
   unsigned int voff = (unsigned int)lane * 16u;  // ASMK: byte offset of the next fragment this lane requests
   long long gstep = 0;                           // !ASMK: k-steps of this wave's stream consumed so far
@@ -731,7 +736,7 @@ __device__ __forceinline__ void mlp_body(
       // ---- the compiler-scheduled k-loop of the other shapes
       // activation fragments, BQPF k-steps ahead of their use (RT = 2 has the registers for one step ahead only -- two
       // measured no faster, with more spills; its four MFMAs per k-step cover the LDS round trip)
-      constexpr int BQD = (SPLIT && NT == 2) ? 2 : (RT == 1 ? 4 : 2);
+      constexpr int BQD = ((SPLIT || NOASM) && NT == 2) ? 2 : (RT == 1 ? 4 : 2);
       constexpr int BQPF = BQD - 1;
       v8 bq[BQD][RT * WP];
 #pragma unroll
