@@ -54,6 +54,18 @@ def cpu_worker(kind, game, A, S, trees, moves):
     from oracle.cport import OracleEnv, OracleTree
     rng = np.random.RandomState(0)
     N = trees
+    if kind == "ref_env":   # the GENUINE rules engine + encoder (oracle/_ref/libpyhanabi.so), one object per game as envs/hanabi/rl_env.py drives it
+        from oracle.ref import RefHanabiEnv
+        envs = [RefHanabiEnv(game, seed=i) for i in range(N)]
+        legal = np.stack([e.reset()[2] for e in envs])
+        t0 = time.perf_counter()
+        for m in range(moves):
+            act = (legal * (1 + (np.arange(A) * 7 + m) % A)).argmax(1)
+            for i, e in enumerate(envs):
+                out = e.step(int(act[i]))
+                legal[i] = e.reset()[2] if out[3] else out[5]
+        dt = time.perf_counter() - t0
+        return N * moves / dt, dt
     env = OracleEnv(game, np.arange(N))
     env.reset()
     obs, legal = env.observe()
@@ -65,8 +77,12 @@ def cpu_worker(kind, game, A, S, trees, moves):
     zeros = np.zeros(N, np.float32)
     t0 = time.perf_counter()
     for m in range(moves):
-        if kind in ("both", "tree"):
-            tree = OracleTree(N, A, S, seed=0, value_delta_max=0.006)  # the reference builds a new Roots per move
+        if kind in ("both", "tree", "ref_tree"):
+            if kind == "ref_tree":   # the GENUINE tree (oracle/_ref/libref_tree.so: core/ctree/cnode.cpp + cminimax.cpp)
+                from oracle.ref import RefTree
+                tree = RefTree(N, A, S, mode=1, seed=0, value_delta_max=0.006)
+            else:
+                tree = OracleTree(N, A, S, seed=0, value_delta_max=0.006)  # the reference builds a new Roots per move
             tree.prepare(0.25, noises, zeros, logits0, legal)
             for sim in range(S - 1):
                 tree.traverse(sim, 19652, 1.25, 0.999)
@@ -112,6 +128,17 @@ def cpu_baseline(game, A, S, trees, moves, workload, max_procs):
     t0 = time.perf_counter()
     rs = [result(p) for p in [spawn("both", per, max(2, moves // 2)) for _ in range(procs)]]
     wall = time.perf_counter() - t0
+    here = None
+    try:  # ... and the genuine reference's own tree and env on THIS box's cores where its build travelled with the snapshot (oracle/_ref)
+        ref_dir = os.path.join(ROOT, "oracle", "_ref")   # (the children load it: this process never imports anything under oracle/)
+        if os.path.exists(os.path.join(ref_dir, "libref_tree.so")) and os.path.exists(os.path.join(ref_dir, "libpyhanabi.so")):
+            rt, re_ = result(spawn("ref_tree", min(trees, 1024), 2)), result(spawn("ref_env", 256, 30))
+            here = {"kind": "reference", "what": "oracle/_ref: the reference's core/ctree/cnode.cpp + cminimax.cpp and envs/hanabi (hanabi_lib + pyhanabi.cc) compiled as they lie, driven through ctypes",
+                    "tree_only": {"value": rt["moves_per_s"], "unit": "root-searches/s", "cores": 1, "sample": "%d trees x 2 moves x %d sims, %.1f s" % (min(trees, 1024), S - 1, rt["seconds"])},
+                    "env_only": {"value": re_["moves_per_s"], "unit": "env-steps/s (step + observation + legal moves, one C-API object per game)", "cores": 1,
+                                 "sample": "256 games x 30 moves, %.1f s" % re_["seconds"]}}
+    except Exception as e:  # noqa: BLE001
+        here = {"error": repr(e)[:300]}
     ref = None
     try:  # the genuine reference beside the port, timed where the reference exists (tools/gen_golden.py --only cpu_rates); a pointer
         # with its provenance, like roofline.traffic_source -- nothing of it is measured in this run
@@ -119,7 +146,7 @@ def cpu_baseline(game, A, S, trees, moves, workload, max_procs):
         ref["source"] = "profiles/r04_cpu_reference_vs_port.json"
     except (OSError, ValueError):
         pass
-    return {"value": one["moves_per_s"], "unit": "moves/s", "cores": 1, "kind": "port", "reference_in_container": ref,
+    return {"value": one["moves_per_s"], "unit": "moves/s", "cores": 1, "kind": "port", "reference_on_this_box": here, "reference_in_container": ref,
             "sample": "oracle tree+env (no nets), %d envs x %d moves x %d sims, %.1f s on 1 core" % (trees, moves, S - 1, one["seconds"]),
             "cpu_model": cpu_model(), "machine_cores": os.cpu_count(), "cores_available": avail,
             "tree_only": {"value": tree["moves_per_s"], "unit": "root-searches/s", "cores": 1,
@@ -625,7 +652,7 @@ def main():
     ap.add_argument("--cpu-sample-trees", type=int, default=4096)
     ap.add_argument("--cpu-sample-moves", type=int, default=16)
     ap.add_argument("--cpu-procs", type=int, default=16, help="upper bound on the processes of the all-cores CPU leg (a 1-GPU box's CPU share)")
-    ap.add_argument("--cpu-worker", default=None, choices=["both", "tree", "env"], help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-worker", default=None, choices=["both", "tree", "env", "ref_tree", "ref_env"], help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     if args.cpu_worker:  # a child of cpu_baseline(): oracle only, before anything imports torch
