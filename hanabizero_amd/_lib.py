@@ -124,6 +124,8 @@ def _load():
         "hz_bn_act_forward_groups": [V, I64, V, I64, V, I64, I, I, I, V, V, V, V, F, F, V, V, V, I, I, V],
         "hz_bn_act_backward_groups": [V, I64, V, I64, V, I64, V, I64, V, I64, I, I, I, V, V, V, V, V, V, I, I, V],
         "hz_bn_groups_finish": [V, I, I, I, V],
+        "hz_state_action_rows": [V, I64, V, I64, I, I, I, V, I64, I, V],
+        "hz_scale_rows3": [V, I, V, I, V, I, V, I, I, V, V, V, I, V],
         "hz_muzero_head_losses": [V, I64, V, I64, V, I64, I, I, I, I, I, V, I64, V, I64, V, I64, V, F, F, F, V, V, V, V, V, V],
         "hz_muzero_unrolled_losses": [V, I64, V, I64, V, I64, I, I, I, I, I, I, V, I64, I64, V, I64, I64, V, I64, I64, V, F, F, F, V, V, V, V, V, V],
         # include/hz_netglue.h

@@ -536,3 +536,58 @@ extern "C" int hz_muzero_unrolled_losses(const void* value_logits, int64_t value
   HZ_HIP(hipGetLastError());
   return 0;
 }
+
+
+// ------------------------------------------------------------------------------------------------ small glue of the unrolled step
+// [state | one-hot(action)] rows, the dynamics net's input (config/hanabi_control/model.py:215-219: zeros + scatter_ + cat in PyTorch)
+__global__ __launch_bounds__(256) void k_state_action_rows(const uint16_t* __restrict__ state, long long ss, const int64_t* __restrict__ action,
+                                                           long long as, int H, int A, uint16_t* __restrict__ out, long long os, uint16_t one) {
+  const int b = blockIdx.x;
+  const uint16_t* s = state + (long long)b * ss;
+  uint16_t* o = out + (long long)b * os;
+  const int a = (int)action[(long long)b * as];
+  for (int c = threadIdx.x; c < H + A; c += blockDim.x) o[c] = c < H ? s[c] : (c - H == a ? one : (uint16_t)0);
+}
+
+extern "C" int hz_state_action_rows(const void* state, int64_t state_stride, const int64_t* action, int64_t action_stride, int rows, int hidden,
+                                    int num_actions, void* out, int64_t out_stride, int dtype, void* stream) {
+  HZ_REQUIRE(state && action && out, "hz_state_action_rows: null pointer");
+  HZ_REQUIRE(rows >= 1 && hidden >= 1 && num_actions >= 1 && state_stride >= hidden && out_stride >= hidden + num_actions && action_stride >= 1,
+             "hz_state_action_rows: rows=%d hidden=%d num_actions=%d", rows, hidden, num_actions);
+  HZ_REQUIRE(dtype == HZ_BF16 || dtype == HZ_F16, "hz_state_action_rows: dtype %d (HZ_BF16 or HZ_F16)", dtype);
+  hipLaunchKernelGGL(k_state_action_rows, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)state, (long long)state_stride, action,
+                     (long long)action_stride, hidden, num_actions, (uint16_t*)out, (long long)out_stride,
+                     (uint16_t)(dtype == HZ_BF16 ? 0x3f80u : 0x3c00u));
+  HZ_HIP(hipGetLastError());
+  return 0;
+}
+
+// out_i[r][c] = in_i[r][c] * round(g[r]) for up to three 16-bit matrices that share their rows' factor (the heads' logit gradients times the
+// upstream gradient of a row's loss: PyTorch's `d * g.to(d.dtype)`, one rounding of the product); reward rows lag the others by `lag` rows
+template <int DT>
+__global__ __launch_bounds__(256) void k_scale_rows3(const uint16_t* __restrict__ a, int wa, const uint16_t* __restrict__ b, int wb,
+                                                     const uint16_t* __restrict__ c, int wc, const float* __restrict__ g, int rows, int lag,
+                                                     uint16_t* __restrict__ oa, uint16_t* __restrict__ ob, uint16_t* __restrict__ oc) {
+  const int r = blockIdx.x;
+  const float f = tr_requant<DT>(g[r]);
+  for (int i = threadIdx.x; i < wa; i += blockDim.x) oa[(long long)r * wa + i] = tr_round<DT>(tr_load<DT>(a + (long long)r * wa + i) * f);
+  for (int i = threadIdx.x; i < wc; i += blockDim.x) oc[(long long)r * wc + i] = tr_round<DT>(tr_load<DT>(c + (long long)r * wc + i) * f);
+  if (b != nullptr && r >= lag)
+    for (int i = threadIdx.x; i < wb; i += blockDim.x)
+      ob[(long long)(r - lag) * wb + i] = tr_round<DT>(tr_load<DT>(b + (long long)(r - lag) * wb + i) * f);
+}
+
+extern "C" int hz_scale_rows3(const void* a, int width_a, const void* b, int width_b, const void* c, int width_c, const float* factor, int rows,
+                              int lag, void* out_a, void* out_b, void* out_c, int dtype, void* stream) {
+  HZ_REQUIRE(a && c && factor && out_a && out_c && (!b || out_b), "hz_scale_rows3: null pointer");
+  HZ_REQUIRE(rows >= 1 && width_a >= 1 && width_c >= 1 && lag >= 0 && lag < rows, "hz_scale_rows3: rows=%d lag=%d", rows, lag);
+  HZ_REQUIRE(dtype == HZ_BF16 || dtype == HZ_F16, "hz_scale_rows3: dtype %d (HZ_BF16 or HZ_F16)", dtype);
+  if (dtype == HZ_BF16)
+    hipLaunchKernelGGL(k_scale_rows3<HZ_BF16>, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)a, width_a, (const uint16_t*)b, width_b,
+                       (const uint16_t*)c, width_c, factor, rows, lag, (uint16_t*)out_a, (uint16_t*)out_b, (uint16_t*)out_c);
+  else
+    hipLaunchKernelGGL(k_scale_rows3<HZ_F16>, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)a, width_a, (const uint16_t*)b, width_b,
+                       (const uint16_t*)c, width_c, factor, rows, lag, (uint16_t*)out_a, (uint16_t*)out_b, (uint16_t*)out_c);
+  HZ_HIP(hipGetLastError());
+  return 0;
+}

@@ -196,8 +196,31 @@ class _UnrolledLosses(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, _gl, _gp):
         dv, dr, dp = ctx.saved_tensors
-        g = g.to(dv.dtype).unsqueeze(1)
-        return dv * g, dr * g[ctx.B:], dp * g, None, None, None, None, None, None
+        if g.dtype != torch.float32 or not g.is_contiguous():
+            g = g.float().contiguous()
+        ov, orr, op = torch.empty_like(dv), torch.empty_like(dr), torch.empty_like(dp)   # d * g.to(d.dtype) for the three, one launch
+        check(lib.hz_scale_rows3(dv.data_ptr(), dv.shape[1], dr.data_ptr(), dr.shape[1], dp.data_ptr(), dp.shape[1], g.data_ptr(), dv.shape[0],
+                                 ctx.B, ov.data_ptr(), orr.data_ptr(), op.data_ptr(), _DT[dv.dtype], _stream()), "hz_scale_rows3")
+        return ov, orr, op, None, None, None, None, None, None
+
+
+class _StateAction(torch.autograd.Function):
+    """[state | one-hot(action)]: the dynamics net's input (config/hanabi_control/model.py:215-219) in one launch; the gradient of the
+    state is the first H columns of the output's (a view)."""
+
+    @staticmethod
+    def forward(ctx, state, action, A):
+        B, H = state.shape
+        assert state.stride(1) == 1 and action.dtype == torch.int64 and action.shape[0] == B
+        out = torch.empty((B, H + A), dtype=state.dtype, device=state.device)
+        check(lib.hz_state_action_rows(state.data_ptr(), state.stride(0), action.data_ptr(), action.stride(0), B, H, A, out.data_ptr(), out.stride(0),
+                                       _DT[state.dtype], _stream()), "hz_state_action_rows")
+        ctx.H = H
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[:, :ctx.H], None, None
 
 
 class FusedTrainNet:
@@ -418,11 +441,8 @@ class FusedTrainNet:
         return NetworkOutput(value, [0.0] * obs.shape[0], policy, state)
 
     def _dynamics(self, hidden_state, action):  # config/hanabi_control/model.py:61-125 behind the one-hot concat of :215-219
-        B = hidden_state.shape[0]
-        one_hot = torch.zeros(B, self.A, dtype=self.dtype, device=hidden_state.device)
-        one_hot.scatter_(1, action, 1.0)
         early, b1, b2, b3 = self.dyn
-        sa = torch.cat((hidden_state, one_hot), 1)
+        sa = _StateAction.apply(hidden_state, action, self.A)
         y = _LinBNAct.apply(sa, hidden_state if early else None, b1, True)
         y = _LinBNAct.apply(y, None, b2, True)
         return _LinBNAct.apply(y, None if early else hidden_state, b3, True)

@@ -103,6 +103,17 @@ int hz_muzero_unrolled_losses(const void* value_logits, int64_t value_stride, co
                               int64_t target_policy_step_stride, const float* weights, float value_coeff, float reward_coeff,
                               float policy_coeff, void* d_value, void* d_reward, void* d_policy, float* losses, float* preds, void* stream);
 
+/* out[r] = [state[r] (hidden elements) | one-hot(action[r]) (num_actions elements)]: the dynamics net's input rows
+ * (config/hanabi_control/model.py:215-219) in one launch (PyTorch: zeros + scatter_ + cat).  16-bit; strides in elements. */
+int hz_state_action_rows(const void* state, int64_t state_stride, const int64_t* action, int64_t action_stride, int rows, int hidden,
+                         int num_actions, void* out, int64_t out_stride, int dtype, void* stream);
+
+/* out_x[r][:] = x[r][:] * round_to_dtype(factor[r]) for x = a, c (rows x width, contiguous) and b ((rows - lag) x width_b: its row r - lag
+ * takes factor[r]; NULL: none): the three heads' logit gradients times the upstream gradient of their row's loss in one launch
+ * (PyTorch: three `d * g.to(d.dtype).unsqueeze(1)`). */
+int hz_scale_rows3(const void* a, int width_a, const void* b, int width_b, const void* c, int width_c, const float* factor, int rows, int lag,
+                   void* out_a, void* out_b, void* out_c, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
