@@ -38,8 +38,21 @@ class _Block:
         self.lin, self.bn, self.uses = lin, bn, uses
         self.w16 = lin.weight.detach().to(dtype)
         self.b16 = lin.bias.detach().to(dtype)
+        self.x_stack = self.dy_stack = None
+        self.stack_uses = self.stack_rows = self.bwd_seen = 0
         self.scratch, self.groups = None, 1   # a call over several row groups (hz_bn_act_*_groups): what crosses the groups waits here
                                               # for hz_bn_groups_finish (FusedTrainNet._finish_groups)
+
+    def use_stacks(self, uses, rows, k_in):
+        """The block is used `uses` times per step on `rows` rows each (the dynamics net): its inputs and its pre-activation
+        gradients of all uses live in two stacked buffers, so that the weight gradient is ONE GEMM over uses x rows rows when
+        the last of them has been through its backward, not one per use."""
+        Cn = self.lin.weight.shape[0]
+        if self.x_stack is None or self.x_stack.shape != (uses * rows, k_in):
+            dev, dt = self.w16.device, self.w16.dtype
+            self.x_stack = torch.zeros((uses * rows, k_in), dtype=dt, device=dev)
+            self.dy_stack = torch.zeros((uses * rows, Cn), dtype=dt, device=dev)
+        self.stack_uses, self.stack_rows, self.bwd_seen = uses, rows, 0
 
     def group_scratch(self, groups):
         Cn = self.lin.weight.shape[0]
@@ -53,15 +66,19 @@ class _LinBNAct(torch.autograd.Function):
     """out = act(batch_norm(x @ W^T + b) + res): forward GEMM + hz_bn_act_forward; backward hz_bn_act_backward + two GEMMs."""
 
     @staticmethod
-    def forward(ctx, x, res, blk, relu, anchor=None, groups=1):
+    def forward(ctx, x, res, blk, relu, anchor=None, groups=1, use=None, out_to=None):
         """anchor: any tensor that requires grad (the parameters do not enter autograd here: the first block of a forward, whose
         input is data, needs one for its output to be part of the graph); its gradient is None.
         groups: x stacks that many batches (the hidden states of the unrolled step's inferences): ONE GEMM over all rows, the
-        BatchNorm of each batch with its own statistics -- the arithmetic of `groups` calls of the module."""
+        BatchNorm of each batch with its own statistics -- the arithmetic of `groups` calls of the module.
+        use (with _Block.use_stacks): this is the block's use number `use` of the step -- x is slot `use` of its input stack, and its
+        weight gradient waits for the other uses; out_to: the block whose input stack takes this block's output (slot `use`)."""
         bn = blk.bn
         y = torch.addmm(blk.b16, x, blk.w16.t())
-        out = torch.empty_like(y)
         rows, Cn = y.shape
+        if use is not None:
+            assert x.data_ptr() == blk.x_stack[use * blk.stack_rows].data_ptr() and rows == blk.stack_rows
+        out = torch.empty_like(y) if out_to is None else out_to.x_stack[use * rows:(use + 1) * rows]
         assert rows % groups == 0
         B = rows // groups
         stats = torch.empty((2, groups, Cn), dtype=torch.float32, device=y.device)
@@ -74,7 +91,7 @@ class _LinBNAct(torch.autograd.Function):
                                            stats[0].data_ptr(), stats[1].data_ptr(), None if scratch is None else scratch.data_ptr(),
                                            int(relu), _DT[y.dtype], _stream()),
               "hz_bn_act_forward_groups")
-        ctx.blk, ctx.relu, ctx.has_res, ctx.groups = blk, relu, res is not None, groups
+        ctx.blk, ctx.relu, ctx.has_res, ctx.groups, ctx.use = blk, relu, res is not None, groups, use
         ctx.save_for_backward(x, y, out, stats)
         return out
 
@@ -89,7 +106,8 @@ class _LinBNAct(torch.autograd.Function):
             dout = dout.contiguous()
         rows, Cn = y.shape
         groups = ctx.groups
-        dy = torch.empty_like(y)
+        use = ctx.use
+        dy = torch.empty_like(y) if use is None else blk.dy_stack[use * rows:(use + 1) * rows]
         dres = torch.empty_like(y) if ctx.has_res else None
         scratch = blk.group_scratch(groups) if groups > 1 else None
         check(lib.hz_bn_act_backward_groups(dout.data_ptr(), dout.stride(0), out.data_ptr(), out.stride(0), y.data_ptr(), y.stride(0),
@@ -99,9 +117,15 @@ class _LinBNAct(torch.autograd.Function):
                                             None if scratch is None else scratch.data_ptr(), int(ctx.relu), _DT[y.dtype], _stream()),
               "hz_bn_act_backward_groups")
         g = blk.lin.weight.grad                                # W.grad += dy^T x: ONE GEMM, 16-bit operands, fp32 accumulate and output
-        torch.addmm(g, dy.t(), x, out_dtype=torch.float32, out=g)
+        if use is None:
+            torch.addmm(g, dy.t(), x, out_dtype=torch.float32, out=g)
+        else:                                                  # ... over all uses of the step at once, when the last one is through
+            blk.bwd_seen += 1
+            if blk.bwd_seen == blk.stack_uses:
+                torch.addmm(g, blk.dy_stack.t(), blk.x_stack, out_dtype=torch.float32, out=g)
+                blk.bwd_seen = 0
         dx = torch.mm(dy, blk.w16) if ctx.needs_input_grad[0] else None
-        return dx, dres, None, None, None, None
+        return dx, dres, None, None, None, None, None, None
 
 
 class _Lin(torch.autograd.Function):
@@ -209,10 +233,10 @@ class _StateAction(torch.autograd.Function):
     state is the first H columns of the output's (a view)."""
 
     @staticmethod
-    def forward(ctx, state, action, A):
+    def forward(ctx, state, action, A, use=None, out_to=None):
         B, H = state.shape
         assert state.stride(1) == 1 and action.dtype == torch.int64 and action.shape[0] == B
-        out = torch.empty((B, H + A), dtype=state.dtype, device=state.device)
+        out = torch.empty((B, H + A), dtype=state.dtype, device=state.device) if out_to is None else out_to.x_stack[use * B:(use + 1) * B]
         check(lib.hz_state_action_rows(state.data_ptr(), state.stride(0), action.data_ptr(), action.stride(0), B, H, A, out.data_ptr(), out.stride(0),
                                        _DT[state.dtype], _stream()), "hz_state_action_rows")
         ctx.H = H
@@ -220,7 +244,7 @@ class _StateAction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        return g[:, :ctx.H], None, None
+        return g[:, :ctx.H], None, None, None, None
 
 
 class FusedTrainNet:
@@ -325,7 +349,7 @@ class FusedTrainNet:
         state = self._run(self.rep, obs_batch.reshape(B, -1).to(self.dtype))
         states = [state]
         for k in range(U):
-            state = self._dynamics(state, action_batch[:, k:k + 1])
+            state = self._dynamics(state, action_batch[:, k:k + 1], k, U)
             state.register_hook(lambda grad: grad * 0.5)  # train.py:169 (the hook sees the heads' share and the next step's)
             states.append(state)
         stacked = torch.cat(states, 0)                    # [(U + 1) B, H]
@@ -440,12 +464,25 @@ class FusedTrainNet:
         value, _, policy = self._heads(state, False)
         return NetworkOutput(value, [0.0] * obs.shape[0], policy, state)
 
-    def _dynamics(self, hidden_state, action):  # config/hanabi_control/model.py:61-125 behind the one-hot concat of :215-219
+    def _dynamics(self, hidden_state, action, use=None, uses=0):
+        """config/hanabi_control/model.py:61-125 behind the one-hot concat of :215-219.  use / uses: step `use` of the `uses` unroll
+        steps of a learner step -- the three blocks keep their inputs and pre-activation gradients in stacks and take their weight
+        gradients in one GEMM each over all steps (_Block.use_stacks)."""
         early, b1, b2, b3 = self.dyn
-        sa = _StateAction.apply(hidden_state, action, self.A)
-        y = _LinBNAct.apply(sa, hidden_state if early else None, b1, True)
-        y = _LinBNAct.apply(y, None, b2, True)
-        return _LinBNAct.apply(y, None if early else hidden_state, b3, True)
+        if use is None:
+            sa = _StateAction.apply(hidden_state, action, self.A)
+            y = _LinBNAct.apply(sa, hidden_state if early else None, b1, True)
+            y = _LinBNAct.apply(y, None, b2, True)
+            return _LinBNAct.apply(y, None if early else hidden_state, b3, True)
+        if use == 0:
+            B, H = hidden_state.shape
+            b1.use_stacks(uses, B, H + self.A)
+            b2.use_stacks(uses, B, b1.lin.weight.shape[0])
+            b3.use_stacks(uses, B, b2.lin.weight.shape[0])
+        sa = _StateAction.apply(hidden_state, action, self.A, use, b1)
+        y = _LinBNAct.apply(sa, hidden_state if early else None, b1, True, None, 1, use, b2)
+        y = _LinBNAct.apply(y, None, b2, True, None, 1, use, b3)
+        return _LinBNAct.apply(y, None if early else hidden_state, b3, True, None, 1, use, None)
 
     def recurrent_inference(self, hidden_state, action):  # core/model.py:74-84, training branch
         state = self._dynamics(hidden_state, action)
