@@ -836,7 +836,8 @@ def main():
                     ("deep_paths_full8192", "full8192", args.dtype, "sharp"),
                     # the engines inside the contract's 1e-3 of the reference's fp32 nets: hand-written recurrent kernel / library GEMMs
                     ("fp16x2", args.workload, "fp16x2", "random"), ("fp32", args.workload, "fp32", "random"),
-                    ("small4096", "small4096", args.dtype, "random")]   # BASELINE configs[1]'s game at 4096 envs
+                    ("small4096", "small4096", args.dtype, "random"),   # BASELINE configs[1]'s game at 4096 envs
+                    ("full5p2048", "full5p2048", args.dtype, "random")]   # configs[4]'s game (A = 48), the self-play part alone
             plan = [p for k, p in enumerate(plan) if p[1:] not in [q[1:] for q in plan[:k]]]
         for name, wl, dt, net in plan:
             r = Run(args, wl, dt, device, 0, 1, net=net)
