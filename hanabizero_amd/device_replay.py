@@ -167,7 +167,7 @@ class DeviceReplay:
         probs = self.priority[self.tail:self.head] ** self.alpha
         probs = probs / probs.sum()
         keys = probs / torch.empty_like(probs).exponential_(1.0, generator=self.gen)
-        idx = torch.topk(keys, batch_size, sorted=False).indices
+        idx = _topk_indices(keys, batch_size)
         w = (total * probs[idx]) ** (-beta)
         return idx + (self.tail + self.origin), (w / w.max()).to(torch.float32)
 
@@ -258,6 +258,26 @@ class DeviceReplay:
         mask = torch.empty(R * (U + 1), dtype=torch.bool, device=self.device)
         self.windows_seq(phys, U + 1, 0, out_windows, slot_elems=slot_elems, legal_out=legal, valid_out=mask)
         return legal, mask
+
+
+def _topk_indices(keys, k):
+    """Indices of the k largest keys (any order).  torch.topk over a replay of the reference's size (25 M positions, float64) is a
+    2-ms radix select -- longer than the learner's step.  Exact shortcut: cut the keys into chunks; an element outside the k chunks
+    with the largest maxima cannot beat the k-th of those maxima, so the k largest lie inside those k chunks (or in the ragged
+    tail behind the last whole chunk): one row-maximum pass, a gather of k chunks, a top-k over k x chunk candidates
+    (25 M positions: 1.9 -> 0.3 ms).  Small replays take torch.topk."""
+    n = keys.numel()
+    if n < (1 << 18) or n < 16 * k:
+        return torch.topk(keys, k, sorted=False).indices
+    chunk = min(4096, 1 << ((n // (4 * k)).bit_length() - 1))       # >= 4 k chunks, each a power of two long
+    C = n // chunk
+    rows = keys[:C * chunk].view(C, chunk)
+    best = torch.topk(rows.amax(1), k, sorted=False).indices          # the k chunks that can hold winners
+    cand = torch.cat((rows[best].reshape(-1), keys[C * chunk:]))      # ... and the tail (< chunk elements)
+    inner = torch.topk(cand, k, sorted=False).indices
+    in_rows = inner < k * chunk
+    safe = torch.where(in_rows, inner, torch.zeros_like(inner))
+    return torch.where(in_rows, best[safe // chunk] * chunk + safe % chunk, inner - k * chunk + C * chunk)
 
 
 def policy_re_device(config, engine, windows, legal, mask, noises=None, generator=None, tie_seed=0, padded=False, roots=None):

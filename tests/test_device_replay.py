@@ -294,3 +294,20 @@ def test_streams_on_distinct_queues_run_side_by_side():
     # (on this pool: three candidates join the first stream -- four hardware queues; asserted loosely: a timing test must not be
     # what turns the suite red on a box whose runtime hands out queues differently)
     assert len(accepted) >= 1, (one, pairs)
+
+
+@pytest.mark.parametrize("n", [300_001, 1_048_576, 5_000_003])
+def test_chunked_top_k_of_the_sampler_is_exact(n):
+    """device_replay._topk_indices (the k chunks with the largest maxima hold the k largest keys: what keeps prioritised sampling at
+    a fraction of a millisecond on a replay of the reference's 25 M positions) == torch.topk, as a set -- with a cluster of
+    maximum-priority positions (freshly ingested games) and winners in the ragged tail behind the last whole chunk."""
+    from hanabizero_amd.device_replay import _topk_indices
+    g = torch.Generator(device="cuda").manual_seed(n)
+    p = (torch.rand(n, device="cuda", dtype=torch.float64, generator=g) + 0.01) ** 0.6
+    p[n // 2:n // 2 + n // 80] = p.max() * 1.5
+    p[-40:] = p.max() * 1e4      # (so heavy that the ragged tail is sure to hold winners)
+    keys = p / torch.empty_like(p).exponential_(1.0, generator=g)
+    got = torch.sort(_topk_indices(keys, 256)).values
+    want = torch.sort(torch.topk(keys, 256, sorted=False).indices).values
+    assert torch.equal(got, want)
+    assert bool((want >= n - 40).any()), "the case is meant to have winners in the tail"
